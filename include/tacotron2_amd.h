@@ -1,0 +1,232 @@
+/* tacotron2_amd.h - C ABI of libtacotron2_amd.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * Tacotron 2 hot path of mattm458/tacotron2.
+ *
+ * The reference has NO native/FFI boundary: its hot path is nn.Module composition
+ * (model/encoder.py, model/attention.py, model/decoder.py, model/postnet.py, model/tacotron2.py) and every
+ * device kernel is an implicit ATen call.  This header is therefore the boundary a maintainer would bind
+ * (ctypes) from those modules' forward()s; each entry cites the reference lines whose
+ * ATen sequence it replaces.
+ *
+ * Conventions
+ *  - plain C: raw DEVICE pointers, ints, floats; no torch / C++ types.  `stream` is a hipStream_t passed as
+ *    void* (NULL = default stream).  Kernels are enqueued on it; nothing here synchronises or allocates
+ *    (workspaces are passed in), so every entry is safe inside stream capture and re-entrant per stream.
+ *  - every function returns 0 on success, a T2_ERR_* code otherwise, and never throws; t2_last_error()
+ *    returns a human-readable message for the calling thread.
+ *  - all floating point is fp32 (north_star), row-major, channel-last: (B,L,C) / (B,T,C); sequence stashes
+ *    used by the frame loop are time-major [t][b][...].  LSTM gate order is PyTorch's i,f,g,o and weight
+ *    matrices are [out][in] exactly as in the reference state_dict.
+ *  - dropout is always an explicit *scale mask* tensor (0 or 1/(1-p)); NULL = identity.  Masks come from
+ *    t2_philox_mask in production or from the caller in parity tests (SURVEY.md section 7 "Dropout RNG parity").
+ */
+#ifndef TACOTRON2_AMD_H
+#define TACOTRON2_AMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T2_OK 0
+#define T2_ERR_ARG 1     /* bad argument / unsupported shape */
+#define T2_ERR_LAUNCH 2  /* HIP launch or runtime error */
+
+const char* t2_last_error(void);
+int t2_version(void);
+int t2_sizeof(const char* struct_name); /* sizeof of an ABI struct by name, -1 if unknown */
+
+/* ------------------------------------------------------------------------------------------------
+ * Generic fp32 MFMA GEMM:  C[M,N] (op)= alpha * A[M,K] x B[K,N]  (+ bias[n] + bias2[n]) (relu) (* mask[m,n])
+ * Used for every dense contraction of the path: nn.Linear / nn.Conv1d (as GEMM over overlapping
+ * channel-last rows) forward, dgrad and wgrad (model/tacotron2.py:85-92,229; model/encoder.py:33-39;
+ * model/postnet.py:9-15; model/decoder.py:26-51 hoisted input projections).
+ *   a_kmajor=1: A element (m,k) at A[m*lda + k];  a_kmajor=0: at A[k*lda + m]
+ *   b_kmajor=1: B element (k,n) at B[n*ldb + k];  b_kmajor=0: at B[k*ldb + n]
+ *   accumulate: 0 store, 1 C += result (plain), 2 C += result (fp32 atomics; required when splitk > 1)
+ *   batch > 1: blockIdx.z strides A,B,C by sA,sB,sC elements.
+ */
+typedef struct {
+    const float* A; const float* B; float* C;
+    int M, N, K;
+    int64_t lda, ldb, ldc;
+    int a_kmajor, b_kmajor;
+    float alpha;
+    const float* bias; const float* bias2;
+    const float* mulmask; int64_t ldmask;
+    int relu;
+    int accumulate;
+    int splitk;
+    int batch; int64_t sA, sB, sC;
+} T2Gemm;
+int t2_gemm(const T2Gemm* g, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * One LSTM-cell step (nn.LSTMCell / one time step of nn.LSTM), M = batch rows on the MFMA M axis:
+ *   gates[b][:] = pre[b][:] + bias1 + bias2 + sum_s x_s[b][0:K_s] . W_s[row][0:K_s]      (i,f,g,o blocks of H)
+ *   c' = f*c + i*g ; h' = o*tanh(c') ; h' *= drop[b][:]         (the dropped h is the carried h,
+ *                                                                model/decoder.py:75,101,114,118)
+ * Replaces model/decoder.py:70-75 (att_rnn), :94-101 (lstm) and one step of model/encoder.py:64.
+ * `len`/`t` (optional): rows with t >= len[b] are inactive: h' = c' = 0 (packed-sequence semantics,
+ * model/encoder.py:61-65).
+ */
+typedef struct { const float* x; int64_t ldx; const float* w; int64_t ldw; int K; } T2Seg;
+typedef struct {
+    int B, H;
+    int nseg; T2Seg seg[3];
+    const float* pre; int64_t ldpre;
+    const float* bias1; const float* bias2;
+    const float* c_prev; int64_t ldc_prev;
+    const float* drop; int64_t lddrop;
+    float* h_out; int64_t ldh;       /* post-dropout h */
+    float* h_out2; int64_t ldh2;     /* optional second copy (NULL to skip) */
+    float* c_out; int64_t ldc_out;
+    float* gates_out; int64_t ldg;   /* optional stash of activated gates [b][4H] for backward */
+    const int32_t* len; int t;       /* optional activity predicate */
+} T2LstmStep;
+/* n = 1 or 2 independent cells in one launch (the two directions of the encoder BiLSTM). */
+int t2_lstm_step_fwd(const T2LstmStep* steps, int n, void* stream);
+
+/* S consecutive steps of a recurrence: step s uses base[i] with every non-NULL pointer advanced by
+ * s * inc[i].<field> ELEMENTS (negative = time-descending, the reverse BiLSTM direction) and t += s*dt.
+ * Replaces the packed nn.LSTM of model/encoder.py:59-65 and, with hoisted input projections, the
+ * decoder-LSTMCell recurrence of model/decoder.py:94-101 over all frames (model/tacotron2.py:276-317). */
+typedef struct {
+    int64_t seg_x[3]; int64_t pre, c_prev, drop, h_out, h_out2, c_out, gates_out; int dt;
+} T2LstmStride;
+int t2_lstm_seq_fwd(const T2LstmStep* base, const T2LstmStride* inc, int n, int S, void* stream);
+
+/* One step of back-propagation through time for an LSTM cell (autograd of the cells above):
+ *   dx[b][u] = sum_n dg_next[b][n] * W[n*ldw + u]          (n over N4 = 4H' rows of the producing cell)
+ *   epi = 0: dx_out = dx + ext1 + ext2                      (gradient w.r.t. a non-recurrent input slice)
+ *   epi = 1: dh = (dx + ext1 + ext2) * drop; pointwise cell backward with the stashed activations of
+ *            step t -> dg_out[b][4H] (pre-activation gate grads), dc[b][H] updated in place.
+ * dg_next may be NULL (last frame: no recurrent contribution). */
+typedef struct {
+    int B, H, N4;
+    const float* dg_next; int64_t lddg;
+    const float* W; int64_t ldw;
+    int ncols; int epi;
+    const float* ext1; int64_t ldx1; const float* ext2; int64_t ldx2;
+    float* dx_out; int64_t lddx;
+    const float* drop; int64_t lddrop;
+    const float* gates; int64_t ldgs;
+    const float* c_prev; int64_t ldcp; const float* c_cur; int64_t ldcc;
+    float* dc; int64_t lddc;
+    float* dg_out; int64_t ldgo;
+    const int32_t* len; int t;
+} T2LstmBwdStep;
+int t2_lstm_step_bwd(const T2LstmBwdStep* steps, int n, void* stream);
+typedef struct { int64_t dg, ext1, ext2, drop, gates, c_prev, c_cur; int dt; } T2LstmBwdStride;
+/* S steps; base[i].dg_next == NULL at entry, afterwards each step consumes the dg_out of the previous one. */
+int t2_lstm_seq_bwd(const T2LstmBwdStep* base, const T2LstmBwdStride* inc, int n, int S, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Location-sensitive attention, one frame (model/attention.py:52-69 + cumulative update model/decoder.py:78-90).
+ *   U   [Ad][2][Kl]  = location_dense.weight . location_conv.weight, folded once per forward by
+ *                      t2_attn_fold_location (pure re-association of two linear maps)
+ *   pmT [B][Ad][L]   = processed memory (att_encoder output, model/tacotron2.py:229) stored transposed
+ *   len [B] int32    : positions l >= len[b] are masked to -inf before the softmax (model/attention.py:63)
+ *   e_part           : workspace [B][Ad/16][L];  th_out: optional stash [B][Ad][L] of tanh(.) for backward
+ * Writes w_out (new attention weights = the alignments row), cum_out = cum_prev + w, ctx_out (context). */
+typedef struct {
+    int B, L, A, Ad, Ef, Kl;
+    const float* att_h; int64_t ldh;
+    const float* Wq; const float* U; const float* v;
+    const float* w_prev; int64_t ldw;        /* NULL = zeros (first frame) */
+    const float* cum_prev; int64_t ldcum;    /* NULL = zeros */
+    const float* pmT; const float* memory; const int32_t* len;
+    float* e_part; float* th_out;
+    float* w_out; int64_t ldwo; float* cum_out; int64_t ldco;
+    float* ctx_out; int64_t ldctx; float* ctx_out2; int64_t ldctx2;
+} T2AttnStep;
+int t2_attn_fold_location(const float* Wd, const float* Wc, float* U, int Ad, int F, int Kl, void* stream);
+int t2_attn_step_fwd(const T2AttnStep* s, void* stream);
+
+/* Teacher-forced attention chain over all T frames (the attention half of the loop at
+ * model/tacotron2.py:276-317; in teacher-forced mode it does not depend on the decoder LSTM, so the two
+ * recurrences are run as separate chains with their input projections hoisted into large GEMMs).
+ * Time-major stashes use slot s = t+1; the caller zero-fills slot 0 (initial states, model/tacotron2.py:126-153).
+ *   pre   [T][B][4A]     prenet part of att_rnn.weight_ih + both biases (hoisted GEMM)
+ *   xdec  [T+1][B][A+Ef] cols [0,A) = att_h_t (post-dropout), cols [A,A+Ef) = context_t
+ *   att_c [T+1][B][A], gates [T][B][4A] (activated, optional), cum [T+1][B][L], th [T][B][Ad][L] (optional)
+ *   align [B][T][L]      the alignments output
+ *   xproj_ctx            optional second copy of context_t, row (t,b) at xproj_ctx[(t*B+b)*ld_xproj] */
+typedef struct {
+    int B, L, T, A, Ad, Ef, Kl;
+    const float* W_ih_ctx; int64_t ld_wih;
+    const float* W_hh; const float* Wq; const float* U; const float* v;
+    const float* pre; const float* pmT; const float* memory; const int32_t* len;
+    const float* att_drop;
+    float* xdec; float* att_c; float* gates; float* align; float* cum; float* th;
+    float* xproj_ctx; int64_t ld_xproj;
+    float* e_part;
+} T2AttnSeq;
+int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Conv stacks (encoder model/encoder.py:31-46,57; postnet model/postnet.py:8-49).
+ * Activations use the padded channel-last layout (B, Lp = L+4, C): data rows [2, L+2), zero rows elsewhere, so a
+ * k=5 'same' Conv1d is one t2_gemm with overlapping A rows (lda = C, K = 5C) against packed weights.
+ *   t2_pack_conv_weight   flip=0: wp[co][k*Ci+ci] = w[co][ci][k]  (forward / wgrad layout)
+ *                         flip=1: wp[ci][(K-1-k)*Co+co] = w[co][ci][k]  (dgrad: correlation with the flipped kernel)
+ *   t2_unpack_conv_wgrad  g[co][ci][k] += gp[co][k*Ci+ci]
+ */
+int t2_embedding_fwd(const int64_t* idx, const float* table, float* out, int B, int L, int E, int pad, void* stream);
+int t2_embedding_bwd(const int64_t* idx, const float* dout, float* dtable, int B, int L, int E, int Lp, int pad, void* stream);
+int t2_pack_conv_weight(const float* w, float* wp, int Co, int Ci, int K, int flip, void* stream);
+int t2_unpack_conv_wgrad(const float* gp, float* g, int Co, int Ci, int K, void* stream);
+
+/* BatchNorm1d (+ activation + dropout mask [+ residual + length mask]) over the B*L valid rows of a raw conv
+ * output in shifted row layout (row b*Lp_x + l).  training: batch statistics incl. padded positions, running
+ * stats updated with momentum (unbiased variance), exactly nn.BatchNorm1d; eval: running statistics.
+ * forward  (t2_bn_fwd): y[b][pad_y + l][c] = mask(act(bn(x))*drop + res); pad rows of y are zero-filled.
+ * backward (t2_bn_bwd): dx (grad w.r.t. x, written at rows b*Lp_dx + pad_dx + l, other rows zero), dgamma/dbeta +=.
+ * act: 0 none, 1 relu, 2 tanh.  sums: workspace of 2*C doubles. */
+typedef struct {
+    int B, L, C;
+    const float* x; int Lp_x;
+    const float* gamma; const float* beta;
+    float* running_mean; float* running_var;
+    int training; float momentum, eps;
+    double* sums;
+    float* mean; float* invstd;
+    int act;
+    const float* drop;
+    const float* res; int Lp_res, pad_res;
+    const int32_t* len; float fill;
+    float* y; int Lp_y, pad_y;
+    const float* dy; int Lp_dy, pad_dy;
+    float* dx; int Lp_dx, pad_dx;
+    float* dgamma; float* dbeta;
+} T2Bn;
+int t2_bn_fwd(const T2Bn* s, void* stream);
+int t2_bn_bwd(const T2Bn* s, void* stream);
+
+/* small data-movement / pointwise pieces of model/tacotron2.py:201-212,255,327-345 and model/tts_model.py:197-201 */
+int t2_colsum(const float* x, int64_t ld, int64_t R, int C, float* out, void* stream);          /* out[c] += sum_r x[r][c] */
+int t2_mel_to_tm(const float* mel, float* out, int B, int T, int M, void* stream);              /* (B,T,M) -> [T+1][B][M], slot 0 = 0 */
+int t2_swap01(const float* in, float* out, int D0, int D1, int C, int accumulate, void* stream); /* (D0,D1,C) -> (D1,D0,C) */
+int t2_finalize_fwd(const float* proj, const int32_t* len, float* mels, float* gates, float* post_in, int B, int T, int M,
+                    void* stream);
+int t2_finalize_bwd(const float* dpost_in, float* dproj, int B, int T, int M, void* stream);
+int t2_loss_fwd_bwd(const float* mels, const float* post, const float* gates, const float* mel_tgt, const float* gate_tgt,
+                    const int32_t* len, int B, int T, int M, double* loss3 /* gate, mel, post */, float* d_post, float* dproj,
+                    float grad_scale, void* stream);
+int t2_relu_mask_bwd(const float* g, const float* y, const float* mask, float* out, int64_t n, void* stream);
+int t2_condition_fwd(const float* enc, const float* spk_table, const int32_t* spk, const float* desc, float* memory, int B,
+                     int L, int E, int Ef, void* stream);
+int t2_condition_bwd(const float* dmem, const float* memory, const int32_t* spk, float* denc, float* dspk_table, float* ddesc,
+                     int B, int L, int E, int Ef, void* stream);
+int t2_tanh_bias(float* x, const float* bias, int64_t rows, int C, void* stream);
+int t2_tanh_bwd(const float* g, const float* y, float* out, int64_t n, void* stream);
+
+/* dropout scale masks (Philox4x32-10, counter = element index) and the optimizer of model/tts_model.py:78-91 +
+ * Lightning gradient_clip_val=1.0 (run/train.py:240) on one flat fp32 parameter buffer. */
+int t2_philox_mask(float* out, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream);
+int t2_sumsq(const float* g, int64_t n, double* out, void* stream);
+int t2_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq, float max_norm, float lr,
+                 float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

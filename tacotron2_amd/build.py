@@ -1,0 +1,61 @@
+"""Build recipe for libtacotron2_amd.so (hand-written gfx950 HIP kernels behind a C ABI, include/tacotron2_amd.h).
+
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the build container; the resulting .so sits
+in-tree (git-ignored) and travels to the GPU box with the snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libtacotron2_amd.so")
+SOURCES = ["t2_error.cpp", "t2_gemm.hip", "t2_lstm.hip", "t2_attention.hip", "t2_elementwise.hip", "t2_logmel.hip",
+           "t2_infer.hip"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "tacotron2_amd.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not force and not _stale():
+        return LIB
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    objdir = os.path.join(HERE, "..", "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    procs = []
+    for s in srcs:
+        o = os.path.join(objdir, os.path.basename(s) + ".o")
+        objs.append(o)
+        if not force and os.path.exists(o) and os.path.getmtime(o) > max(
+                os.path.getmtime(s), os.path.getmtime(os.path.join(CSRC, "t2_common.hpp")),
+                os.path.getmtime(os.path.join(HERE, "..", "include", "tacotron2_amd.h"))):
+            continue
+        cmd = [hipcc] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {s}:\n{out}")
+        if verbose and out.strip():
+            print(out)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

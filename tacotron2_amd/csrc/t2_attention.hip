@@ -1,0 +1,268 @@
+// Location-sensitive attention step for gfx950 (replaces the ~14 ATen ops of model/attention.py:52-69 and
+// the cumulative-weight update of model/decoder.py:78-90).
+//
+// Each sample's step is spread over many CUs so that the encoder memory (L x Ef fp32, ~330 KB/sample) is
+// streamed by 16 workgroups instead of one (per-CU L2/HBM bandwidth is the limit for a single workgroup):
+//
+//  attn_energy_kernel   grid (B, Ad/16)   workgroup (b, j) owns 16 attention dims for ALL positions l:
+//     q[a]      = Wq[a][:] . att_h[b][:]                           (wave-wide dot products, 16-byte loads)
+//     loc[l][a] = sum_{c,k} U[a][c][k] * in[c][l+k-15]             (U = location_dense . location_conv folded
+//                                                                   once per forward; sliding register window,
+//                                                                   4 positions x 62 taps per work item)
+//     th[l][a]  = tanh(q[a] + loc[l][a] + pmT[b][a][l]);  partial energy e_j[l] = sum_a v[a] * th[l][a]
+//     (processed memory is kept transposed [b][a][l] so these reads are contiguous in l)
+//  attn_context_kernel  grid (B, Ef/32)   workgroup (b, s): e[l] = sum_j e_j[l], mask l >= len -> -inf,
+//     softmax over l (block reductions, LDS-staged), then its 32-column slice of
+//     context[b][e] = sum_l w[l] * memory[b][l][e]  (128-byte coalesced rows), slice 0 also writes the new
+//     weights (the alignments row) and cumulative weights.
+#include "t2_common.hpp"
+
+int t2_lstm_step_fwd_launch(const T2LstmStep* steps, int n, hipStream_t st);
+int t2_lstm_step_bwd_launch(const T2LstmBwdStep* steps, int n, hipStream_t st);
+
+namespace {
+
+constexpr int KL = 31, KPAD = 15;
+
+struct AttnK {
+    int B, L, A, Ad, Ef;
+    const float* att_h; long ldh;
+    const float* Wq; const float* U; const float* v;
+    const float* w_prev; long ldw; const float* cum_prev; long ldcum;
+    const float* pmT; const float* memory; const int32_t* len;
+    float* e_part; float* th_out;
+    float* w_out; long ldwo; float* cum_out; long ldco;
+    float* ctx_out; long ldctx; float* ctx_out2; long ldctx2;
+};
+
+__global__ __launch_bounds__(256) void attn_energy_kernel(AttnK p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x, j = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int L = p.L, NG = (L + 3) >> 2, Lp = 4 * NG + 36;
+    float* inp = sm;             // [2][Lp]   zero-haloed (w_prev, cum_prev)
+    float* Us = inp + 2 * Lp;    // [16][64]  folded location filter rows of this slice
+    float* qs = Us + 16 * 64;    // [16]
+    float* ec = qs + 16;         // [16][4*NG] per-dim energy contributions
+
+    {   // phase 1: query projection for this slice (4 dims per wave)
+        const float* h = p.att_h + (long)b * p.ldh;
+        for (int aa = 0; aa < 4; ++aa) {
+            const int a = j * 16 + w * 4 + aa;
+            const float* wq = p.Wq + (long)a * p.A;
+            float s = 0.f;
+            for (int k = lane * 4; k < p.A; k += 256) {
+                const f32x4 hv = *reinterpret_cast<const f32x4*>(h + k);
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wq + k);
+                s += hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + hv[3] * wv[3];
+            }
+            s = t2_wave_sum(s);
+            if (lane == 0) qs[w * 4 + aa] = s;
+        }
+    }
+    for (int idx = tid; idx < 2 * Lp; idx += 256) {
+        const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
+        float val = 0.f;
+        if (l >= 0 && l < L) {
+            const float* src = c == 0 ? p.w_prev : p.cum_prev;
+            const long ld = c == 0 ? p.ldw : p.ldcum;
+            if (src) val = src[(long)b * ld + l];
+        }
+        inp[idx] = val;
+    }
+    for (int idx = tid; idx < 16 * 64; idx += 256) {
+        const int al = idx >> 6, kk = idx & 63;
+        Us[idx] = kk < 2 * KL ? p.U[(long)(j * 16 + al) * 2 * KL + kk] : 0.f;
+    }
+    __syncthreads();
+
+    const int items = 16 * NG;
+    for (int item = tid; item < items; item += 256) {
+        const int al = item / NG, lg = item - al * NG;
+        const int a = j * 16 + al;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float win[36];
+            const f32x4* wp = reinterpret_cast<const f32x4*>(inp + c * Lp + 4 * lg);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const f32x4 t = wp[i];
+                win[4 * i] = t[0]; win[4 * i + 1] = t[1]; win[4 * i + 2] = t[2]; win[4 * i + 3] = t[3];
+            }
+            const float* u = Us + al * 64 + c * KL;
+#pragma unroll
+            for (int k = 0; k < KL; ++k) {
+                const float uk = u[k];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = fmaf(uk, win[i + k], acc[i]);
+            }
+        }
+        const float qa = qs[al], va = p.v[a];
+        const long rowoff = ((long)b * p.Ad + a) * L;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int l = 4 * lg + i;
+            if (l < L) {
+                const float th = tanhf(qa + acc[i] + p.pmT[rowoff + l]);
+                if (p.th_out) p.th_out[rowoff + l] = th;
+                ec[al * 4 * NG + l] = va * th;
+            }
+        }
+    }
+    __syncthreads();
+    for (int l = tid; l < L; l += 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int al = 0; al < 16; ++al) s += ec[al * 4 * NG + l];
+        p.e_part[((long)b * gridDim.y + j) * L + l] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_context_kernel(AttnK p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x, es0 = blockIdx.y * 32, tid = threadIdx.x;
+    const int L = p.L, NA = p.Ad >> 4;
+    float* ws = sm;                       // [L rounded to 4]
+    float* red = ws + ((L + 3) & ~3);     // [8]
+    float* part = red + 8;                // [8][32]
+    const int len = p.len[b];
+    float mx = -INFINITY;
+    for (int l = tid; l < L; l += 256) {
+        float e = 0.f;
+        for (int j = 0; j < NA; ++j) e += p.e_part[((long)b * NA + j) * L + l];
+        if (l >= len) e = -INFINITY;
+        ws[l] = e;
+        mx = fmaxf(mx, e);
+    }
+    mx = t2_block_max(mx, red);
+    float sum = 0.f;
+    for (int l = tid; l < L; l += 256) {
+        const float pe = expf(ws[l] - mx);
+        ws[l] = pe;
+        sum += pe;
+    }
+    sum = t2_block_sum(sum, red);
+    for (int l = tid; l < L; l += 256) {
+        const float wv = ws[l] / sum;
+        ws[l] = wv;
+        if (blockIdx.y == 0) {
+            p.w_out[(long)b * p.ldwo + l] = wv;
+            if (p.cum_out) p.cum_out[(long)b * p.ldco + l] = (p.cum_prev ? p.cum_prev[(long)b * p.ldcum + l] : 0.f) + wv;
+        }
+    }
+    __syncthreads();
+    const int el = tid & 31, lg = tid >> 5;
+    float acc = 0.f;
+    const float* mp = p.memory + (long)b * L * p.Ef + es0 + el;
+    for (int l = lg; l < L; l += 8) acc = fmaf(ws[l], mp[(long)l * p.Ef], acc);
+    part[lg * 32 + el] = acc;
+    __syncthreads();
+    if (tid < 32) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) s += part[g * 32 + tid];
+        p.ctx_out[(long)b * p.ldctx + es0 + tid] = s;
+        if (p.ctx_out2) p.ctx_out2[(long)b * p.ldctx2 + es0 + tid] = s;
+    }
+}
+
+// U[a][c][k] = sum_f Wd[a][f] * Wc[f][c][k]
+__global__ void fold_location_kernel(const float* Wd, const float* Wc, float* U, int Ad, int F, int CK) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Ad * CK) return;
+    const int a = idx / CK, ck = idx - a * CK;
+    float s = 0.f;
+    for (int f = 0; f < F; ++f) s = fmaf(Wd[a * F + f], Wc[f * CK + ck], s);
+    U[idx] = s;
+}
+
+int check_attn(const T2AttnStep& s) {
+    T2_REQUIRE(s.B >= 1 && s.L >= 1 && s.L <= 768, "attention: need 1 <= L <= 768");
+    T2_REQUIRE(s.Kl == KL, "attention: location kernel size must be 31 (model/decoder.py:36)");
+    T2_REQUIRE(s.Ad % 16 == 0 && s.Ef % 32 == 0 && s.A % 4 == 0, "attention: need Ad%16==0, Ef%32==0, A%4==0");
+    T2_REQUIRE(s.ldh % 4 == 0 && t2_aligned16(s.att_h) && t2_aligned16(s.Wq), "attention: att_h/Wq alignment");
+    T2_REQUIRE(s.e_part && s.w_out && s.ctx_out && s.pmT && s.memory && s.len && s.U && s.v, "attention: null operand");
+    return T2_OK;
+}
+
+void to_ak(const T2AttnStep& s, AttnK& k) {
+    k.B = s.B; k.L = s.L; k.A = s.A; k.Ad = s.Ad; k.Ef = s.Ef;
+    k.att_h = s.att_h; k.ldh = s.ldh; k.Wq = s.Wq; k.U = s.U; k.v = s.v;
+    k.w_prev = s.w_prev; k.ldw = s.ldw; k.cum_prev = s.cum_prev; k.ldcum = s.ldcum;
+    k.pmT = s.pmT; k.memory = s.memory; k.len = s.len; k.e_part = s.e_part; k.th_out = s.th_out;
+    k.w_out = s.w_out; k.ldwo = s.ldwo; k.cum_out = s.cum_out; k.ldco = s.ldco;
+    k.ctx_out = s.ctx_out; k.ldctx = s.ldctx; k.ctx_out2 = s.ctx_out2; k.ldctx2 = s.ldctx2;
+}
+
+int launch_attn(const T2AttnStep& s, hipStream_t st) {
+    AttnK k;
+    to_ak(s, k);
+    const int NG = (s.L + 3) >> 2, Lp = 4 * NG + 36;
+    const size_t sm_e = (size_t)(2 * Lp + 16 * 64 + 16 + 16 * 4 * NG) * sizeof(float);
+    const size_t sm_c = (size_t)(((s.L + 3) & ~3) + 8 + 256) * sizeof(float);
+    hipLaunchKernelGGL(attn_energy_kernel, dim3(s.B, s.Ad / 16), dim3(256), sm_e, st, k);
+    hipLaunchKernelGGL(attn_context_kernel, dim3(s.B, s.Ef / 32), dim3(256), sm_c, st, k);
+    T2_CHECK_LAUNCH();
+    return T2_OK;
+}
+
+}  // namespace
+
+int t2_attn_step_launch(const T2AttnStep* s, hipStream_t st) {
+    T2_TRY(check_attn(*s));
+    return launch_attn(*s, st);
+}
+
+extern "C" int t2_attn_fold_location(const float* Wd, const float* Wc, float* U, int Ad, int F, int Kl, void* stream) {
+    T2_REQUIRE(Wd && Wc && U && Ad > 0 && F > 0 && Kl > 0, "t2_attn_fold_location: bad arguments");
+    const int n = Ad * 2 * Kl;
+    hipLaunchKernelGGL(fold_location_kernel, dim3(t2_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, Wd, Wc, U, Ad, F,
+                       2 * Kl);
+    T2_CHECK_LAUNCH();
+    return T2_OK;
+}
+
+extern "C" int t2_attn_step_fwd(const T2AttnStep* s, void* stream) {
+    T2_REQUIRE(s != nullptr, "t2_attn_step_fwd: null");
+    return t2_attn_step_launch(s, (hipStream_t)stream);
+}
+
+// Teacher-forced attention chain over all T frames: per frame  attention-LSTMCell -> energies -> softmax/context.
+extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
+    T2_REQUIRE(a != nullptr, "t2_attn_seq_fwd: null");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = a->B, L = a->L, T = a->T, A = a->A, Ef = a->Ef, Ad = a->Ad;
+    const long ldx = A + Ef;
+    for (int t = 0; t < T; ++t) {
+        T2LstmStep s;
+        memset(&s, 0, sizeof(s));
+        s.B = B; s.H = A; s.nseg = 2;
+        const float* slot = a->xdec + (long)t * B * ldx;
+        float* slot1 = a->xdec + (long)(t + 1) * B * ldx;
+        s.seg[0].x = slot + A; s.seg[0].ldx = ldx; s.seg[0].w = a->W_ih_ctx; s.seg[0].ldw = a->ld_wih; s.seg[0].K = Ef;
+        s.seg[1].x = slot; s.seg[1].ldx = ldx; s.seg[1].w = a->W_hh; s.seg[1].ldw = A; s.seg[1].K = A;
+        s.pre = a->pre + (long)t * B * 4 * A; s.ldpre = 4 * A;
+        s.c_prev = a->att_c + (long)t * B * A; s.ldc_prev = A;
+        if (a->att_drop) { s.drop = a->att_drop + (long)t * B * A; s.lddrop = A; }
+        s.h_out = slot1; s.ldh = ldx;
+        s.c_out = a->att_c + (long)(t + 1) * B * A; s.ldc_out = A;
+        if (a->gates) { s.gates_out = a->gates + (long)t * B * 4 * A; s.ldg = 4 * A; }
+        T2_TRY(t2_lstm_step_fwd_launch(&s, 1, st));
+
+        T2AttnStep q;
+        memset(&q, 0, sizeof(q));
+        q.B = B; q.L = L; q.A = A; q.Ad = Ad; q.Ef = Ef; q.Kl = a->Kl;
+        q.att_h = slot1; q.ldh = ldx; q.Wq = a->Wq; q.U = a->U; q.v = a->v;
+        if (t > 0) { q.w_prev = a->align + (long)(t - 1) * L; q.ldw = (long)T * L; }
+        q.cum_prev = a->cum + (long)t * B * L; q.ldcum = L;
+        q.pmT = a->pmT; q.memory = a->memory; q.len = a->len; q.e_part = a->e_part;
+        if (a->th) q.th_out = a->th + (long)t * B * Ad * L;
+        q.w_out = a->align + (long)t * L; q.ldwo = (long)T * L;
+        q.cum_out = a->cum + (long)(t + 1) * B * L; q.ldco = L;
+        q.ctx_out = slot1 + A; q.ldctx = ldx;
+        if (a->xproj_ctx) { q.ctx_out2 = a->xproj_ctx + (long)t * B * a->ld_xproj; q.ldctx2 = a->ld_xproj; }
+        if (t == 0) T2_TRY(check_attn(q));
+        T2_TRY(launch_attn(q, st));
+    }
+    return T2_OK;
+}

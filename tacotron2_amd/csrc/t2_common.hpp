@@ -1,0 +1,103 @@
+// Shared host/device helpers for the gfx950 Tacotron 2 kernels.  CDNA4 only: 64-lane wavefronts,
+// fp32-input MFMA (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32), no other targets.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/tacotron2_amd.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define T2_WAVE 64
+
+// Every C-ABI entry returns an int status (0 = ok) and never throws; see include/tacotron2_amd.h.
+#define T2_CHECK_LAUNCH()                                                     \
+    do {                                                                      \
+        hipError_t e__ = hipGetLastError();                                   \
+        if (e__ != hipSuccess) {                                              \
+            t2_set_error(hipGetErrorString(e__), __FILE__, __LINE__);         \
+            return T2_ERR_LAUNCH;                                             \
+        }                                                                     \
+    } while (0)
+
+#define T2_REQUIRE(cond, msg)                                                 \
+    do {                                                                      \
+        if (!(cond)) {                                                        \
+            t2_set_error(msg, __FILE__, __LINE__);                            \
+            return T2_ERR_ARG;                                                \
+        }                                                                     \
+    } while (0)
+
+#define T2_TRY(expr)                                                          \
+    do {                                                                      \
+        int rc__ = (expr);                                                    \
+        if (rc__ != 0) return rc__;                                           \
+    } while (0)
+
+void t2_set_error(const char* msg, const char* file, int line);
+
+static inline int t2_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline bool t2_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float t2_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float t2_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float t2_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double t2_wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block-wide sum; `red` is >= (blockDim.x/64) floats of LDS.  All threads get the result.
+__device__ __forceinline__ float t2_block_sum(float v, float* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = t2_wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
+}
+__device__ __forceinline__ float t2_block_max(float v, float* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = t2_wave_max(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float s = red[0];
+    for (int i = 1; i < nw; ++i) s = fmaxf(s, red[i]);
+    return s;
+}
+
+// Philox4x32-10 counter RNG (Salmon et al. 2011); one call -> 4 x 32 random bits.
+__device__ __forceinline__ void t2_philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                           uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}

@@ -1,0 +1,589 @@
+// HBM-bound elementwise / reduction kernels of the Tacotron 2 path for gfx950: embedding gather, Conv1d weight
+// packing for the conv-as-GEMM formulation, BatchNorm1d (batch statistics over ALL rows incl. padding, as the
+// reference does), activation/dropout epilogues, output masking, the 3-term loss, Philox dropout masks and
+// the flat-buffer Adam step.  All accesses are coalesced along the channel axis (channel-last tensors).
+//
+// Conv stacks use one padded activation layout: (B, Lp = L+4, C), data rows [2, L+2), zero rows elsewhere.
+// A 'same' k=5 convolution is then ONE GEMM whose A rows overlap: row r = b*Lp + l of A is the 5*C contiguous
+// floats starting at padded row r (lda = C, K = 5C); outputs land in the 'shifted' row layout r = b*Lp + l
+// (l < L valid, 4 junk rows per sample that every consumer skips or zeroes).
+#include "t2_common.hpp"
+
+namespace {
+
+__global__ void embedding_fwd_kernel(const int64_t* idx, const float* table, float* out, int B, int L, int E, int pad) {
+    const int Lp = L + 2 * pad;
+    const long n = (long)B * Lp * E;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(i % E);
+        const long row = i / E;
+        const int lp = (int)(row % Lp), b = (int)(row / Lp);
+        const int l = lp - pad;
+        float v = 0.f;
+        if (l >= 0 && l < L) v = table[idx[(long)b * L + l] * E + e];
+        out[i] = v;
+    }
+}
+
+// dtable[idx] += dout (rows of the padded buffer); padding_idx row 0 receives nothing (model/encoder.py:25)
+__global__ void embedding_bwd_kernel(const int64_t* idx, const float* dout, float* dtable, int B, int L, int E, int Lp,
+                                     int pad) {
+    const long n = (long)B * L * E;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(i % E);
+        const long row = i / E;
+        const int l = (int)(row % L), b = (int)(row / L);
+        const int64_t id = idx[row];
+        if (id != 0) atomicAdd(&dtable[id * E + e], dout[((long)b * Lp + pad + l) * E + e]);
+    }
+}
+
+__global__ void pack_conv_w_kernel(const float* w, float* wp, int Co, int Ci, int K, int flip) {
+    const long n = (long)Co * Ci * K;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const int ci = (int)((i / K) % Ci);
+        const int co = (int)(i / ((long)K * Ci));
+        if (!flip) wp[(long)co * K * Ci + (long)k * Ci + ci] = w[i];
+        else wp[(long)ci * K * Co + (long)(K - 1 - k) * Co + co] = w[i];
+    }
+}
+
+__global__ void unpack_conv_wgrad_kernel(const float* gp, float* g, int Co, int Ci, int K) {
+    const long n = (long)Co * Ci * K;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const int ci = (int)((i / K) % Ci);
+        const int co = (int)(i / ((long)K * Ci));
+        g[i] += gp[(long)co * K * Ci + (long)k * Ci + ci];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm1d
+// ---------------------------------------------------------------------------------------------
+struct BnK {
+    int B, L, C;
+    const float* x; int Lp_x;             // raw conv output, shifted rows b*Lp_x + l
+    const float* gamma; const float* beta;
+    float* rmean; float* rvar;            // running stats (read in eval, updated in training)
+    int training; float momentum, eps;
+    double* sums;                         // [2][C]
+    float* mean; float* invstd;           // [C] saved batch stats (training) / derived from running (eval)
+    int act;                              // 0 none, 1 relu, 2 tanh
+    const float* drop;                    // dense [B][L][C] scale mask or null
+    const float* res; int Lp_res, pad_res;  // optional residual added after dropout
+    const int32_t* len; float fill;       // optional: rows l >= len[b] are set to `fill`
+    float* y; int Lp_y, pad_y;            // output; pad rows are zero-filled
+    // backward
+    const float* dy; int Lp_dy, pad_dy;
+    float* dx; int Lp_dx, pad_dx;
+    float* dgamma; float* dbeta;
+};
+
+// grid (ceil(C/64), row chunks); block 256 = 64 channels x 4 row lanes
+__global__ __launch_bounds__(256) void bn_stats_kernel(BnK p, int rows_per_block) {
+    __shared__ float s1[4][64], s2[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const long R = (long)p.B * p.L;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block; if (r1 > R) r1 = R;
+    float a = 0.f, q = 0.f;
+    if (c < p.C) {
+        for (long r = r0 + rl; r < r1; r += 4) {
+            const int b = (int)(r / p.L), l = (int)(r % p.L);
+            const float v = p.x[((long)b * p.Lp_x + l) * p.C + c];
+            a += v; q = fmaf(v, v, q);
+        }
+    }
+    s1[rl][cl] = a; s2[rl][cl] = q;
+    __syncthreads();
+    if (rl == 0 && c < p.C) {
+        const double sa = (double)s1[0][cl] + s1[1][cl] + s1[2][cl] + s1[3][cl];
+        const double sq = (double)s2[0][cl] + s2[1][cl] + s2[2][cl] + s2[3][cl];
+        atomicAdd(&p.sums[c], sa);
+        atomicAdd(&p.sums[p.C + c], sq);
+    }
+}
+
+__global__ void bn_finalize_kernel(BnK p) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= p.C) return;
+    if (p.training) {
+        const double n = (double)p.B * p.L;
+        const double m = p.sums[c] / n;
+        double var = p.sums[p.C + c] / n - m * m;
+        if (var < 0) var = 0;
+        p.mean[c] = (float)m;
+        p.invstd[c] = (float)(1.0 / sqrt(var + (double)p.eps));
+        if (p.rmean) {
+            const double unb = n > 1 ? var * n / (n - 1) : var;
+            p.rmean[c] = (1.f - p.momentum) * p.rmean[c] + p.momentum * (float)m;
+            p.rvar[c] = (1.f - p.momentum) * p.rvar[c] + p.momentum * (float)unb;
+        }
+    } else {
+        p.mean[c] = p.rmean[c];
+        p.invstd[c] = 1.f / sqrtf(p.rvar[c] + p.eps);
+    }
+}
+
+__global__ void bn_apply_kernel(BnK p) {
+    const long n = (long)p.B * p.Lp_y * p.C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % p.C);
+        const long row = i / p.C;
+        const int lp = (int)(row % p.Lp_y), b = (int)(row / p.Lp_y);
+        const int l = lp - p.pad_y;
+        float v = 0.f;
+        if (l >= 0 && l < p.L) {
+            const float xv = p.x[((long)b * p.Lp_x + l) * p.C + c];
+            v = (xv - p.mean[c]) * p.invstd[c] * p.gamma[c] + p.beta[c];
+            if (p.act == 1) v = fmaxf(v, 0.f);
+            else if (p.act == 2) v = tanhf(v);
+            if (p.drop) v *= p.drop[((long)b * p.L + l) * p.C + c];
+            if (p.res) v += p.res[((long)b * p.Lp_res + p.pad_res + l) * p.C + c];
+            if (p.len && l >= p.len[b]) v = p.fill;
+        }
+        p.y[i] = v;
+    }
+}
+
+// dz = dy * drop * act'(bn(x)); sums[0][c] = sum dz, sums[1][c] = sum dz * xhat
+__device__ __forceinline__ float bn_dz(const BnK& p, int b, int l, int c, float& xhat) {
+    const float xv = p.x[((long)b * p.Lp_x + l) * p.C + c];
+    xhat = (xv - p.mean[c]) * p.invstd[c];
+    float g = p.dy[((long)b * p.Lp_dy + p.pad_dy + l) * p.C + c];
+    if (p.drop) g *= p.drop[((long)b * p.L + l) * p.C + c];
+    const float pre = xhat * p.gamma[c] + p.beta[c];
+    if (p.act == 1) g = pre > 0.f ? g : 0.f;
+    else if (p.act == 2) { const float t = tanhf(pre); g *= (1.f - t * t); }
+    return g;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnK p, int rows_per_block) {
+    __shared__ float s1[4][64], s2[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const long R = (long)p.B * p.L;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block; if (r1 > R) r1 = R;
+    float a = 0.f, q = 0.f;
+    if (c < p.C) {
+        for (long r = r0 + rl; r < r1; r += 4) {
+            const int b = (int)(r / p.L), l = (int)(r % p.L);
+            float xh;
+            const float dz = bn_dz(p, b, l, c, xh);
+            a += dz; q = fmaf(dz, xh, q);
+        }
+    }
+    s1[rl][cl] = a; s2[rl][cl] = q;
+    __syncthreads();
+    if (rl == 0 && c < p.C) {
+        atomicAdd(&p.sums[c], (double)s1[0][cl] + s1[1][cl] + s1[2][cl] + s1[3][cl]);
+        atomicAdd(&p.sums[p.C + c], (double)s2[0][cl] + s2[1][cl] + s2[2][cl] + s2[3][cl]);
+    }
+}
+
+__global__ void bn_bwd_apply_kernel(BnK p) {
+    const long n = (long)p.B * p.Lp_dx * p.C;
+    const float invn = 1.f / ((float)p.B * (float)p.L);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % p.C);
+        const long row = i / p.C;
+        const int lp = (int)(row % p.Lp_dx), b = (int)(row / p.Lp_dx);
+        const int l = lp - p.pad_dx;
+        float v = 0.f;
+        if (l >= 0 && l < p.L) {
+            float xh;
+            const float dz = bn_dz(p, b, l, c, xh);
+            const float gi = p.gamma[c] * p.invstd[c];
+            if (p.training) v = gi * (dz - (float)p.sums[c] * invn - xh * (float)p.sums[p.C + c] * invn);
+            else v = gi * dz;
+        }
+        p.dx[i] = v;
+        if (lp == 0 && b == 0) {   // one thread per channel folds the parameter gradients
+            p.dbeta[c] += (float)p.sums[c];
+            p.dgamma[c] += (float)p.sums[p.C + c];
+        }
+    }
+}
+
+void to_bnk(const T2Bn* s, BnK& k) {
+    k.B = s->B; k.L = s->L; k.C = s->C; k.x = s->x; k.Lp_x = s->Lp_x; k.gamma = s->gamma; k.beta = s->beta;
+    k.rmean = s->running_mean; k.rvar = s->running_var; k.training = s->training; k.momentum = s->momentum; k.eps = s->eps;
+    k.sums = s->sums; k.mean = s->mean; k.invstd = s->invstd; k.act = s->act; k.drop = s->drop;
+    k.res = s->res; k.Lp_res = s->Lp_res; k.pad_res = s->pad_res; k.len = s->len; k.fill = s->fill;
+    k.y = s->y; k.Lp_y = s->Lp_y; k.pad_y = s->pad_y; k.dy = s->dy; k.Lp_dy = s->Lp_dy; k.pad_dy = s->pad_dy;
+    k.dx = s->dx; k.Lp_dx = s->Lp_dx; k.pad_dx = s->pad_dx; k.dgamma = s->dgamma; k.dbeta = s->dbeta;
+}
+
+inline int ew_grid(long n) { long g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
+
+// ---------------------------------------------------------------------------------------------
+// misc elementwise
+// ---------------------------------------------------------------------------------------------
+// column sums: out[c] += sum_r x[r*ld + c]   (bias gradients)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* x, long ld, long R, int C, float* out, int rows_per_block) {
+    __shared__ float s1[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block; if (r1 > R) r1 = R;
+    float a = 0.f;
+    if (c < C) for (long r = r0 + rl; r < r1; r += 4) a += x[r * ld + c];
+    s1[rl][cl] = a;
+    __syncthreads();
+    if (rl == 0 && c < C) atomicAdd(&out[c], s1[0][cl] + s1[1][cl] + s1[2][cl] + s1[3][cl]);
+}
+
+// (B,T,M) batch-major -> [T+1][B][M] time-major with a zero frame at slot 0 (F.pad(mel,(0,0,1,0)), model/tacotron2.py:255)
+__global__ void mel_to_tm_kernel(const float* mel, float* out, int B, int T, int M) {
+    const long n = (long)(T + 1) * B * M;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i % M);
+        const long row = i / M;
+        const int b = (int)(row % B), s = (int)(row / B);
+        out[i] = s == 0 ? 0.f : mel[((long)b * T + (s - 1)) * M + m];
+    }
+}
+
+// generic (D0, D1, C) -> (D1, D0, C) transpose (mask / gradient re-layout between batch- and time-major)
+__global__ void swap01_kernel(const float* in, float* out, int D0, int D1, int C, int accumulate) {
+    const long n = (long)D0 * D1 * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long row = i / C;
+        const int d1 = (int)(row % D1), d0 = (int)(row / D1);
+        const long o = ((long)d1 * D0 + d0) * C + c;
+        if (accumulate) out[o] += in[i]; else out[o] = in[i];
+    }
+}
+
+// proj [T][B][M+1] (time-major, col M = stop logit) -> mels (B,T,M) masked 0, gates (B,T,1) masked -1000,
+// postnet input (B,T+4,M) padded layout holding the UNMASKED mels (model/tacotron2.py:327-345)
+__global__ void finalize_fwd_kernel(const float* proj, const int32_t* len, float* mels, float* gates, float* post_in,
+                                    int B, int T, int M) {
+    const int Tp = T + 4, M1 = M + 1;
+    const long n = (long)B * Tp * M1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i % M1);
+        const long row = i / M1;
+        const int tp = (int)(row % Tp), b = (int)(row / Tp);
+        const int t = tp - 2;
+        const bool in = t >= 0 && t < T;
+        const float v = in ? proj[((long)t * B + b) * M1 + m] : 0.f;
+        if (m < M) {
+            if (post_in) post_in[((long)b * Tp + tp) * M + m] = v;
+            if (in) mels[((long)b * T + t) * M + m] = (t >= len[b]) ? 0.f : v;
+        } else if (in) {
+            gates[(long)b * T + t] = (t >= len[b]) ? -1000.f : v;
+        }
+    }
+}
+
+// Loss (model/tts_model.py:197-201) and its gradient in one pass.
+//   loss = mean BCEWithLogits(gates, gate_tgt) + mean (mels - tgt)^2 + mean (post - tgt)^2   (padding included)
+// Gradients are w.r.t. the UNDERLYING (pre-masking) tensors: masked positions are constants -> zero gradient.
+//   d_post (B,T,M) dense;  dproj [T][B][M+1] time-major gets d_mels + d_post in cols < M and d_gate in col M.
+__global__ __launch_bounds__(256) void loss_kernel(const float* mels, const float* post, const float* gates, const float* mel_tgt,
+                                                   const float* gate_tgt, const int32_t* len, int B, int T, int M,
+                                                   double* loss3, float* d_post, float* dproj, float gscale) {
+    __shared__ double red[3][4];
+    const long nm = (long)B * T * M, ng = (long)B * T;
+    const float sm = 1.f / (float)nm, sg = 1.f / (float)ng;
+    double a_g = 0, a_m = 0, a_p = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nm + ng; i += (long)gridDim.x * blockDim.x) {
+        if (i < nm) {
+            const int m = (int)(i % M);
+            const long row = i / M;
+            const int t = (int)(row % T), b = (int)(row / T);
+            const bool masked = t >= len[b];
+            const float tg = mel_tgt[i];
+            const float e1 = mels[i] - tg, e2 = post[i] - tg;
+            a_m += (double)e1 * e1; a_p += (double)e2 * e2;
+            const float g1 = masked ? 0.f : 2.f * e1 * sm * gscale;
+            const float g2 = masked ? 0.f : 2.f * e2 * sm * gscale;
+            if (d_post) d_post[i] = g2;
+            if (dproj) dproj[((long)t * B + b) * (M + 1) + m] = g1 + g2;
+        } else {
+            const long r = i - nm;
+            const int t = (int)(r % T), b = (int)(r / T);
+            const bool masked = t >= len[b];
+            const float x = gates[r], y = gate_tgt[r];
+            a_g += (double)(fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x))));
+            const float g = masked ? 0.f : (t2_sigmoid(x) - y) * sg * gscale;
+            if (dproj) dproj[((long)t * B + b) * (M + 1) + M] = g;
+        }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    a_g = t2_wave_sum_d(a_g); a_m = t2_wave_sum_d(a_m); a_p = t2_wave_sum_d(a_p);
+    if (lane == 0) { red[0][w] = a_g; red[1][w] = a_m; red[2][w] = a_p; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const double s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        atomicAdd(&loss3[threadIdx.x], s / (threadIdx.x == 0 ? (double)ng : (double)nm));
+    }
+}
+
+// Gradient of finalize + postnet residual: dproj[t][b][m] += dpost_in[b][t][m]  (dpost_in in shifted rows b*Tp + t)
+__global__ void finalize_bwd_kernel(const float* dpost_in, float* dproj, int B, int T, int M) {
+    const int Tp = T + 4;
+    const long n = (long)B * T * M;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i % M);
+        const long row = i / M;
+        const int t = (int)(row % T), b = (int)(row / T);
+        dproj[((long)t * B + b) * (M + 1) + m] += dpost_in[((long)b * Tp + t) * M + m];
+    }
+}
+
+// out = relu'(y) * mask * g   (prenet layers: y is the stored post-dropout output; y > 0 <=> pre-activation > 0 and kept)
+__global__ void relu_mask_bwd_kernel(const float* g, const float* y, const float* mask, float* out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = y[i] > 0.f ? g[i] * (mask ? mask[i] : 1.f) : 0.f;
+}
+
+// speaker conditioning: enc[b][l][:E] = tanh(enc + emb[spk[b]]) (model/tacotron2.py:202), written into the first E
+// columns of memory (B,L,Ef); description vector d[b][0:Ef-E] broadcast into the remaining columns (:203-212)
+__global__ void condition_fwd_kernel(const float* enc, const float* spk_table, const int32_t* spk, const float* desc,
+                                     float* memory, int B, int L, int E, int Ef) {
+    const long n = (long)B * L * Ef;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(i % Ef);
+        const long row = i / Ef;
+        const int b = (int)(row / L);
+        float v;
+        if (e < E) {
+            v = enc[row * E + e];
+            if (spk_table) v = tanhf(v + spk_table[(long)spk[b] * E + e]);
+        } else {
+            v = desc[(long)b * (Ef - E) + (e - E)];
+        }
+        memory[i] = v;
+    }
+}
+
+// backward of the above: denc = dmem[:, :, :E] * (1 - mem^2) (if speakers), dspk_table[spk[b]] += sum_l denc,
+// ddesc[b][:] += sum_l dmem[b][l][E:]
+__global__ void condition_bwd_kernel(const float* dmem, const float* memory, const int32_t* spk, int has_spk, float* denc,
+                                     float* dspk_table, float* ddesc, int B, int L, int E, int Ef) {
+    const int b = blockIdx.x;
+    for (int e = threadIdx.x; e < Ef; e += blockDim.x) {
+        float acc = 0.f;
+        for (int l = 0; l < L; ++l) {
+            const long i = ((long)b * L + l) * Ef + e;
+            float g = dmem[i];
+            if (e < E) {
+                if (has_spk) { const float m = memory[i]; g *= (1.f - m * m); }
+                denc[((long)b * L + l) * E + e] = g;
+            }
+            acc += g;
+        }
+        if (e < E) { if (has_spk) atomicAdd(&dspk_table[(long)spk[b] * E + e], acc); }
+        else if (ddesc) ddesc[(long)b * (Ef - E) + (e - E)] = acc;
+    }
+}
+
+__global__ void tanh_bias_kernel(float* x, const float* bias, long rows, int C) {
+    const long n = rows * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        x[i] = tanhf(x[i] + (bias ? bias[i % C] : 0.f));
+}
+__global__ void tanh_bwd_kernel(const float* g, const float* y, float* out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = g[i] * (1.f - y[i] * y[i]);
+}
+
+// scale mask: 0 with probability p, 1/(1-p) otherwise; Philox4x32-10 keyed by (seed, stream), counter = element/4
+__global__ void philox_mask_kernel(float* out, long n, float p, uint64_t seed, uint64_t stream_id) {
+    const float keep_scale = 1.f / (1.f - p);
+    const long n4 = (n + 3) / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        uint32_t r[4];
+        t2_philox4((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32), (uint32_t)seed,
+                   (uint32_t)(seed >> 32), r);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long e = 4 * i + j;
+            if (e < n) {
+                const float u = (float)(r[j] >> 8) * (1.0f / 16777216.0f);   // [0,1)
+                out[e] = u < p ? 0.f : keep_scale;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// optimizer: global-norm clip + Adam with L2-in-gradient weight decay on one flat fp32 buffer
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, double* out) {
+    __shared__ double red[4];
+    double a = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const double v = g[i];
+        a += v * v;
+    }
+    a = t2_wave_sum_d(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n, const double* sumsq, float max_norm,
+                            float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, float gscale) {
+    float clip = 1.f;
+    if (sumsq && max_norm > 0.f) {
+        const float tot = (float)sqrt(*sumsq) * gscale;
+        const float c = max_norm / (tot + 1e-6f);
+        clip = c < 1.f ? c : 1.f;
+    }
+    clip *= gscale;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float pv = p[i];
+        const float gr = g[i] * clip + wd * pv;
+        const float mv = b1 * m[i] + (1.f - b1) * gr;
+        const float vv = b2 * v[i] + (1.f - b2) * gr * gr;
+        m[i] = mv; v[i] = vv;
+        p[i] = pv - lr * (mv / bc1) / (sqrtf(vv / bc2) + eps);
+    }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int t2_embedding_fwd(const int64_t* idx, const float* table, float* out, int B, int L, int E, int pad, void* stream) {
+    T2_REQUIRE(idx && table && out, "t2_embedding_fwd: null");
+    hipLaunchKernelGGL(embedding_fwd_kernel, dim3(ew_grid((long)B * (L + 2 * pad) * E)), dim3(256), 0, ST, idx, table, out, B, L, E, pad);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
+extern "C" int t2_embedding_bwd(const int64_t* idx, const float* dout, float* dtable, int B, int L, int E, int Lp, int pad, void* stream) {
+    T2_REQUIRE(idx && dout && dtable, "t2_embedding_bwd: null");
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(ew_grid((long)B * L * E)), dim3(256), 0, ST, idx, dout, dtable, B, L, E, Lp, pad);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
+extern "C" int t2_pack_conv_weight(const float* w, float* wp, int Co, int Ci, int K, int flip, void* stream) {
+    T2_REQUIRE(w && wp, "t2_pack_conv_weight: null");
+    hipLaunchKernelGGL(pack_conv_w_kernel, dim3(ew_grid((long)Co * Ci * K)), dim3(256), 0, ST, w, wp, Co, Ci, K, flip);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
+extern "C" int t2_unpack_conv_wgrad(const float* gp, float* g, int Co, int Ci, int K, void* stream) {
+    T2_REQUIRE(gp && g, "t2_unpack_conv_wgrad: null");
+    hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(ew_grid((long)Co * Ci * K)), dim3(256), 0, ST, gp, g, Co, Ci, K);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
+
+extern "C" int t2_bn_fwd(const T2Bn* s, void* stream) {
+    T2_REQUIRE(s && s->x && s->gamma && s->beta && s->mean && s->invstd && s->y, "t2_bn_fwd: null operand");
+    T2_REQUIRE(s->training ? (s->sums != nullptr) : (s->running_mean && s->running_var), "t2_bn_fwd: stats operands");
+    BnK k; to_bnk(s, k);
+    if (s->training) {
+        (void)hipMemsetAsync(s->sums, 0, sizeof(double) * 2 * s->C, ST);
+        const long R = (long)s->B * s->L;
+        const int rpb = 128;
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(t2_cdiv(s->C, 64), t2_cdiv(R, rpb)), dim3(256), 0, ST, k, rpb);
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(t2_cdiv(s->C, 256)), dim3(256), 0, ST, k);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid((long)s->B * s->Lp_y * s->C)), dim3(256), 0, ST, k);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
+
+extern "C" int t2_bn_bwd(const T2Bn* s, void* stream) {
+    T2_REQUIRE(s && s->x && s->gamma && s->beta && s->mean && s->invstd && s->dy && s->dx && s->sums && s->dgamma && s->dbeta,
+               "t2_bn_bwd: null operand");
+    BnK k; to_bnk(s, k);
+    (void)hipMemsetAsync(s->sums, 0, sizeof(double) * 2 * s->C, ST);
+    const long R = (long)s->B * s->L;
+    const int rpb = 128;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(t2_cdiv(s->C, 64), t2_cdiv(R, rpb)), dim3(256), 0, ST, k, rpb);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid((long)s->B * s->Lp_dx * s->C)), dim3(256), 0, ST, k);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
+
+extern "C" int t2_colsum(const float* x, int64_t ld, int64_t R, int C, float* out, void* stream) {
+    T2_REQUIRE(x && out && R > 0 && C > 0, "t2_colsum: bad arguments");
+    const int rpb = 256;
+    hipLaunchKernelGGL(colsum_kernel, dim3(t2_cdiv(C, 64), t2_cdiv(R, rpb)), dim3(256), 0, ST, x, (long)ld, (long)R, C, out, rpb);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
+extern "C" int t2_mel_to_tm(const float* mel, float* out, int B, int T, int M, void* stream) {
+    T2_REQUIRE(mel && out, "t2_mel_to_tm: null");
+    hipLaunchKernelGGL(mel_to_tm_kernel, dim3(ew_grid((long)(T + 1) * B * M)), dim3(256), 0, ST, mel, out, B, T, M);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
+extern "C" int t2_swap01(const float* in, float* out, int D0, int D1, int C, int accumulate, void* stream) {
+    T2_REQUIRE(in && out, "t2_swap01: null");
+    hipLaunchKernelGGL(swap01_kernel, dim3(ew_grid((long)D0 * D1 * C)), dim3(256), 0, ST, in, out, D0, D1, C, accumulate);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
+extern "C" int t2_finalize_fwd(const float* proj, const int32_t* len, float* mels, float* gates, float* post_in, int B, int T,
+                               int M, void* stream) {
+    T2_REQUIRE(proj && len && mels && gates, "t2_finalize_fwd: null");
+    hipLaunchKernelGGL(finalize_fwd_kernel, dim3(ew_grid((long)B * (T + 4) * (M + 1))), dim3(256), 0, ST, proj, len, mels, gates,
+                       post_in, B, T, M);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
+extern "C" int t2_loss_fwd_bwd(const float* mels, const float* post, const float* gates, const float* mel_tgt,
+                               const float* gate_tgt, const int32_t* len, int B, int T, int M, double* loss3, float* d_post,
+                               float* dproj, float grad_scale, void* stream) {
+    T2_REQUIRE(mels && post && gates && mel_tgt && gate_tgt && len && loss3, "t2_loss_fwd_bwd: null");
+    (void)hipMemsetAsync(loss3, 0, 3 * sizeof(double), ST);
+    hipLaunchKernelGGL(loss_kernel, dim3(ew_grid((long)B * T * (M + 1))), dim3(256), 0, ST, mels, post, gates, mel_tgt, gate_tgt,
+                       len, B, T, M, loss3, d_post, dproj, grad_scale);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
+extern "C" int t2_finalize_bwd(const float* dpost_in, float* dproj, int B, int T, int M, void* stream) {
+    T2_REQUIRE(dpost_in && dproj, "t2_finalize_bwd: null");
+    hipLaunchKernelGGL(finalize_bwd_kernel, dim3(ew_grid((long)B * T * M)), dim3(256), 0, ST, dpost_in, dproj, B, T, M);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
+extern "C" int t2_relu_mask_bwd(const float* g, const float* y, const float* mask, float* out, int64_t n, void* stream) {
+    T2_REQUIRE(g && y && out, "t2_relu_mask_bwd: null");
+    hipLaunchKernelGGL(relu_mask_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, g, y, mask, out, (long)n);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
+extern "C" int t2_condition_fwd(const float* enc, const float* spk_table, const int32_t* spk, const float* desc, float* memory,
+                                int B, int L, int E, int Ef, void* stream) {
+    T2_REQUIRE(enc && memory && (Ef == E || desc), "t2_condition_fwd: bad arguments");
+    hipLaunchKernelGGL(condition_fwd_kernel, dim3(ew_grid((long)B * L * Ef)), dim3(256), 0, ST, enc, spk_table, spk, desc, memory, B,
+                       L, E, Ef);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
+extern "C" int t2_condition_bwd(const float* dmem, const float* memory, const int32_t* spk, float* denc, float* dspk_table,
+                                float* ddesc, int B, int L, int E, int Ef, void* stream) {
+    T2_REQUIRE(dmem && memory && denc, "t2_condition_bwd: null");
+    hipLaunchKernelGGL(condition_bwd_kernel, dim3(B), dim3(256), 0, ST, dmem, memory, spk, dspk_table != nullptr, denc, dspk_table,
+                       ddesc, B, L, E, Ef);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
+extern "C" int t2_tanh_bias(float* x, const float* bias, int64_t rows, int C, void* stream) {
+    T2_REQUIRE(x, "t2_tanh_bias: null");
+    hipLaunchKernelGGL(tanh_bias_kernel, dim3(ew_grid(rows * C)), dim3(256), 0, ST, x, bias, (long)rows, C);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
+extern "C" int t2_tanh_bwd(const float* g, const float* y, float* out, int64_t n, void* stream) {
+    T2_REQUIRE(g && y && out, "t2_tanh_bwd: null");
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, g, y, out, (long)n);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
+extern "C" int t2_philox_mask(float* out, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream) {
+    T2_REQUIRE(out && n >= 0 && p >= 0.f && p < 1.f, "t2_philox_mask: bad arguments");
+    if (n == 0) return T2_OK;
+    hipLaunchKernelGGL(philox_mask_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, ST, out, (long)n, p, seed, stream_id);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
+extern "C" int t2_sumsq(const float* g, int64_t n, double* out, void* stream) {
+    T2_REQUIRE(g && out, "t2_sumsq: null");
+    (void)hipMemsetAsync(out, 0, sizeof(double), ST);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(ew_grid(n) > 1024 ? 1024 : ew_grid(n)), dim3(256), 0, ST, g, (long)n, out);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
+extern "C" int t2_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq, float max_norm, float lr,
+                            float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+    T2_REQUIRE(p && g && m && v && step >= 1, "t2_adam_step: bad arguments");
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, p, g, m, v, (long)n, sumsq, max_norm, lr, beta1, beta2, eps,
+                       weight_decay, bc1, bc2, grad_scale);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}

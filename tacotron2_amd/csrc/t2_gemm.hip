@@ -1,0 +1,245 @@
+// fp32 MFMA GEMM for gfx950 (v_mfma_f32_32x32x2_f32: exact fp32, 64 cycles / instruction / SIMD).
+//
+// Tile: 128 x 128 x 32 per 256-thread workgroup (4 waves, one per SIMD, 2 x 2 waves of 64 x 64, each wave
+// 2 x 2 MFMA tiles of 32 x 32 -> 64 accumulator registers).  LDS: two stages x (A tile + B tile), 73.7 KB, so
+// two workgroups are resident per CU.  Global -> register -> LDS staging with the next tile's global loads in
+// flight during the current tile's 64 MFMAs per wave.
+//
+// LDS images
+//   k-major operand (element (r,k) contiguous in k):  tile[r][36]  (32 k + 4 pad).  A lane reads its fragment
+//     as ONE ds_read_b128 = 4 consecutive k.  The K order inside a 32-deep tile is permuted consistently for A and B:
+//     k-group g (8 k's), lane half h reads k = 8g+4h .. 8g+4h+3 and MFMA step s uses element s, i.e. the k pair
+//     {8g+s, 8g+4+s}.  Row stride 36 dwords = 4*9 -> the 16-lane b128 groups hit 16 distinct 4-bank slots.
+//   m-major operand (element (r,k) contiguous in r):  tile[k][132]; fragment reads are conflict-free ds_read_b32
+//     (32 consecutive rows per lane half).
+//
+// blockIdx.x -> tile mapping is XCD-aware (8 XCDs, round-robin dispatch): the workgroups that land on one XCD
+// form a contiguous run of a grouped (8 m-tiles wide) tile order, so their A/B panels share that XCD's L2.
+#include "t2_common.hpp"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDK = BK + 4;    // k-major tile row stride
+constexpr int LDM = BM + 4;    // m-major tile row stride
+constexpr int TILE_FLOATS = BM * LDK;  // 4608 >= BK*LDM = 4224
+
+struct GemmK {
+    const float* A; const float* B; float* C;
+    int M, N, K;
+    long lda, ldb, ldc;
+    float alpha;
+    const float* bias; const float* bias2;
+    const float* mulmask; long ldmask;
+    int relu, accumulate, splitk;
+    long sA, sB, sC;
+    int a_vec, b_vec;
+    int ntm, ntn;
+};
+
+// Load 4 consecutive elements starting at p[0] with `nvalid` (<=4) of them in range.
+__device__ __forceinline__ f32x4 load4(const float* p, int nvalid, bool vec) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (nvalid >= 4 && vec) {
+        v = *reinterpret_cast<const f32x4*>(p);
+    } else {
+        if (nvalid > 0) v[0] = p[0];
+        if (nvalid > 1) v[1] = p[1];
+        if (nvalid > 2) v[2] = p[2];
+        if (nvalid > 3) v[3] = p[3];
+    }
+    return v;
+}
+
+// Stage one operand tile: global -> 4 x f32x4 registers.
+// KMAJ: rows r in [r0, r0+128), k in [k0, k0+32): idx = tid + 256*j, r = idx>>3, kq = idx&7
+// MMAJ: k rows kk in [k0,k0+32), r in [r0, r0+128): idx = tid + 256*j, kk = idx>>5, rq = idx&31
+template <bool KMAJ>
+__device__ __forceinline__ void stage_load(f32x4 (&reg)[4], const float* __restrict__ base, long ld, int r0, int k0,
+                                           int R, int Kend, bool vec, int tid) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = tid + 256 * j;
+        if (KMAJ) {
+            const int r = r0 + (idx >> 3), k = k0 + ((idx & 7) << 2);
+            int nv = (r < R) ? (Kend - k) : 0;
+            nv = nv < 0 ? 0 : nv;
+            reg[j] = load4(base + (long)r * ld + k, nv, vec);
+        } else {
+            const int k = k0 + (idx >> 5), r = r0 + ((idx & 31) << 2);
+            int nv = (k < Kend) ? (R - r) : 0;
+            nv = nv < 0 ? 0 : nv;
+            reg[j] = load4(base + (long)k * ld + r, nv, vec);
+        }
+    }
+}
+
+template <bool KMAJ>
+__device__ __forceinline__ void stage_store(const f32x4 (&reg)[4], float* tile, int tid) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = tid + 256 * j;
+        if (KMAJ) {
+            *reinterpret_cast<f32x4*>(tile + (idx >> 3) * LDK + ((idx & 7) << 2)) = reg[j];
+        } else {
+            *reinterpret_cast<f32x4*>(tile + (idx >> 5) * LDM + ((idx & 31) << 2)) = reg[j];
+        }
+    }
+}
+
+// Fragment for k-group g: 4 values (MFMA steps s=0..3) for tile row `row` (0..127), lane half h.
+template <bool KMAJ>
+__device__ __forceinline__ f32x4 frag(const float* tile, int row, int g, int h) {
+    if (KMAJ) {
+        return *reinterpret_cast<const f32x4*>(tile + row * LDK + 8 * g + 4 * h);
+    } else {
+        const float* p = tile + (8 * g + 4 * h) * LDM + row;
+        f32x4 v;
+        v[0] = p[0]; v[1] = p[LDM]; v[2] = p[2 * LDM]; v[3] = p[3 * LDM];
+        return v;
+    }
+}
+
+template <bool AK, bool BKM>
+__global__ __launch_bounds__(256, 2) void gemm_f32_mfma(GemmK p) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * TILE_FLOATS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // ---- XCD-aware tile mapping (bijective for any grid size) ----
+    const int nblk = p.ntm * p.ntn;
+    int id = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = id & 7, slot = id >> 3;
+        id = slot + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q);
+    }
+    constexpr int GM = 8;
+    const int per_group = GM * p.ntn;
+    const int grp = id / per_group;
+    const int gm0 = grp * GM;
+    const int gsz = (p.ntm - gm0) < GM ? (p.ntm - gm0) : GM;
+    const int within = id - grp * per_group;
+    const int tm = gm0 + within % gsz, tn = within / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- batch / split-K ----
+    const int kz = blockIdx.z % p.splitk, bz = blockIdx.z / p.splitk;
+    const float* A = p.A + (long)bz * p.sA;
+    const float* B = p.B + (long)bz * p.sB;
+    float* C = p.C + (long)bz * p.sC;
+    const int nkt = (p.K + BK - 1) / BK;
+    const int per = (nkt + p.splitk - 1) / p.splitk;
+    const int kt0 = kz * per;
+    const int kt1 = (kt0 + per) < nkt ? (kt0 + per) : nkt;
+    if (kt0 >= kt1) return;
+    const int Kend = (kt1 * BK) < p.K ? (kt1 * BK) : p.K;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[4], rb[4];
+    stage_load<AK>(ra, A, p.lda, m0, kt0 * BK, p.M, Kend, p.a_vec, tid);
+    stage_load<BKM>(rb, B, p.ldb, n0, kt0 * BK, p.N, Kend, p.b_vec, tid);
+    stage_store<AK>(ra, smem, tid);
+    stage_store<BKM>(rb, smem + TILE_FLOATS, tid);
+    __syncthreads();
+
+    int cur = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const bool more = (kt + 1) < kt1;
+        if (more) {
+            stage_load<AK>(ra, A, p.lda, m0, (kt + 1) * BK, p.M, Kend, p.a_vec, tid);
+            stage_load<BKM>(rb, B, p.ldb, n0, (kt + 1) * BK, p.N, Kend, p.b_vec, tid);
+        }
+        const float* As = smem + cur * 2 * TILE_FLOATS;
+        const float* Bs = As + TILE_FLOATS;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = frag<AK>(As, wm * 64 + i * 32 + li, g, lh);
+                fb[i] = frag<BKM>(Bs, wn * 64 + i * 32 + li, g, lh);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            float* An = smem + (cur ^ 1) * 2 * TILE_FLOATS;
+            stage_store<AK>(ra, An, tid);
+            stage_store<BKM>(rb, An + TILE_FLOATS, tid);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + li;
+            if (col >= p.N) continue;
+            float badd = 0.f;
+            if (p.bias && kz == 0) badd += p.bias[col];
+            if (p.bias2 && kz == 0) badd += p.bias2[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row >= p.M) continue;
+                float v = p.alpha * acc[i][j][r] + badd;
+                float* cp = C + (long)row * p.ldc + col;
+                if (p.accumulate == 2) {
+                    atomicAdd(cp, v);
+                } else {
+                    if (p.accumulate == 1) v += *cp;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.mulmask) v *= p.mulmask[(long)row * p.ldmask + col];
+                    *cp = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int t2_gemm(const T2Gemm* g, void* stream) {
+    T2_REQUIRE(g && g->A && g->B && g->C, "t2_gemm: null operand");
+    T2_REQUIRE(g->M > 0 && g->N > 0 && g->K > 0, "t2_gemm: empty dims");
+    const int splitk = g->splitk > 1 ? g->splitk : 1;
+    const int batch = g->batch > 1 ? g->batch : 1;
+    T2_REQUIRE(splitk == 1 || g->accumulate == 2, "t2_gemm: splitk>1 requires accumulate=2 (atomic)");
+    T2_REQUIRE(g->accumulate != 2 || (!g->relu && !g->mulmask), "t2_gemm: atomic epilogue cannot apply relu/mask");
+    T2_REQUIRE(!(g->a_kmajor == 0 && g->b_kmajor == 1), "t2_gemm: (A m-major, B k-major) layout not instantiated");
+    GemmK p;
+    p.A = g->A; p.B = g->B; p.C = g->C;
+    p.M = g->M; p.N = g->N; p.K = g->K;
+    p.lda = g->lda; p.ldb = g->ldb; p.ldc = g->ldc;
+    p.alpha = g->alpha;
+    p.bias = g->bias; p.bias2 = g->bias2; p.mulmask = g->mulmask; p.ldmask = g->ldmask;
+    p.relu = g->relu; p.accumulate = g->accumulate; p.splitk = splitk;
+    p.sA = g->sA; p.sB = g->sB; p.sC = g->sC;
+    p.a_vec = (g->lda % 4 == 0) && t2_aligned16(g->A) && (g->sA % 4 == 0);
+    p.b_vec = (g->ldb % 4 == 0) && t2_aligned16(g->B) && (g->sB % 4 == 0);
+    p.ntm = t2_cdiv(g->M, BM); p.ntn = t2_cdiv(g->N, BN);
+    dim3 grid(p.ntm * p.ntn, 1, batch * splitk), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (g->a_kmajor && g->b_kmajor) hipLaunchKernelGGL((gemm_f32_mfma<true, true>), grid, block, 0, s, p);
+    else if (g->a_kmajor && !g->b_kmajor) hipLaunchKernelGGL((gemm_f32_mfma<true, false>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_f32_mfma<false, false>), grid, block, 0, s, p);
+    T2_CHECK_LAUNCH();
+    return T2_OK;
+}

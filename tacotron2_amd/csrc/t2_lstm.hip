@@ -1,0 +1,396 @@
+// LSTM cell steps for gfx950: batch rows on the MFMA M axis (v_mfma_f32_16x16x4_f32, exact fp32).
+//
+// Forward step (lstm_step_fwd_kernel)
+//   One workgroup = 4 hidden units x 4 gates = 16 gate columns, all batch rows (MT tiles of 16 rows).
+//   grid.x = H/4 workgroups (256 for H = 1024: one per CU), grid.y = independent cells (BiLSTM directions).
+//   The 4 waves split K (the concatenated input segments) in 16-deep chunks; each lane streams its
+//   fragment straight from global memory as one 16-byte load per operand per chunk (weights are read once
+//   per step per workgroup - the GEMV/M<=64 regime, no LDS round trip), 4 MFMA k-steps per load with the
+//   k-permutation {s, 4+s, 8+s, 12+s}.  Partial tiles are summed across waves in LDS in fixed order, then
+//   threads (b, unit) apply the gate non-linearities, cell update, dropout mask and write h/c/stash.
+//
+// Backward step (lstm_step_bwd_kernel)
+//   dx[b][u] = sum_n dgates_next[b][n] * W[n][u]  (K = 4H over 4 waves, two accumulator chains), one
+//   16 x 16 (batch x unit) tile per workgroup, then (epilogue) the cell's pointwise backward for step t,
+//   producing dgates_t - the A operand of the next launch and the row block of the wgrad GEMMs.
+#include "t2_common.hpp"
+
+namespace {
+
+struct Seg { const float* x; long ldx; const float* w; long ldw; int K; };
+struct LstmK {
+    int B, H, nseg;
+    Seg seg[3];
+    const float* pre; long ldpre;
+    const float* bias1; const float* bias2;
+    const float* c_prev; long ldc_prev;
+    const float* drop; long lddrop;
+    float* h_out; long ldh;
+    float* h_out2; long ldh2;
+    float* c_out; long ldc_out;
+    float* gates_out; long ldg;
+    const int32_t* len; int t;
+};
+struct LstmK2 { LstmK s[2]; };
+
+template <int MT>
+__global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmK2 pp) {
+    const LstmK& p = pp.s[blockIdx.y];
+    __shared__ float red[4 * MT * 256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int u0 = blockIdx.x * 4;
+    const int H = p.H;
+    // this lane's weight row: gate block (r>>2), unit u0 + (r&3)
+    const long wrow = (long)(r >> 2) * H + u0 + (r & 3);
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // Flattened 16-deep chunk list over the input segments; wave w owns chunks w, w+4, ...
+    const int cb1 = p.nseg > 0 ? (p.seg[0].K >> 4) : 0;
+    const int cb2 = cb1 + (p.nseg > 1 ? (p.seg[1].K >> 4) : 0);
+    const int NT = cb2 + (p.nseg > 2 ? (p.seg[2].K >> 4) : 0);
+    bool xin[MT];
+    long xrow[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { xin[m] = (m * 16 + r) < p.B; xrow[m] = xin[m] ? (m * 16 + r) : 0; }
+
+    constexpr int U = 4;
+    auto load_group = [&](int c0, f32x4 (&bw)[U], f32x4 (&ax)[U][MT]) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int c = c0 + 4 * j;
+            if (c < NT) {
+                const int sgi = (c >= cb1 ? 1 : 0) + (c >= cb2 ? 1 : 0);
+                const int lc = c - (sgi == 0 ? 0 : (sgi == 1 ? cb1 : cb2));
+                const float* sw = sgi == 0 ? p.seg[0].w : (sgi == 1 ? p.seg[1].w : p.seg[2].w);
+                const float* sx = sgi == 0 ? p.seg[0].x : (sgi == 1 ? p.seg[1].x : p.seg[2].x);
+                const long ldw = sgi == 0 ? p.seg[0].ldw : (sgi == 1 ? p.seg[1].ldw : p.seg[2].ldw);
+                const long ldx = sgi == 0 ? p.seg[0].ldx : (sgi == 1 ? p.seg[1].ldx : p.seg[2].ldx);
+                bw[j] = *reinterpret_cast<const f32x4*>(sw + wrow * ldw + 16 * lc + 4 * q);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    ax[j][m] = *reinterpret_cast<const f32x4*>(sx + xrow[m] * ldx + 16 * lc + 4 * q);
+                    if (!xin[m]) ax[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            } else {
+                bw[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < MT; ++m) ax[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto mma_group = [&](const f32x4 (&bw)[U], const f32x4 (&ax)[U][MT]) {
+#pragma unroll
+        for (int j = 0; j < U; ++j)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[j][m][s], bw[j][s], acc[m], 0, 0, 0);
+    };
+    {
+        f32x4 bwA[U], bwB[U], axA[U][MT], axB[U][MT];
+        int c = w;
+        load_group(c, bwA, axA); c += 4 * U;
+        while (true) {
+            load_group(c, bwB, axB);
+            mma_group(bwA, axA);
+            if (c >= NT) break;
+            c += 4 * U;
+            load_group(c, bwA, axA);
+            mma_group(bwB, axB);
+            if (c >= NT) break;
+            c += 4 * U;
+        }
+    }
+    // C/D layout 16x16: col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) red[((w * MT + m) * 16 + (q * 4 + g)) * 16 + r] = acc[m][g];
+    __syncthreads();
+
+    if (tid < MT * 64) {
+        const int b = tid >> 2, uu = tid & 3;
+        if (b < p.B) {
+            const int u = u0 + uu;
+            float gsum[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float s = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) s += red[((ww * MT + (b >> 4)) * 16 + (b & 15)) * 16 + g * 4 + uu];
+                const int n = g * H + u;
+                if (p.pre) s += p.pre[(long)b * p.ldpre + n];
+                if (p.bias1) s += p.bias1[n];
+                if (p.bias2) s += p.bias2[n];
+                gsum[g] = s;
+            }
+            const bool active = (p.len == nullptr) || (p.t < p.len[b]);
+            float gi = t2_sigmoid(gsum[0]), gf = t2_sigmoid(gsum[1]), gg = tanhf(gsum[2]), go = t2_sigmoid(gsum[3]);
+            const float cp = p.c_prev ? p.c_prev[(long)b * p.ldc_prev + u] : 0.f;
+            float cn = gf * cp + gi * gg;
+            float hn = go * tanhf(cn);
+            if (p.drop) hn *= p.drop[(long)b * p.lddrop + u];
+            if (!active) { hn = 0.f; cn = 0.f; gi = gf = gg = go = 0.f; }
+            p.h_out[(long)b * p.ldh + u] = hn;
+            if (p.h_out2) p.h_out2[(long)b * p.ldh2 + u] = hn;
+            if (p.c_out) p.c_out[(long)b * p.ldc_out + u] = cn;
+            if (p.gates_out) {
+                float* go_ = p.gates_out + (long)b * p.ldg + u;
+                go_[0] = gi; go_[H] = gf; go_[2 * H] = gg; go_[3 * H] = go;
+            }
+        }
+    }
+}
+
+int check_step(const T2LstmStep& s) {
+    T2_REQUIRE(s.B >= 1 && s.H >= 4 && s.H % 4 == 0, "lstm step: need B >= 1 and H % 4 == 0");
+    T2_REQUIRE(s.nseg >= 0 && s.nseg <= 3, "lstm step: 0..3 input segments");
+    for (int i = 0; i < s.nseg; ++i) {
+        T2_REQUIRE(s.seg[i].K % 16 == 0 && s.seg[i].K > 0, "lstm step: segment K must be a multiple of 16");
+        T2_REQUIRE(s.seg[i].ldx % 4 == 0 && s.seg[i].ldw % 4 == 0 && t2_aligned16(s.seg[i].x) && t2_aligned16(s.seg[i].w),
+                   "lstm step: segment pointers/strides must be 16-byte aligned");
+    }
+    T2_REQUIRE(s.h_out != nullptr, "lstm step: h_out required");
+    return T2_OK;
+}
+
+void to_k(const T2LstmStep& s, LstmK& k, int b0, int bn) {
+    k.B = bn; k.H = s.H; k.nseg = s.nseg;
+    for (int i = 0; i < 3; ++i) {
+        k.seg[i].x = (i < s.nseg && s.seg[i].x) ? s.seg[i].x + (long)b0 * s.seg[i].ldx : nullptr;
+        k.seg[i].ldx = s.seg[i].ldx; k.seg[i].w = s.seg[i].w; k.seg[i].ldw = s.seg[i].ldw; k.seg[i].K = s.seg[i].K;
+    }
+    k.pre = s.pre ? s.pre + (long)b0 * s.ldpre : nullptr; k.ldpre = s.ldpre;
+    k.bias1 = s.bias1; k.bias2 = s.bias2;
+    k.c_prev = s.c_prev ? s.c_prev + (long)b0 * s.ldc_prev : nullptr; k.ldc_prev = s.ldc_prev;
+    k.drop = s.drop ? s.drop + (long)b0 * s.lddrop : nullptr; k.lddrop = s.lddrop;
+    k.h_out = s.h_out + (long)b0 * s.ldh; k.ldh = s.ldh;
+    k.h_out2 = s.h_out2 ? s.h_out2 + (long)b0 * s.ldh2 : nullptr; k.ldh2 = s.ldh2;
+    k.c_out = s.c_out ? s.c_out + (long)b0 * s.ldc_out : nullptr; k.ldc_out = s.ldc_out;
+    k.gates_out = s.gates_out ? s.gates_out + (long)b0 * s.ldg : nullptr; k.ldg = s.ldg;
+    k.len = s.len ? s.len + b0 : nullptr; k.t = s.t;
+}
+
+int launch_fwd(const T2LstmStep* steps, int n, hipStream_t st) {
+    T2_REQUIRE(n == 1 || n == 2, "lstm step: n must be 1 or 2");
+    for (int i = 0; i < n; ++i) T2_TRY(check_step(steps[i]));
+    if (n == 2) T2_REQUIRE(steps[0].B == steps[1].B && steps[0].H == steps[1].H, "lstm step: cells must share B,H");
+    const int B = steps[0].B;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int bn = (B - b0) < 64 ? (B - b0) : 64;
+        LstmK2 kk;
+        for (int i = 0; i < n; ++i) to_k(steps[i], kk.s[i], b0, bn);
+        if (n == 1) kk.s[1] = kk.s[0];
+        dim3 grid(steps[0].H / 4, n), block(256);
+        if (bn <= 16) hipLaunchKernelGGL((lstm_step_fwd_kernel<1>), grid, block, 0, st, kk);
+        else if (bn <= 32) hipLaunchKernelGGL((lstm_step_fwd_kernel<2>), grid, block, 0, st, kk);
+        else hipLaunchKernelGGL((lstm_step_fwd_kernel<4>), grid, block, 0, st, kk);
+    }
+    T2_CHECK_LAUNCH();
+    return T2_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+struct BwdK {
+    int B, H, N4;                       // N4 = reduction length (4H of the producing cell)
+    const float* dg_next; long lddg;    // [b][N4] or null (no recurrent contribution)
+    const float* W; long ldw;           // element (n,u) at W[n*ldw + u]
+    int ncols;                          // number of output columns u (H for the recurrent path)
+    int epi;                            // 0: plain store of dx (+ext), 1: LSTM pointwise backward
+    const float* ext1; long ldx1; const float* ext2; long ldx2;
+    float* dx_out; long lddx;           // epi 0
+    const float* drop; long lddrop;
+    const float* gates; long ldgs;
+    const float* c_prev; long ldcp; const float* c_cur; long ldcc;
+    float* dc; long lddc;
+    float* dg_out; long ldgo;
+    const int32_t* len; int t;
+};
+struct BwdK2 { BwdK s[2]; };
+
+__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(BwdK2 pp) {
+    const BwdK& p = pp.s[blockIdx.z];
+    __shared__ float red[4 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int u0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if (p.dg_next) {
+        const int row = b0 + r;
+        const bool rin = row < p.B;
+        const float* ap = p.dg_next + (long)(rin ? row : 0) * p.lddg + 4 * q;
+        const bool cin = (u0 + r) < p.ncols;
+        const float* bp = p.W + (long)(4 * q) * p.ldw + u0 + (cin ? r : 0);
+        const int nch = p.N4 >> 4;
+        constexpr int U = 4;
+        auto load_group = [&](int c0, f32x4 (&a)[U], f32x4 (&b)[U]) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int c = c0 + 4 * j;
+                a[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                b[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (c < nch) {
+                    if (rin) a[j] = *reinterpret_cast<const f32x4*>(ap + 16 * c);
+                    if (cin) {
+                        const float* bq = bp + (long)(16 * c) * p.ldw;
+                        b[j][0] = bq[0]; b[j][1] = bq[p.ldw]; b[j][2] = bq[2 * p.ldw]; b[j][3] = bq[3 * p.ldw];
+                    }
+                }
+            }
+        };
+        auto mma_group = [&](const f32x4 (&a)[U], const f32x4 (&b)[U]) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][0], b[j][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][1], b[j][1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][2], b[j][2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][3], b[j][3], acc1, 0, 0, 0);
+            }
+        };
+        f32x4 aA[U], bA[U], aB[U], bB[U];
+        int c = w;
+        load_group(c, aA, bA); c += 4 * U;
+        while (true) {
+            load_group(c, aB, bB);
+            mma_group(aA, bA);
+            if (c >= nch) break;
+            c += 4 * U;
+            load_group(c, aA, bA);
+            mma_group(aB, bB);
+            if (c >= nch) break;
+            c += 4 * U;
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) red[(w * 16 + (q * 4 + g)) * 16 + r] = acc0[g] + acc1[g];
+    __syncthreads();
+    {
+        const int bl = tid >> 4, ul = tid & 15;
+        const int b = b0 + bl, u = u0 + ul;
+        if (b < p.B && u < p.ncols) {
+            float dx = red[(0 * 16 + bl) * 16 + ul] + red[(1 * 16 + bl) * 16 + ul] + red[(2 * 16 + bl) * 16 + ul] +
+                       red[(3 * 16 + bl) * 16 + ul];
+            if (p.ext1) dx += p.ext1[(long)b * p.ldx1 + u];
+            if (p.ext2) dx += p.ext2[(long)b * p.ldx2 + u];
+            if (p.epi == 0) {
+                p.dx_out[(long)b * p.lddx + u] = dx;
+            } else {
+                const int H = p.H;
+                const bool active = (p.len == nullptr) || (p.t < p.len[b]);
+                float dh = dx;
+                if (p.drop) dh *= p.drop[(long)b * p.lddrop + u];
+                const float* gs = p.gates + (long)b * p.ldgs + u;
+                const float gi = gs[0], gf = gs[H], gg = gs[2 * H], go = gs[3 * H];
+                const float cp = p.c_prev ? p.c_prev[(long)b * p.ldcp + u] : 0.f;
+                const float tc = tanhf(p.c_cur[(long)b * p.ldcc + u]);
+                float dcv = p.dc[(long)b * p.lddc + u] + dh * go * (1.f - tc * tc);
+                float d_o = dh * tc * go * (1.f - go);
+                float d_i = dcv * gg * gi * (1.f - gi);
+                float d_f = dcv * cp * gf * (1.f - gf);
+                float d_g = dcv * gi * (1.f - gg * gg);
+                float dcp = dcv * gf;
+                if (!active) { d_i = d_f = d_g = d_o = 0.f; dcp = 0.f; }
+                p.dc[(long)b * p.lddc + u] = dcp;
+                float* dgo = p.dg_out + (long)b * p.ldgo + u;
+                dgo[0] = d_i; dgo[H] = d_f; dgo[2 * H] = d_g; dgo[3 * H] = d_o;
+            }
+        }
+    }
+}
+
+void to_bk(const T2LstmBwdStep& s, BwdK& k) {
+    k.B = s.B; k.H = s.H; k.N4 = s.N4;
+    k.dg_next = s.dg_next; k.lddg = s.lddg; k.W = s.W; k.ldw = s.ldw; k.ncols = s.ncols; k.epi = s.epi;
+    k.ext1 = s.ext1; k.ldx1 = s.ldx1; k.ext2 = s.ext2; k.ldx2 = s.ldx2;
+    k.dx_out = s.dx_out; k.lddx = s.lddx; k.drop = s.drop; k.lddrop = s.lddrop;
+    k.gates = s.gates; k.ldgs = s.ldgs; k.c_prev = s.c_prev; k.ldcp = s.ldcp; k.c_cur = s.c_cur; k.ldcc = s.ldcc;
+    k.dc = s.dc; k.lddc = s.lddc; k.dg_out = s.dg_out; k.ldgo = s.ldgo; k.len = s.len; k.t = s.t;
+}
+
+int check_bwd(const T2LstmBwdStep& s) {
+    T2_REQUIRE(s.B >= 1 && s.ncols >= 1, "lstm bwd step: empty");
+    if (s.dg_next) {
+        T2_REQUIRE(s.N4 % 16 == 0 && s.lddg % 4 == 0 && t2_aligned16(s.dg_next), "lstm bwd step: dg_next alignment");
+        T2_REQUIRE(s.W != nullptr, "lstm bwd step: W required with dg_next");
+    }
+    if (s.epi == 1) {
+        T2_REQUIRE(s.gates && s.c_cur && s.dc && s.dg_out && s.ncols == s.H, "lstm bwd step: epilogue operands");
+    } else {
+        T2_REQUIRE(s.dx_out != nullptr, "lstm bwd step: dx_out required");
+    }
+    return T2_OK;
+}
+
+int launch_bwd(const T2LstmBwdStep* steps, int n, hipStream_t st) {
+    T2_REQUIRE(n == 1 || n == 2, "lstm bwd step: n must be 1 or 2");
+    BwdK2 kk;
+    for (int i = 0; i < n; ++i) { T2_TRY(check_bwd(steps[i])); to_bk(steps[i], kk.s[i]); }
+    if (n == 2) T2_REQUIRE(steps[0].B == steps[1].B && steps[0].ncols == steps[1].ncols, "lstm bwd step: shapes differ");
+    if (n == 1) kk.s[1] = kk.s[0];
+    dim3 grid(t2_cdiv(steps[0].ncols, 16), t2_cdiv(steps[0].B, 16), n), block(256);
+    hipLaunchKernelGGL(lstm_step_bwd_kernel, grid, block, 0, st, kk);
+    T2_CHECK_LAUNCH();
+    return T2_OK;
+}
+
+template <typename T>
+inline void adv(T*& p, int64_t inc) { if (p) p += inc; }
+
+}  // namespace
+
+// internal entry used by the attention sequence (t2_attention.hip)
+int t2_lstm_step_fwd_launch(const T2LstmStep* steps, int n, hipStream_t st) { return launch_fwd(steps, n, st); }
+int t2_lstm_step_bwd_launch(const T2LstmBwdStep* steps, int n, hipStream_t st) { return launch_bwd(steps, n, st); }
+
+extern "C" int t2_lstm_step_fwd(const T2LstmStep* steps, int n, void* stream) {
+    T2_REQUIRE(steps != nullptr, "t2_lstm_step_fwd: null");
+    return launch_fwd(steps, n, (hipStream_t)stream);
+}
+
+extern "C" int t2_lstm_step_bwd(const T2LstmBwdStep* steps, int n, void* stream) {
+    T2_REQUIRE(steps != nullptr, "t2_lstm_step_bwd: null");
+    return launch_bwd(steps, n, (hipStream_t)stream);
+}
+
+extern "C" int t2_lstm_seq_fwd(const T2LstmStep* base, const T2LstmStride* inc, int n, int S, void* stream) {
+    T2_REQUIRE(base && inc && (n == 1 || n == 2) && S >= 0, "t2_lstm_seq_fwd: bad arguments");
+    T2LstmStep cur[2];
+    for (int i = 0; i < n; ++i) cur[i] = base[i];
+    for (int s = 0; s < S; ++s) {
+        T2_TRY(launch_fwd(cur, n, (hipStream_t)stream));
+        for (int i = 0; i < n; ++i) {
+            for (int j = 0; j < 3; ++j) adv(cur[i].seg[j].x, inc[i].seg_x[j]);
+            adv(cur[i].pre, inc[i].pre); adv(cur[i].c_prev, inc[i].c_prev); adv(cur[i].drop, inc[i].drop);
+            adv(cur[i].h_out, inc[i].h_out); adv(cur[i].h_out2, inc[i].h_out2); adv(cur[i].c_out, inc[i].c_out);
+            adv(cur[i].gates_out, inc[i].gates_out);
+            cur[i].t += inc[i].dt;
+        }
+    }
+    return T2_OK;
+}
+
+extern "C" int t2_lstm_seq_bwd(const T2LstmBwdStep* base, const T2LstmBwdStride* inc, int n, int S, void* stream) {
+    T2_REQUIRE(base && inc && (n == 1 || n == 2) && S >= 0, "t2_lstm_seq_bwd: bad arguments");
+    T2LstmBwdStep cur[2];
+    for (int i = 0; i < n; ++i) cur[i] = base[i];
+    for (int s = 0; s < S; ++s) {
+        T2_TRY(launch_bwd(cur, n, (hipStream_t)stream));
+        for (int i = 0; i < n; ++i) {
+            // after the first step the recurrent operand is the dgates just produced
+            if (s == 0 && cur[i].dg_next == nullptr) { cur[i].dg_next = cur[i].dg_out; cur[i].lddg = cur[i].ldgo; }
+            else adv(cur[i].dg_next, inc[i].dg);
+            adv(cur[i].ext1, inc[i].ext1); adv(cur[i].ext2, inc[i].ext2); adv(cur[i].drop, inc[i].drop);
+            adv(cur[i].gates, inc[i].gates); adv(cur[i].c_prev, inc[i].c_prev); adv(cur[i].c_cur, inc[i].c_cur);
+            adv(cur[i].dg_out, inc[i].dg);
+            cur[i].t += inc[i].dt;
+        }
+    }
+    return T2_OK;
+}

@@ -1,0 +1,131 @@
+"""Model-level parity on the GPU: the HIP path (through the C ABI) against
+ (a) the committed golden vectors produced by the reference itself, and
+ (b) the CPU oracle on seeded inputs at sizes the oracle finishes in seconds.
+Tolerance: north_star's fp32 bar, mel L1 < 1e-4 (checked as mean abs error), plus a max-abs guard."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tacotron2_ref as R  # noqa: E402
+from tests.helpers import SMALL, load_golden, params_from, tf_masks_from  # noqa: E402
+
+MEL_L1_TOL = 1e-4
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def masks_to_device(m, dev):
+    """oracle mask dict -> engine convention (prenet masks time-major)."""
+    out = {}
+    if m.get("enc_drop") is not None:
+        out["enc_drop"] = [x.to(dev).contiguous() for x in m["enc_drop"]]
+    if m.get("prenet_drop") is not None:
+        out["prenet_drop"] = [x.transpose(0, 1).contiguous().to(dev) for x in m["prenet_drop"]]
+    for k in ("att_drop", "dec_drop"):
+        if m.get(k) is not None:
+            out[k] = m[k].to(dev).contiguous()
+    if m.get("post_drop") is not None:
+        out["post_drop"] = [x.to(dev).contiguous() for x in m["post_drop"]]
+    return out
+
+
+def build_engine(d, P, dev):
+    from tacotron2_amd.engine import Engine
+    from tacotron2_amd.params import ParamStore
+    ps = ParamStore(d, dev)
+    ps.load_state_dict(P)
+    return Engine(ps), ps
+
+
+def l1(a, b):
+    return float((a.double().cpu() - torch.as_tensor(b).double()).abs().mean())
+
+
+def mx(a, b):
+    return float((a.double().cpu() - torch.as_tensor(b).double()).abs().max())
+
+
+def test_forward_eval_matches_reference_golden():
+    dev = _dev()
+    z = load_golden("tf_eval")
+    d = R.default_dims(**SMALL, dropout=0.0)
+    eng, ps = build_engine(d, params_from(z), dev)
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    (mels, post, gates, al), _ = eng.forward_tf(t("chars_idx"), t("chars_len"), t("mel"), t("mel_len"), training=False,
+                                                save_for_backward=False)
+    torch.cuda.synchronize()
+    assert l1(mels, z["o_mels"]) < MEL_L1_TOL and l1(post, z["o_post"]) < MEL_L1_TOL
+    assert mx(mels, z["o_mels"]) < 2e-4 and mx(post, z["o_post"]) < 2e-4
+    assert mx(al, z["o_align"]) < 1e-5
+    assert mx(gates, z["o_gates"]) < 2e-4
+    ml = z["mel_len"]
+    for b in range(len(ml)):
+        assert float(mels[b, ml[b]:].abs().max()) == 0.0 and bool((gates[b, ml[b]:] == -1000.0).all())
+
+
+@pytest.mark.parametrize("name,extra", [("tf_train", {}),
+                                        ("tf_train_desc", dict(speaker_tokens=True, num_speakers=7,
+                                                               description_embeddings=True, description_embeddings_dim=24))])
+def test_forward_train_matches_reference_golden(name, extra):
+    dev = _dev()
+    z = load_golden(name)
+    d = R.default_dims(**SMALL, dropout=0.5, **extra)
+    eng, ps = build_engine(d, params_from(z), dev)
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    kw = {}
+    if "speaker_id" in z:
+        kw["speaker_id"] = t("speaker_id")
+    if "description_embeddings" in z:
+        kw["description_embeddings"] = t("description_embeddings")
+    masks = masks_to_device(tf_masks_from(z), dev)
+    (mels, post, gates, al), _ = eng.forward_tf(t("chars_idx"), t("chars_len"), t("mel"), t("mel_len"), training=True,
+                                                masks=masks, **kw)
+    torch.cuda.synchronize()
+    assert l1(mels, z["o_mels"]) < MEL_L1_TOL and l1(post, z["o_post"]) < MEL_L1_TOL
+    assert mx(mels, z["o_mels"]) < 2e-4 and mx(post, z["o_post"]) < 5e-4
+    assert mx(al, z["o_align"]) < 1e-5
+    # BatchNorm running statistics were updated like nn.BatchNorm1d (momentum 0.1, unbiased variance)
+    sd = ps.state_dict()
+    for k in z:
+        if k.startswith("new.") and not k.endswith("num_batches_tracked"):
+            assert mx(sd[k[4:]], z[k]) < 1e-5, k
+
+
+def random_case(d, B, L, T, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(max(3, L // 2), L + 1, (B,), generator=g); lens[0] = L
+    tl = torch.randint(max(3, T // 2), T + 1, (B,), generator=g); tl[-1] = T
+    ci = torch.zeros(B, L, dtype=torch.int64); mel = torch.zeros(B, T, d["num_mels"]); gate = torch.zeros(B, T, 1)
+    for b in range(B):
+        ci[b, :lens[b]] = torch.randint(1, d["num_chars"] + 1, (int(lens[b]),), generator=g)
+        mel[b, :tl[b]] = torch.randn(int(tl[b]), d["num_mels"], generator=g) * 1.5 - 3
+        gate[b, :tl[b] - 1] = 1.0
+    A, Dd, Pd, E, Pn, M = d["att_rnn_dim"], d["rnn_hidden_dim"], d["prenet_dim"], d["encoded_dim"], d["postnet_dim"], d["num_mels"]
+    sm = lambda shape, p: (torch.rand(shape, generator=g) >= p).float() / (1 - p)
+    chans = [Pn, Pn, Pn, Pn, M]
+    masks = dict(enc_drop=[sm((B, L, E), 0.5) for _ in range(3)], prenet_drop=[sm((B, T + 1, Pd), 0.5) for _ in range(2)],
+                 att_drop=sm((T, B, A), 0.1), dec_drop=sm((T, B, Dd), 0.1), post_drop=[sm((B, T, c), 0.5) for c in chans])
+    return ci, lens, mel, tl.to(torch.int32), gate, masks
+
+
+def test_forward_train_midsize_matches_oracle():
+    """Closer to production dims (H = 256, att 64, L = 45, T = 37, B = 5); oracle runs on CPU in seconds."""
+    dev = _dev()
+    d = R.default_dims(num_chars=39, encoded_dim=128, prenet_dim=64, att_rnn_dim=256, att_dim=64, rnn_hidden_dim=256,
+                       postnet_dim=128, num_mels=80, dropout=0.5)
+    P = R.init_params(d, seed=3)
+    ci, lens, mel, tl, gate, masks = random_case(d, 5, 45, 37, 17, dev)
+    with torch.no_grad():
+        ref = R.tacotron2_fwd(P, d, ci, lens, True, mel, tl, training=True, masks=masks)
+    eng, ps = build_engine(d, P, dev)
+    (mels, post, gates, al), _ = eng.forward_tf(ci.to(dev), lens.to(dev), mel.to(dev), tl.to(dev), training=True,
+                                                masks=masks_to_device(masks, dev))
+    torch.cuda.synchronize()
+    assert l1(mels, ref[0]) < MEL_L1_TOL and l1(post, ref[1]) < MEL_L1_TOL
+    assert mx(al, ref[3]) < 2e-5
+    assert mx(mels, ref[0]) < 1e-3 and mx(post, ref[1]) < 1e-3
