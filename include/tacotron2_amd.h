@@ -104,6 +104,7 @@ typedef struct {
     int B, H, N4;
     const float* dg_next; int64_t lddg;
     const float* W; int64_t ldw;
+    const float* dg2; int64_t lddg2; const float* W2; int64_t ldw2; int N2;  /* optional second K segment (+= dg2 . W2) */
     int ncols; int epi;
     const float* ext1; int64_t ldx1; const float* ext2; int64_t ldx2;
     float* dx_out; int64_t lddx;
@@ -112,10 +113,11 @@ typedef struct {
     const float* c_prev; int64_t ldcp; const float* c_cur; int64_t ldcc;
     float* dc; int64_t lddc;
     float* dg_out; int64_t ldgo;
+    float* dg_out2; int64_t ldgo2;          /* optional second copy of dg_out with its own row stride */
     const int32_t* len; int t;
 } T2LstmBwdStep;
 int t2_lstm_step_bwd(const T2LstmBwdStep* steps, int n, void* stream);
-typedef struct { int64_t dg, ext1, ext2, drop, gates, c_prev, c_cur; int dt; } T2LstmBwdStride;
+typedef struct { int64_t dg, dg2, ext1, ext2, drop, gates, c_prev, c_cur; int dt; } T2LstmBwdStride;
 /* S steps; base[i].dg_next == NULL at entry, afterwards each step consumes the dg_out of the previous one. */
 int t2_lstm_seq_bwd(const T2LstmBwdStep* base, const T2LstmBwdStride* inc, int n, int S, void* stream);
 
@@ -161,6 +163,27 @@ typedef struct {
     float* e_part;
 } T2AttnSeq;
 int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream);
+
+/* Back-propagation through the attention chain, frames T-1 .. 0 (autograd of t2_attn_seq_fwd), 4 launches / frame:
+ *   dctx_tot[t] = dctx_ext1[t] + dctx_ext2[t] + dgates[t+1] . W_ih_ctx ; attention backward (weights/energies,
+ *   then per attention-dim slice) ; attention-LSTM cell backward with dh = dh_ext[t] + dgates[t+1].W_hh + dq[t].Wq.
+ * Upstream gradients are time-major rows (t,b) with their own leading dimensions.  Outputs: dgates [T][B][4A],
+ * dctx_tot [T][B][Ef], dq [T][B][Ad] (inputs of the post-loop weight-gradient GEMMs) and the per-sample
+ * accumulators dpmT [B][Ad][L], dv_part [B][Ad], dU_part [B][Ad][2][Kl] (caller zero-fills; summed over b after).
+ * Workspaces: dc [B][A] (zero-filled), G [2][B][L], de [B][L], din_part [B][Ad/16][2][L]. */
+typedef struct {
+    int B, L, T, A, Ad, Ef, Kl;
+    const float* W_ih_ctx; int64_t ld_wih;
+    const float* W_hh; const float* Wq; const float* U; const float* v;
+    const float* memory; const float* xdec; const float* att_c; const float* gates; const float* align;
+    const float* cum; const float* th; const float* att_drop;
+    const float* dh_ext; int64_t ld_dh;
+    const float* dctx_ext1; int64_t ld_dc1;
+    const float* dctx_ext2; int64_t ld_dc2;
+    float* dgates; float* dctx_tot; float* dq; float* dpmT; float* dv_part; float* dU_part;
+    float* dc; float* G; float* de; float* din_part;
+} T2AttnSeqBwd;
+int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Conv stacks (encoder model/encoder.py:31-46,57; postnet model/postnet.py:8-49).

@@ -266,3 +266,262 @@ extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
     }
     return T2_OK;
 }
+
+// =================================================================================================
+// Backward through one attention frame (autograd of the kernels above), again spread over many CUs.
+//
+//  attn_bwd_dw_kernel   grid (B, ceil(L/32)): grad w.r.t. the attention weights and energies.
+//     dw[l]  = sum_e dctx[e] * memory[l][e]  (its 32 positions, 128-byte rows, 8 lanes per row)
+//     dwx[l] = location-path gradient of w_t  = d_in_{t+1}[0][l] + G_t[l],  G_t = d_in_{t+1}[1] + G_{t+1}
+//              (cumulative weights: cum_t = cum_{t-1} + w_t feeds every later frame)
+//     softmax backward needs sigma = sum_l w[l]*(dw[l]+dwx[l]) = dctx.context_t + sum_l w[l]*dwx[l],
+//     which every workgroup recomputes locally - no cross-workgroup reduction.
+//     de[l] = w[l] * (dw[l] + dwx[l] - sigma)        (masked positions have w = 0 -> de = 0)
+//  attn_bwd_ds_kernel   grid (B, Ad/16): workgroup (b, j) owns 16 attention dims for all l.
+//     ds[l][a] = de[l] * v[a] * (1 - th^2);  dpmT += ds;  dq[a] = sum_l ds;  dv[a] += sum_l de[l]*th[l][a]
+//     dU[a][c][k] += sum_l ds[l][a] * in[c][l+k-15]                   (per-sample partial, summed after the loop)
+//     d_in partial [c][l'] = sum_{a in slice,k} ds[l'+15-k][a] * U[a][c][k]  (summed over slices by the next frame)
+struct AttnBwdK {
+    int B, L, Ad, Ef;
+    const float* dctx; long lddctx;
+    const float* ctx; long ldctx;
+    const float* w; long ldw;
+    const float* memory;
+    const float* din_part; const float* G_in; float* G_out;
+    float* de;
+    const float* th; const float* v; const float* U;
+    const float* w_prev; long ldwp; const float* cum_prev; long ldcp;
+    float* dpmT; float* dq; long lddq; float* dv_part; float* dU_part; float* din_part_out;
+};
+
+namespace {
+
+__global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdK p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x, l0 = blockIdx.y * 32, tid = threadIdx.x;
+    const int L = p.L, Ef = p.Ef, NA = p.Ad >> 4;
+    float* dctx_s = sm;                    // [Ef]
+    float* dwx_s = dctx_s + Ef;            // [L rounded]
+    float* red = dwx_s + ((L + 3) & ~3);   // [8]
+    float part = 0.f;
+    for (int e = tid; e < Ef; e += 256) {
+        const float dv = p.dctx[(long)b * p.lddctx + e];
+        dctx_s[e] = dv;
+        part = fmaf(dv, p.ctx[(long)b * p.ldctx + e], part);
+    }
+    for (int l = tid; l < L; l += 256) {
+        float g0 = 0.f, g1 = 0.f;
+        if (p.din_part) {
+            for (int j = 0; j < NA; ++j) {
+                g0 += p.din_part[(((long)b * NA + j) * 2 + 0) * L + l];
+                g1 += p.din_part[(((long)b * NA + j) * 2 + 1) * L + l];
+            }
+        }
+        const float Gn = g1 + (p.G_in ? p.G_in[(long)b * L + l] : 0.f);
+        const float dx = g0 + Gn;
+        dwx_s[l] = dx;
+        if (blockIdx.y == 0) p.G_out[(long)b * L + l] = Gn;
+        part = fmaf(p.w[(long)b * p.ldw + l], dx, part);
+    }
+    const float sigma = t2_block_sum(part, red);
+    const int l = l0 + (tid >> 3), sub = tid & 7;
+    float acc = 0.f;
+    if (l < L) {
+        const float* mp = p.memory + ((long)b * L + l) * Ef;
+        for (int e = sub * 4; e < Ef; e += 32) {
+            const f32x4 m = *reinterpret_cast<const f32x4*>(mp + e);
+            acc += m[0] * dctx_s[e] + m[1] * dctx_s[e + 1] + m[2] * dctx_s[e + 2] + m[3] * dctx_s[e + 3];
+        }
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (sub == 0 && l < L) p.de[(long)b * L + l] = p.w[(long)b * p.ldw + l] * (acc + dwx_s[l] - sigma);
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_ds_kernel(AttnBwdK p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
+    const int L = p.L, NG = (L + 3) >> 2, Lp = 4 * NG + 36, L4 = 4 * NG;
+    float* inp = sm;               // [2][Lp]  haloed (w_{t-1}, cum_{t-1})
+    float* dsp = inp + 2 * Lp;     // [16][Lp] haloed ds (index l + 15)
+    float* tvs = dsp + 16 * Lp;    // [16][L4] de*th, later reused for the d_in partials [4][2][L4]
+    float* Us = tvs + 16 * L4;     // [16][64]
+    float* des = Us + 16 * 64;     // [L4]
+    for (int idx = tid; idx < 2 * Lp; idx += 256) {
+        const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
+        float val = 0.f;
+        if (l >= 0 && l < L) {
+            const float* src = c == 0 ? p.w_prev : p.cum_prev;
+            const long ld = c == 0 ? p.ldwp : p.ldcp;
+            if (src) val = src[(long)b * ld + l];
+        }
+        inp[idx] = val;
+    }
+    for (int idx = tid; idx < 16 * Lp; idx += 256) dsp[idx] = 0.f;
+    for (int idx = tid; idx < 16 * 64; idx += 256) {
+        const int al = idx >> 6, kk = idx & 63;
+        Us[idx] = kk < 2 * KL ? p.U[(long)(j * 16 + al) * 2 * KL + kk] : 0.f;
+    }
+    for (int l = tid; l < L4; l += 256) des[l] = l < L ? p.de[(long)b * L + l] : 0.f;
+    __syncthreads();
+
+    // phase A: ds, dpmT accumulation
+    const int items = 16 * NG;
+    for (int item = tid; item < items; item += 256) {
+        const int al = item / NG, lg = item - al * NG;
+        const int a = j * 16 + al;
+        const float va = p.v[a];
+        const long rowoff = ((long)b * p.Ad + a) * L;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int l = 4 * lg + i;
+            float d = 0.f, tv = 0.f;
+            if (l < L) {
+                const float th = p.th[rowoff + l];
+                d = des[l] * va * (1.f - th * th);
+                tv = des[l] * th;
+                p.dpmT[rowoff + l] += d;
+            }
+            dsp[al * Lp + KPAD + l] = d;
+            tvs[al * L4 + l] = tv;
+        }
+    }
+    __syncthreads();
+
+    {   // phase B: dq[a], dv[a]: 16 lanes per attention dim
+        const int al = tid >> 4, sub = tid & 15;
+        float sq = 0.f, sv = 0.f;
+        for (int l = sub; l < L; l += 16) { sq += dsp[al * Lp + KPAD + l]; sv += tvs[al * L4 + l]; }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { sq += __shfl_xor(sq, o, 64); sv += __shfl_xor(sv, o, 64); }
+        if (sub == 0) {
+            const int a = j * 16 + al;
+            p.dq[(long)b * p.lddq + a] = sq;
+            p.dv_part[(long)b * p.Ad + a] += sv;
+        }
+    }
+
+    {   // phase C: dU partial; thread = (dim al, channel c, tap group kg of 4)
+        const int al = tid >> 4, c = (tid >> 3) & 1, kg = tid & 7, k0 = 4 * kg;
+        float out[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* dsr = dsp + al * Lp + KPAD;
+        const float* inr = inp + c * Lp + k0;
+        for (int l = 0; l < L4; l += 4) {
+            float d4[4], wv[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d4[i] = dsr[l + i];
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(inr + l);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(inr + l + 4);
+            wv[0] = w0[0]; wv[1] = w0[1]; wv[2] = w0[2]; wv[3] = w0[3];
+            wv[4] = w1[0]; wv[5] = w1[1]; wv[6] = w1[2]; wv[7] = w1[3];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) out[kk] = fmaf(d4[i], wv[i + kk], out[kk]);
+        }
+        float* dst = p.dU_part + (((long)b * p.Ad + j * 16 + al) * 2 + c) * KL + k0;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            if (k0 + kk < KL) dst[kk] += out[kk];
+    }
+    __syncthreads();   // tvs is reused below
+
+    // phase D: d_in partials; item = ((aq*2 + c)*NG + lg), 4 dims per item
+    float* dinq = tvs;   // [4][2][L4]
+    const int items_d = 8 * NG;
+    for (int item = tid; item < items_d; item += 256) {
+        const int lg = item % NG, ac = item / NG, c = ac & 1, aq = ac >> 1;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int ai = 0; ai < 4; ++ai) {
+            const int al = aq * 4 + ai;
+            float win[36];
+            const f32x4* wp = reinterpret_cast<const f32x4*>(dsp + al * Lp + 4 * lg);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const f32x4 t = wp[i];
+                win[4 * i] = t[0]; win[4 * i + 1] = t[1]; win[4 * i + 2] = t[2]; win[4 * i + 3] = t[3];
+            }
+            const float* u = Us + al * 64 + c * KL;
+#pragma unroll
+            for (int k = 0; k < KL; ++k) {
+                const float uk = u[k];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = fmaf(uk, win[i + 30 - k], acc[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dinq[(aq * 2 + c) * L4 + 4 * lg + i] = acc[i];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 2 * L; idx += 256) {
+        const int c = idx >= L ? 1 : 0, l = idx - c * L;
+        const float s = dinq[(0 * 2 + c) * L4 + l] + dinq[(1 * 2 + c) * L4 + l] + dinq[(2 * 2 + c) * L4 + l] +
+                        dinq[(3 * 2 + c) * L4 + l];
+        p.din_part_out[(((long)b * gridDim.y + j) * 2 + c) * L + l] = s;
+    }
+}
+
+}  // namespace
+
+extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
+    T2_REQUIRE(a != nullptr, "t2_attn_seq_bwd: null");
+    T2_REQUIRE(a->Kl == KL && a->Ad % 16 == 0 && a->Ef % 32 == 0, "t2_attn_seq_bwd: unsupported dims");
+    T2_REQUIRE(a->L >= 1 && a->L <= 384, "t2_attn_seq_bwd: need 1 <= L <= 384");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = a->B, L = a->L, T = a->T, A = a->A, Ef = a->Ef, Ad = a->Ad, NA = Ad / 16;
+    const long ldx = A + Ef;
+    const int NG = (L + 3) >> 2, Lp = 4 * NG + 36, L4 = 4 * NG;
+    const size_t sm_dw = (size_t)(Ef + ((L + 3) & ~3) + 8) * sizeof(float);
+    const size_t sm_ds = (size_t)(2 * Lp + 16 * Lp + 16 * L4 + 16 * 64 + L4) * sizeof(float);
+    T2_REQUIRE(sm_ds <= 64 * 1024, "t2_attn_seq_bwd: LDS budget exceeded");
+    for (int t = T - 1; t >= 0; --t) {
+        const bool last = (t == T - 1);
+        const float* dg_next = last ? nullptr : a->dgates + (long)(t + 1) * B * 4 * A;
+        // (1) total gradient w.r.t. context_t
+        T2LstmBwdStep s;
+        memset(&s, 0, sizeof(s));
+        s.B = B; s.H = A; s.N4 = 4 * A; s.dg_next = dg_next; s.lddg = 4 * A; s.W = a->W_ih_ctx; s.ldw = a->ld_wih;
+        s.ncols = Ef; s.epi = 0;
+        s.ext1 = a->dctx_ext1 + (long)t * B * a->ld_dc1; s.ldx1 = a->ld_dc1;
+        s.ext2 = a->dctx_ext2 + (long)t * B * a->ld_dc2; s.ldx2 = a->ld_dc2;
+        s.dx_out = a->dctx_tot + (long)t * B * Ef; s.lddx = Ef;
+        T2_TRY(t2_lstm_step_bwd_launch(&s, 1, st));
+        // (2),(3) attention backward
+        AttnBwdK k;
+        memset(&k, 0, sizeof(k));
+        k.B = B; k.L = L; k.Ad = Ad; k.Ef = Ef;
+        k.dctx = a->dctx_tot + (long)t * B * Ef; k.lddctx = Ef;
+        k.ctx = a->xdec + (long)(t + 1) * B * ldx + A; k.ldctx = ldx;
+        k.w = a->align + (long)t * L; k.ldw = (long)T * L;
+        k.memory = a->memory;
+        k.din_part = last ? nullptr : a->din_part;
+        k.G_in = last ? nullptr : a->G + (long)((t + 1) & 1) * B * L;
+        k.G_out = a->G + (long)(t & 1) * B * L;
+        k.de = a->de;
+        k.th = a->th + (long)t * B * Ad * L; k.v = a->v; k.U = a->U;
+        if (t > 0) { k.w_prev = a->align + (long)(t - 1) * L; k.ldwp = (long)T * L; }
+        k.cum_prev = a->cum + (long)t * B * L; k.ldcp = L;
+        k.dpmT = a->dpmT; k.dq = a->dq + (long)t * B * Ad; k.lddq = Ad;
+        k.dv_part = a->dv_part; k.dU_part = a->dU_part; k.din_part_out = a->din_part;
+        hipLaunchKernelGGL(attn_bwd_dw_kernel, dim3(B, t2_cdiv(L, 32)), dim3(256), sm_dw, st, k);
+        hipLaunchKernelGGL(attn_bwd_ds_kernel, dim3(B, NA), dim3(256), sm_ds, st, k);
+        // (4) attention-LSTM cell backward: dh = dh_ext + dgates_{t+1}.W_hh + dq_t.Wq
+        T2LstmBwdStep c;
+        memset(&c, 0, sizeof(c));
+        c.B = B; c.H = A; c.N4 = 4 * A; c.dg_next = dg_next; c.lddg = 4 * A; c.W = a->W_hh; c.ldw = A;
+        c.dg2 = a->dq + (long)t * B * Ad; c.lddg2 = Ad; c.W2 = a->Wq; c.ldw2 = A; c.N2 = Ad;
+        c.ncols = A; c.epi = 1;
+        c.ext1 = a->dh_ext + (long)t * B * a->ld_dh; c.ldx1 = a->ld_dh;
+        if (a->att_drop) { c.drop = a->att_drop + (long)t * B * A; c.lddrop = A; }
+        c.gates = a->gates + (long)t * B * 4 * A; c.ldgs = 4 * A;
+        c.c_prev = a->att_c + (long)t * B * A; c.ldcp = A;
+        c.c_cur = a->att_c + (long)(t + 1) * B * A; c.ldcc = A;
+        c.dc = a->dc; c.lddc = A;
+        c.dg_out = a->dgates + (long)t * B * 4 * A; c.ldgo = 4 * A;
+        T2_TRY(t2_lstm_step_bwd_launch(&c, 1, st));
+    }
+    T2_CHECK_LAUNCH();
+    return T2_OK;
+}

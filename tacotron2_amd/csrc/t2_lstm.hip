@@ -202,6 +202,7 @@ struct BwdK {
     int B, H, N4;                       // N4 = reduction length (4H of the producing cell)
     const float* dg_next; long lddg;    // [b][N4] or null (no recurrent contribution)
     const float* W; long ldw;           // element (n,u) at W[n*ldw + u]
+    const float* dg2; long lddg2; const float* W2; long ldw2; int N2;   // optional second K segment
     int ncols;                          // number of output columns u (H for the recurrent path)
     int epi;                            // 0: plain store of dx (+ext), 1: LSTM pointwise backward
     const float* ext1; long ldx1; const float* ext2; long ldx2;
@@ -211,6 +212,7 @@ struct BwdK {
     const float* c_prev; long ldcp; const float* c_cur; long ldcc;
     float* dc; long lddc;
     float* dg_out; long ldgo;
+    float* dg_out2; long ldgo2;
     const int32_t* len; int t;
 };
 struct BwdK2 { BwdK s[2]; };
@@ -222,13 +224,14 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(BwdK2 pp) {
     const int r = lane & 15, q = lane >> 4;
     const int u0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    if (p.dg_next) {
+    {
         const int row = b0 + r;
         const bool rin = row < p.B;
-        const float* ap = p.dg_next + (long)(rin ? row : 0) * p.lddg + 4 * q;
         const bool cin = (u0 + r) < p.ncols;
-        const float* bp = p.W + (long)(4 * q) * p.ldw + u0 + (cin ? r : 0);
-        const int nch = p.N4 >> 4;
+        const long arow = rin ? row : 0;
+        const int ucol = u0 + (cin ? r : 0);
+        const int nch1 = p.dg_next ? (p.N4 >> 4) : 0;
+        const int nch = nch1 + (p.dg2 ? (p.N2 >> 4) : 0);
         constexpr int U = 4;
         auto load_group = [&](int c0, f32x4 (&a)[U], f32x4 (&b)[U]) {
 #pragma unroll
@@ -237,11 +240,13 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(BwdK2 pp) {
                 a[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 b[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (c < nch) {
-                    if (rin) a[j] = *reinterpret_cast<const f32x4*>(ap + 16 * c);
-                    if (cin) {
-                        const float* bq = bp + (long)(16 * c) * p.ldw;
-                        b[j][0] = bq[0]; b[j][1] = bq[p.ldw]; b[j][2] = bq[2 * p.ldw]; b[j][3] = bq[3 * p.ldw];
-                    }
+                    const bool s2 = c >= nch1;
+                    const int lc = s2 ? c - nch1 : c;
+                    const float* ap = (s2 ? p.dg2 + arow * p.lddg2 : p.dg_next + arow * p.lddg) + 16 * lc + 4 * q;
+                    const long ldw = s2 ? p.ldw2 : p.ldw;
+                    const float* bq = (s2 ? p.W2 : p.W) + (long)(16 * lc + 4 * q) * ldw + ucol;
+                    if (rin) a[j] = *reinterpret_cast<const f32x4*>(ap);
+                    if (cin) { b[j][0] = bq[0]; b[j][1] = bq[ldw]; b[j][2] = bq[2 * ldw]; b[j][3] = bq[3 * ldw]; }
                 }
             }
         };
@@ -254,18 +259,20 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(BwdK2 pp) {
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][3], b[j][3], acc1, 0, 0, 0);
             }
         };
-        f32x4 aA[U], bA[U], aB[U], bB[U];
-        int c = w;
-        load_group(c, aA, bA); c += 4 * U;
-        while (true) {
-            load_group(c, aB, bB);
-            mma_group(aA, bA);
-            if (c >= nch) break;
-            c += 4 * U;
-            load_group(c, aA, bA);
-            mma_group(aB, bB);
-            if (c >= nch) break;
-            c += 4 * U;
+        if (nch > 0) {
+            f32x4 aA[U], bA[U], aB[U], bB[U];
+            int c = w;
+            load_group(c, aA, bA); c += 4 * U;
+            while (true) {
+                load_group(c, aB, bB);
+                mma_group(aA, bA);
+                if (c >= nch) break;
+                c += 4 * U;
+                load_group(c, aA, bA);
+                mma_group(aB, bB);
+                if (c >= nch) break;
+                c += 4 * U;
+            }
         }
     }
 #pragma unroll
@@ -300,6 +307,10 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(BwdK2 pp) {
                 p.dc[(long)b * p.lddc + u] = dcp;
                 float* dgo = p.dg_out + (long)b * p.ldgo + u;
                 dgo[0] = d_i; dgo[H] = d_f; dgo[2 * H] = d_g; dgo[3 * H] = d_o;
+                if (p.dg_out2) {
+                    float* dg2o = p.dg_out2 + (long)b * p.ldgo2 + u;
+                    dg2o[0] = d_i; dg2o[H] = d_f; dg2o[2 * H] = d_g; dg2o[3 * H] = d_o;
+                }
             }
         }
     }
@@ -308,6 +319,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(BwdK2 pp) {
 void to_bk(const T2LstmBwdStep& s, BwdK& k) {
     k.B = s.B; k.H = s.H; k.N4 = s.N4;
     k.dg_next = s.dg_next; k.lddg = s.lddg; k.W = s.W; k.ldw = s.ldw; k.ncols = s.ncols; k.epi = s.epi;
+    k.dg2 = s.dg2; k.lddg2 = s.lddg2; k.W2 = s.W2; k.ldw2 = s.ldw2; k.N2 = s.N2; k.dg_out2 = s.dg_out2; k.ldgo2 = s.ldgo2;
     k.ext1 = s.ext1; k.ldx1 = s.ldx1; k.ext2 = s.ext2; k.ldx2 = s.ldx2;
     k.dx_out = s.dx_out; k.lddx = s.lddx; k.drop = s.drop; k.lddrop = s.lddrop;
     k.gates = s.gates; k.ldgs = s.ldgs; k.c_prev = s.c_prev; k.ldcp = s.ldcp; k.c_cur = s.c_cur; k.ldcc = s.ldcc;
@@ -319,6 +331,9 @@ int check_bwd(const T2LstmBwdStep& s) {
     if (s.dg_next) {
         T2_REQUIRE(s.N4 % 16 == 0 && s.lddg % 4 == 0 && t2_aligned16(s.dg_next), "lstm bwd step: dg_next alignment");
         T2_REQUIRE(s.W != nullptr, "lstm bwd step: W required with dg_next");
+    }
+    if (s.dg2) {
+        T2_REQUIRE(s.N2 % 16 == 0 && s.lddg2 % 4 == 0 && t2_aligned16(s.dg2) && s.W2, "lstm bwd step: dg2 alignment");
     }
     if (s.epi == 1) {
         T2_REQUIRE(s.gates && s.c_cur && s.dc && s.dg_out && s.ncols == s.H, "lstm bwd step: epilogue operands");
@@ -389,6 +404,7 @@ extern "C" int t2_lstm_seq_bwd(const T2LstmBwdStep* base, const T2LstmBwdStride*
             adv(cur[i].ext1, inc[i].ext1); adv(cur[i].ext2, inc[i].ext2); adv(cur[i].drop, inc[i].drop);
             adv(cur[i].gates, inc[i].gates); adv(cur[i].c_prev, inc[i].c_prev); adv(cur[i].c_cur, inc[i].c_cur);
             adv(cur[i].dg_out, inc[i].dg);
+            adv(cur[i].dg_out2, inc[i].dg2);
             cur[i].t += inc[i].dt;
         }
     }

@@ -145,7 +145,7 @@ class Engine:
             ic.pre = sg * 8 * H; ic.c_prev = sg * B * H; ic.h_out = sg * B * H; ic.h_out2 = sg * E
             ic.c_out = sg * B * H; ic.gates_out = sg * B * 4 * H; ic.dt = sg
         call("t2_lstm_seq_fwd", steps, incs, 2, S, _stream())
-        ctx["enc"] = dict(x3=x, pre=pre, hs=hs, cs=cs, gs=gs, B=B, L=L)
+        ctx["enc_stash"] = dict(x3=x, pre=pre, hs=hs, cs=cs, gs=gs, B=B, L=L)
         return enc
 
     # ---- full teacher-forced forward -------------------------------------------------------------
@@ -270,3 +270,235 @@ class Engine:
                    xproj=xproj, gates_att=gates_att, th=th, align=align, pre_dec=pre_dec, dec_c=dec_c,
                    gates_dec=gates_dec, proj=proj, post_in=post_in, masks=masks, training=training)
         return (mels, post, gates, align), ctx
+
+    # =============================================================================================
+    # backward
+    # =============================================================================================
+    def _wgrad(self, dY, ldy, X, ldx, Cgrad, ldc, Mout, Nin, R):
+        """Cgrad[Mout, Nin] += dY[R, Mout]^T @ X[R, Nin]  (split-K, fp32 atomics into the zero-initialised grad buffer)."""
+        gemm(dY, X, Cgrad, Mout, Nin, R, ldy, ldx, ldc, a_k=0, b_k=0, accumulate=2, splitk=splitk_for(Mout, Nin, R))
+
+    def conv_bn_bwd(self, tag, ctx, dy, Lp_dy, pad_dy, w, gw, gbias, bn_prefix, B, L, Ci, Co, act, training, need_dx=True):
+        """Backward of conv_bn_fwd.  dy: gradient w.r.t. the layer output.  Returns dX in shifted rows (B*(L+4), Ci)."""
+        P, G = self.ps.P, self.ps.G
+        c = ctx[tag]
+        Lp = L + 4
+        st = _stream()
+        draw = self.buf(f"{tag}.draw", B, Lp, Co)
+        sums = self.buf(f"{tag}.sums", 2 * Co, dtype=torch.float64)
+        bn = make("T2Bn", B=B, L=L, C=Co, x=c["raw"], Lp_x=Lp, gamma=P[bn_prefix + ".weight"], beta=P[bn_prefix + ".bias"],
+                  training=1 if training else 0, momentum=0.1, eps=1e-5, sums=sums, mean=c["mean"], invstd=c["invstd"],
+                  act=act, drop=c["drop"], dy=dy, Lp_dy=Lp_dy, pad_dy=pad_dy, dx=draw, Lp_dx=Lp, pad_dx=2,
+                  dgamma=G[bn_prefix + ".weight"], dbeta=G[bn_prefix + ".bias"])
+        call("t2_bn_bwd", bn, st)
+        R = B * Lp - 4
+        if gbias is not None:
+            call("t2_colsum", draw, Co, B * Lp, Co, gbias, st)
+        dwp = self.buf(f"{tag}.dwp", Co, 5 * Ci, zero=True)
+        self._wgrad(_ptr(draw, 2 * Co), Co, c["x_pad"], Ci, dwp, 5 * Ci, Co, 5 * Ci, R)
+        call("t2_unpack_conv_wgrad", dwp, gw, Co, Ci, 5, st)
+        if not need_dx:
+            return None
+        wf = self.buf(f"{tag}.wf", Ci, 5 * Co)
+        call("t2_pack_conv_weight", w, wf, Co, Ci, 5, 1, st)
+        dx = self.buf(f"{tag}.dx", B * Lp, Ci)
+        gemm(draw, wf, dx, R, Ci, 5 * Co, Co, 5 * Co, Ci)
+        return dx
+
+    def backward_tf(self, ctx, d_post, dproj):
+        """d_post (B,T,M): gradient w.r.t. mels_post (masked positions zero).  dproj [T][B][M+1]: gradient w.r.t. the
+        decoder projection from the mel / residual / gate terms.  Accumulates into ps.grad (caller zeroes it)."""
+        d, P, G, ps = self.d, self.ps.P, self.ps.G, self.ps
+        B, L, T = ctx["B"], ctx["L"], ctx["T"]
+        M, E, Pd, A, D, Ad = d["num_mels"], d["encoded_dim"], d["prenet_dim"], d["att_rnn_dim"], d["rnn_hidden_dim"], d["att_dim"]
+        Ef = E + (128 if d.get("description_embeddings") else 0)
+        F = d.get("loc_filters", 32)
+        H = E // 2
+        Pn = d["postnet_dim"]
+        st = _stream()
+        training = ctx["training"]
+        masks = ctx["masks"]
+        R, R1 = T * B, (T + 1) * B
+        ldp, ldx = D + Ef, A + Ef
+
+        # ---- postnet --------------------------------------------------------------------------------
+        chans = [M, Pn, Pn, Pn, Pn, M]
+        dy, Lp_dy = d_post, T
+        for li in range(4, -1, -1):
+            dy = self.conv_bn_bwd(f"post.conv{li}", ctx, dy, Lp_dy, 0, P[f"postnet.postnet.{4 * li}.weight"],
+                                  G[f"postnet.postnet.{4 * li}.weight"], None, f"postnet.postnet.{4 * li + 1}", B, T,
+                                  chans[li], chans[li + 1], 0 if li == 4 else 2, training)
+            Lp_dy = T + 4
+        call("t2_finalize_bwd", dy, dproj, B, T, M, st)
+
+        # ---- mel/stop projection ----------------------------------------------------------------------
+        xproj, xdec = ctx["xproj"], ctx["xdec"]
+        wproj = ps.cat_view("decoder.mel_out.weight", M + 1, ldp)
+        dxproj = self.buf("dxproj", T, B, ldp)
+        gemm(dproj, wproj, dxproj, R, ldp, M + 1, M + 1, ldp, ldp, a_k=1, b_k=0)
+        self._wgrad(dproj, M + 1, _ptr(xproj, B * ldp), ldp, ps.cat_view("decoder.mel_out.weight", M + 1, ldp, grad=True),
+                    ldp, M + 1, ldp, R)
+        call("t2_colsum", dproj, M + 1, R, M + 1, ps.cat_view("decoder.mel_out.bias", M + 1, 0, grad=True), st)
+
+        # ---- decoder-LSTM chain, back-propagation through time ----------------------------------------------
+        dgd = self.buf("dgd", T, B, 4 * D)
+        dc_dec = self.buf("dc_dec", B, D, zero=True)
+        dd = masks.get("dec_drop")
+        s = make("T2LstmBwdStep", B=B, H=D, N4=4 * D, W=P["decoder.lstm.weight_hh"], ldw=D, ncols=D, epi=1,
+                 ext1=_ptr(dxproj, (T - 1) * B * ldp), ldx1=ldp,
+                 drop=_ptr(dd, (T - 1) * B * D) if dd is not None else None, lddrop=D,
+                 gates=_ptr(ctx["gates_dec"], (T - 1) * B * 4 * D), ldgs=4 * D,
+                 c_prev=_ptr(ctx["dec_c"], (T - 1) * B * D), ldcp=D, c_cur=_ptr(ctx["dec_c"], T * B * D), ldcc=D,
+                 dc=dc_dec, lddc=D, dg_out=_ptr(dgd, (T - 1) * B * 4 * D), ldgo=4 * D)
+        inc = make("T2LstmBwdStride", dg=-B * 4 * D, ext1=-B * ldp, drop=-B * D, gates=-B * 4 * D, c_prev=-B * D,
+                   c_cur=-B * D, dt=0)
+        call("t2_lstm_seq_bwd", s, inc, 1, T, st)
+        self._wgrad(dgd, 4 * D, _ptr(xdec, B * ldx), ldx, G["decoder.lstm.weight_ih"], ldx, 4 * D, ldx, R)
+        self._wgrad(dgd, 4 * D, xproj, ldp, G["decoder.lstm.weight_hh"], D, 4 * D, D, R)
+        call("t2_colsum", dgd, 4 * D, R, 4 * D, G["decoder.lstm.bias_ih"], st)
+        call("t2_colsum", dgd, 4 * D, R, 4 * D, G["decoder.lstm.bias_hh"], st)
+        dxdec = self.buf("dxdec", T, B, ldx)
+        gemm(dgd, P["decoder.lstm.weight_ih"], dxdec, R, ldx, 4 * D, 4 * D, ldx, ldx, a_k=1, b_k=0)
+
+        # ---- attention chain, back-propagation through time ---------------------------------------------------
+        dga = self.buf("dga", T, B, 4 * A)
+        dctx_tot = self.buf("dctx_tot", T, B, Ef)
+        dq = self.buf("dq", T, B, Ad)
+        dpmT = self.buf("dpmT", B, Ad, L, zero=True)
+        dv_part = self.buf("dv_part", B, Ad, zero=True)
+        dU_part = self.buf("dU_part", B, Ad * 2 * KL, zero=True)
+        dc_att = self.buf("dc_att", B, A, zero=True)
+        Gc = self.buf("Gcum", 2, B, L)
+        de = self.buf("de", B, L)
+        din_part = self.buf("din_part", B, Ad // 16, 2, L)
+        sb = make("T2AttnSeqBwd", B=B, L=L, T=T, A=A, Ad=Ad, Ef=Ef, Kl=KL,
+                  W_ih_ctx=_ptr(P["decoder.att_rnn.weight_ih"], Pd), ld_wih=Pd + Ef, W_hh=P["decoder.att_rnn.weight_hh"],
+                  Wq=P["decoder.attention.query_layer.weight"], U=ctx["U"], v=P["decoder.attention.v.weight"],
+                  memory=ctx["memory"], xdec=xdec, att_c=ctx["att_c"], gates=ctx["gates_att"], align=ctx["align"],
+                  cum=ctx["cum"], th=ctx["th"], att_drop=masks.get("att_drop"),
+                  dh_ext=dxdec, ld_dh=ldx, dctx_ext1=_ptr(dxdec, A), ld_dc1=ldx, dctx_ext2=_ptr(dxproj, D), ld_dc2=ldp,
+                  dgates=dga, dctx_tot=dctx_tot, dq=dq, dpmT=dpmT, dv_part=dv_part, dU_part=dU_part,
+                  dc=dc_att, G=Gc, de=de, din_part=din_part)
+        call("t2_attn_seq_bwd", sb, st)
+
+        # weight gradients of the attention chain (large GEMMs over all frames)
+        gWih = G["decoder.att_rnn.weight_ih"]
+        self._wgrad(dga, 4 * A, ctx["p2"], Pd, gWih, Pd + Ef, 4 * A, Pd, R)
+        self._wgrad(dga, 4 * A, _ptr(xdec, A), ldx, _ptr(gWih, Pd), Pd + Ef, 4 * A, Ef, R)
+        self._wgrad(dga, 4 * A, xdec, ldx, G["decoder.att_rnn.weight_hh"], A, 4 * A, A, R)
+        call("t2_colsum", dga, 4 * A, R, 4 * A, G["decoder.att_rnn.bias_ih"], st)
+        call("t2_colsum", dga, 4 * A, R, 4 * A, G["decoder.att_rnn.bias_hh"], st)
+        self._wgrad(dq, Ad, _ptr(xdec, B * ldx), ldx, G["decoder.attention.query_layer.weight"], A, Ad, A, R)
+        call("t2_colsum", dv_part, Ad, B, Ad, G["decoder.attention.v.weight"], st)
+        dU = self.buf("dU", Ad, 2 * KL, zero=True)
+        call("t2_colsum", dU_part, Ad * 2 * KL, B, Ad * 2 * KL, dU, st)
+        Wd, Wc = P["decoder.attention.location_dense.weight"], P["decoder.attention.location_conv.weight"]
+        gemm(dU, Wc, G["decoder.attention.location_dense.weight"], Ad, F, 2 * KL, 2 * KL, 2 * KL, F, accumulate=1)
+        gemm(Wd, dU, G["decoder.attention.location_conv.weight"], F, 2 * KL, Ad, F, 2 * KL, 2 * KL, a_k=0, b_k=0,
+             accumulate=1)
+
+        # gradient w.r.t. the encoder memory: context path (batched over samples) + processed-memory path
+        dmem = self.buf("dmem", B, L, Ef)
+        gemm(ctx["align"], dctx_tot, dmem, L, Ef, T, L, B * Ef, Ef, a_k=0, b_k=0, batch=B, sA=T * L, sB=Ef, sC=L * Ef)
+        Watt = P["att_encoder.weight"]
+        gemm(dpmT, Watt, dmem, L, Ef, Ad, L, Ef, Ef, a_k=0, b_k=0, accumulate=1, batch=B, sA=Ad * L, sB=0, sC=L * Ef)
+        gemm(dpmT, ctx["memory"], G["att_encoder.weight"], Ad, Ef, L, L, Ef, Ef, a_k=1, b_k=0, accumulate=2, batch=B,
+             sA=Ad * L, sB=L * Ef, sC=0)
+
+        # ---- prenet -----------------------------------------------------------------------------------------
+        dp2 = self.buf("dp2", T + 1, B, Pd)
+        dp2[T].zero_()
+        gemm(dga, P["decoder.att_rnn.weight_ih"], dp2, R, Pd, 4 * A, 4 * A, Pd + Ef, Pd, a_k=1, b_k=0)
+        pd = ctx["pd"]
+        g2 = self.buf("g2", T + 1, B, Pd)
+        call("t2_relu_mask_bwd", dp2, ctx["p2"], pd[1] if pd else None, g2, R1 * Pd, st)
+        self._wgrad(g2, Pd, ctx["p1"], Pd, G["prenet.3.weight"], Pd, Pd, Pd, R1)
+        dp1 = self.buf("dp1", T + 1, B, Pd)
+        gemm(g2, P["prenet.3.weight"], dp1, R1, Pd, Pd, Pd, Pd, Pd, a_k=1, b_k=0)
+        g1 = self.buf("g1", T + 1, B, Pd)
+        call("t2_relu_mask_bwd", dp1, ctx["p1"], pd[0] if pd else None, g1, R1 * Pd, st)
+        self._wgrad(g1, Pd, ctx["mel_tm"], M, G["prenet.0.weight"], M, Pd, M, R1)
+
+        # ---- conditioning ---------------------------------------------------------------------------------------
+        denc = self.buf("denc", B, L, E)
+        ddesc = self.buf("ddesc", B, 128) if d.get("description_embeddings") else None
+        call("t2_condition_bwd", dmem, ctx["memory"], ctx["spk32"], denc,
+             G["speaker_embedding.weight"] if d.get("speaker_tokens") else None, ddesc, B, L, E, Ef, st)
+        if ddesc is not None:
+            Dd = d["description_embeddings_dim"]
+            dlin = self.buf("dlin", B, 128)
+            call("t2_tanh_bwd", ddesc, ctx["desc"], dlin, B * 128, st)
+            self._wgrad(dlin, 128, ctx["desc_in"], Dd, G["description_embeddings_linear.0.weight"], Dd, 128, Dd, B)
+            call("t2_colsum", dlin, 128, B, 128, G["description_embeddings_linear.0.bias"], st)
+
+        # ---- encoder BiLSTM ---------------------------------------------------------------------------------------
+        e = ctx["enc_stash"]
+        S, Lp = L, L + 4
+        hs, cs, gs = e["hs"], e["cs"], e["gs"]
+        dgt = self.buf("enc.dgt", 2, S, B, 4 * H)
+        dpre = self.buf("enc.dpre", B * Lp, 8 * H, zero=True)
+        dc_enc = self.buf("enc.dc", 2, B, H, zero=True)
+        steps = (_lib.S["T2LstmBwdStep"] * 2)()
+        incs = (_lib.S["T2LstmBwdStride"] * 2)()
+        len32 = ctx["len32"]
+        for dr in range(2):
+            sg = -1 if dr == 0 else 1                 # BPTT runs against the forward processing order
+            t0 = S - 1 if dr == 0 else 0
+            whh = P["encoder.lstm.weight_hh_l0" + ("" if dr == 0 else "_reverse")]
+            sp = steps[dr]
+            sp.B, sp.H, sp.N4, sp.ncols, sp.epi = B, H, 4 * H, H, 1
+            sp.W = whh.data_ptr(); sp.ldw = H
+            sp.ext1 = _ptr(denc, t0 * E + dr * H); sp.ldx1 = L * E
+            sp.gates = _ptr(gs[dr, t0]); sp.ldgs = 4 * H
+            sp.c_prev = _ptr(cs[dr, t0 if dr == 0 else t0 + 1]); sp.ldcp = H
+            sp.c_cur = _ptr(cs[dr, t0 + 1 if dr == 0 else t0]); sp.ldcc = H
+            sp.dc = _ptr(dc_enc[dr]); sp.lddc = H
+            sp.dg_out = _ptr(dgt[dr, t0]); sp.ldgo = 4 * H
+            sp.dg_out2 = _ptr(dpre, t0 * 8 * H + dr * 4 * H); sp.ldgo2 = Lp * 8 * H
+            sp.len = len32.data_ptr(); sp.t = t0
+            ic = incs[dr]
+            ic.dg = sg * B * 4 * H; ic.dg2 = sg * 8 * H; ic.ext1 = sg * E; ic.gates = sg * B * 4 * H
+            ic.c_prev = sg * B * H; ic.c_cur = sg * B * H; ic.dt = sg
+        call("t2_lstm_seq_bwd", steps, incs, 2, S, st)
+        for dr in range(2):
+            nm = "encoder.lstm.weight_hh_l0" + ("" if dr == 0 else "_reverse")
+            hprev = hs[0, 0] if dr == 0 else hs[1, 1]
+            self._wgrad(_ptr(dgt[dr]), 4 * H, hprev, H, G[nm], H, 4 * H, H, S * B)
+        Rr = B * Lp - 4
+        x3 = e["x3"]
+        self._wgrad(dpre, 8 * H, _ptr(x3, 2 * E), E, ps.cat_view("encoder.lstm.weight_ih_l0", 8 * H, E, grad=True), E, 8 * H, E, Rr)
+        call("t2_colsum", dpre, 8 * H, B * Lp, 8 * H, ps.cat_view("encoder.lstm.bias_ih_l0", 8 * H, 0, grad=True), st)
+        call("t2_colsum", dpre, 8 * H, B * Lp, 8 * H, ps.cat_view("encoder.lstm.bias_hh_l0", 8 * H, 0, grad=True), st)
+        dx = self.buf("enc.dx3", B * Lp, E)
+        gemm(dpre, ps.cat_view("encoder.lstm.weight_ih_l0", 8 * H, E), dx, Rr, E, 8 * H, 8 * H, E, E, a_k=1, b_k=0)
+
+        # ---- encoder convolutions + embedding -----------------------------------------------------------------
+        for li, i in reversed(list(enumerate((0, 4, 8)))):
+            dx = self.conv_bn_bwd(f"enc.conv{li}", ctx, dx, Lp, 0, P[f"encoder.convolutions.{i}.weight"],
+                                  G[f"encoder.convolutions.{i}.weight"], G[f"encoder.convolutions.{i}.bias"],
+                                  f"encoder.convolutions.{i + 1}", B, L, E, E, 1, training)
+        call("t2_embedding_bwd", ctx["chars_idx"], dx, G["encoder.embedding.weight"], B, L, E, Lp, 0, st)
+
+    # =============================================================================================
+    # loss + one optimisation step
+    # =============================================================================================
+    def loss_and_grads(self, outs, ctx, mel_tgt, gate_tgt, grad_scale=1.0):
+        """3-term loss of model/tts_model.py:197-201 and the full backward.  Returns loss3 (device, float64[3])."""
+        mels, post, gates, _ = outs
+        B, T, M = mels.shape
+        loss3 = self.buf("loss3", 3, dtype=torch.float64)
+        d_post = self.buf("d_post", B, T, M)
+        dproj = self.buf("dproj", T, B, M + 1)
+        call("t2_loss_fwd_bwd", mels, post, gates, mel_tgt, gate_tgt, ctx["mlen32"], B, T, M, loss3, d_post, dproj,
+             float(grad_scale), _stream())
+        self.backward_tf(ctx, d_post, dproj)
+        return loss3
+
+    def adam_step(self, step, lr, weight_decay, max_norm=1.0, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):
+        ps = self.ps
+        ps.init_adam()
+        sumsq = self.buf("sumsq", 1, dtype=torch.float64)
+        call("t2_sumsq", ps.grad, ps.numel, sumsq, _stream())
+        call("t2_adam_step", ps.flat, ps.grad, ps.exp_avg, ps.exp_avg_sq, ps.numel, sumsq, float(max_norm), float(lr),
+             float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step), float(grad_scale), _stream())
+        return sumsq

@@ -65,7 +65,8 @@ def test_forward_eval_matches_reference_golden():
     assert mx(gates, z["o_gates"]) < 2e-4
     ml = z["mel_len"]
     for b in range(len(ml)):
-        assert float(mels[b, ml[b]:].abs().max()) == 0.0 and bool((gates[b, ml[b]:] == -1000.0).all())
+        if ml[b] < mels.shape[1]:
+            assert float(mels[b, ml[b]:].abs().max()) == 0.0 and bool((gates[b, ml[b]:] == -1000.0).all())
 
 
 @pytest.mark.parametrize("name,extra", [("tf_train", {}),
@@ -129,3 +130,86 @@ def test_forward_train_midsize_matches_oracle():
     assert l1(mels, ref[0]) < MEL_L1_TOL and l1(post, ref[1]) < MEL_L1_TOL
     assert mx(al, ref[3]) < 2e-5
     assert mx(mels, ref[0]) < 1e-3 and mx(post, ref[1]) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------------
+# backward / training step
+# ------------------------------------------------------------------------------------------------------
+def _grad_check(ps, ref_grads, tol=3e-4, floor=1e-3):
+    """relative-to-scale comparison of every parameter gradient."""
+    bad = []
+    for name, g in ps.G.items():
+        r = torch.as_tensor(ref_grads[name]).double()
+        got = g.double().cpu()
+        scale = max(float(r.abs().max()), floor)
+        err = float((got - r).abs().max()) / scale
+        if not err < tol:
+            bad.append((name, err, scale))
+    assert not bad, "gradient mismatch: " + ", ".join(f"{n}: rel {e:.2e} (scale {s:.2e})" for n, e, s in bad[:12])
+
+
+@pytest.mark.parametrize("name,extra", [("tf_train", {}),
+                                        ("tf_train_desc", dict(speaker_tokens=True, num_speakers=7,
+                                                               description_embeddings=True, description_embeddings_dim=24))])
+def test_backward_matches_reference_golden(name, extra):
+    dev = _dev()
+    z = load_golden(name)
+    d = R.default_dims(**SMALL, dropout=0.5, **extra)
+    eng, ps = build_engine(d, params_from(z), dev)
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    kw = {}
+    if "speaker_id" in z:
+        kw["speaker_id"] = t("speaker_id")
+    if "description_embeddings" in z:
+        kw["description_embeddings"] = t("description_embeddings")
+    outs, ctx = eng.forward_tf(t("chars_idx"), t("chars_len"), t("mel"), t("mel_len"), training=True,
+                               masks=masks_to_device(tf_masks_from(z), dev), **kw)
+    ps.grad.zero_()
+    loss3 = eng.loss_and_grads(outs, ctx, t("mel"), t("gate"))
+    torch.cuda.synchronize()
+    l3 = loss3.cpu().numpy()
+    assert abs(l3.sum() - z["o_loss"][0]) < 1e-5 * max(1.0, abs(z["o_loss"][0]))
+    assert np.allclose(l3, z["o_loss"][1:], rtol=1e-5, atol=1e-6)
+    _grad_check(ps, {k[2:]: v for k, v in z.items() if k.startswith("g.")})
+
+
+def test_train_step_midsize_matches_oracle():
+    """Two full optimisation steps (forward, loss, backward, global-norm clip, Adam with L2) at mid-size dims against
+    the CPU oracle driven by autograd + torch-free Adam restatement."""
+    dev = _dev()
+    d = R.default_dims(num_chars=39, encoded_dim=128, prenet_dim=64, att_rnn_dim=256, att_dim=64, rnn_hidden_dim=256,
+                       postnet_dim=128, num_mels=80, dropout=0.5)
+    P = R.init_params(d, seed=5)
+    eng, ps = build_engine(d, P, dev)
+    lr, wd = 1e-3, 1e-6
+    Pc = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not R.is_buffer(k)) else v.clone()) for k, v in P.items()}
+    m_ = {k: torch.zeros_like(v) for k, v in Pc.items() if v.requires_grad}
+    v_ = {k: torch.zeros_like(v) for k, v in Pc.items() if v.requires_grad}
+    for step in (1, 2):
+        ci, lens, mel, tl, gate, masks = random_case(d, 4, 33, 29, 100 + step, dev)
+        # --- oracle ---
+        new_stats = {}
+        o = R.tacotron2_fwd(Pc, d, ci, lens, True, mel, tl, training=True, masks=masks, new_stats=new_stats)
+        loss = R.tts_loss(o[0], o[1], o[2], mel, gate)[0]
+        names = [k for k, v in Pc.items() if v.requires_grad]
+        grads = torch.autograd.grad(loss, [Pc[k] for k in names])
+        coef, tot = R.clip_coef(list(grads), 1.0)
+        # --- HIP ---
+        outs, ctx = eng.forward_tf(ci.to(dev), lens.to(dev), mel.to(dev), tl.to(dev), training=True,
+                                   masks=masks_to_device(masks, dev))
+        ps.grad.zero_()
+        loss3 = eng.loss_and_grads(outs, ctx, mel.to(dev), gate.to(dev))
+        sumsq = eng.adam_step(step, lr, wd, max_norm=1.0)
+        torch.cuda.synchronize()
+        assert abs(float(loss3.sum()) - float(loss)) < 2e-5 * max(1.0, abs(float(loss)))
+        assert abs(float(sumsq.sqrt()) - tot) < 1e-3 * tot
+        if step == 1:
+            _grad_check(ps, {k: g for k, g in zip(names, grads)})
+        with torch.no_grad():
+            for k, g in zip(names, grads):
+                p_new, m_[k], v_[k] = R.adam_l2_step(Pc[k].detach(), g * coef, m_[k], v_[k], step, lr, wd)
+                Pc[k] = p_new.requires_grad_(True)
+            for k, v in new_stats.items():
+                Pc[k] = v
+        worst = max(float((ps.P[k].double().cpu() - Pc[k].detach().double()).abs().max()) for k in names)
+        assert worst < 2e-5, f"parameter drift after step {step}: {worst}"
