@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Headline benchmark: LJSpeech-shaped teacher-forced TRAINING throughput (mel-frames/s, whole job) of the
+hand-written gfx950 path, one process per GPU (RCCL gradient all-reduce for N > 1).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One step = dropout-mask generation + forward + 3-term loss + backward + [all-reduce] + global-norm clip + Adam on one
+synthetic batch of 32 utterances per GPU (SURVEY.md section 8d shapes, vanilla-lj-hifi-stop dims: 4 speaker tokens,
+fp32, random-init weights).  Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+VANILLA = dict(num_chars=39, encoded_dim=512, encoder_kernel_size=5, num_mels=80, prenet_dim=256, att_rnn_dim=1024,
+               att_dim=128, rnn_hidden_dim=1024, postnet_dim=512, dropout=0.5, speaker_tokens=True, num_speakers=4,
+               description_embeddings=False, description_embeddings_dim=0)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+
+
+def decoder_step_bytes(B, L, Ef, P=256, A=1024, D=1024, Ad=128, M=80, F=32, Kl=31):
+    """Algorithmic bytes of ONE fused decoder step: weights once + per-sample streams."""
+    w = (4 * A * (P + Ef + A) + 8 * A + 4 * D * (A + Ef + D) + 8 * D + A * Ad + Ad + F * 2 * Kl + Ad * F
+         + (D + Ef) * M + M + (D + Ef) + 1)
+    r = 4 * (L * Ad + L * Ef + 2 * L + 2 * A + 2 * D + Ef + P) + L
+    wr = 4 * (2 * A + 2 * D + Ef + M + 1 + 2 * L)
+    return 4 * w + B * (r + wr)
+
+
+def cpu_baseline(dims, batch, t_cap, b_cap):
+    """Oracle (CPU restatement pinned to the reference, oracle/tacotron2_ref.py) timed on this host's cores on a bounded
+    sample of the same workload: the first b_cap utterances, frames capped at t_cap, one fwd+loss+bwd+Adam step."""
+    from oracle import tacotron2_ref as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    d = R.default_dims(**dims)
+    P = R.init_params(d, seed=0)
+    for v in P.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    ci = batch["chars_idx"][:b_cap]; cl = batch["chars_idx_len"][:b_cap]
+    L = int(cl.max()); ci = ci[:, :L]
+    tl = torch.clamp(batch["mel_spectrogram_len"][:b_cap], max=t_cap)
+    T = int(tl.max())
+    mel = batch["mel_spectrogram"][:b_cap, :T]; gate = batch["gate"][:b_cap, :T]
+    spk = batch["speaker_id"][:b_cap] if "speaker_id" in batch else None
+    g = torch.Generator().manual_seed(0)
+    sm = lambda shape, p: (torch.rand(shape, generator=g) >= p).float() / (1 - p)
+    Pn, M = d["postnet_dim"], d["num_mels"]
+    masks = dict(enc_drop=[sm((b_cap, L, d["encoded_dim"]), 0.5) for _ in range(3)],
+                 prenet_drop=[sm((b_cap, T + 1, d["prenet_dim"]), 0.5) for _ in range(2)],
+                 att_drop=sm((T, b_cap, d["att_rnn_dim"]), 0.1), dec_drop=sm((T, b_cap, d["rnn_hidden_dim"]), 0.1),
+                 post_drop=[sm((b_cap, T, c), 0.5) for c in (Pn, Pn, Pn, Pn, M)])
+    t0 = time.perf_counter()
+    o = R.tacotron2_fwd(P, d, ci, cl, True, mel, tl, speaker_id=spk, training=True, masks=masks)
+    loss = R.tts_loss(o[0], o[1], o[2], mel, gate)[0]
+    names = [k for k, v in P.items() if v.requires_grad]
+    grads = torch.autograd.grad(loss, [P[k] for k in names])
+    coef, _ = R.clip_coef(list(grads), 1.0)
+    with torch.no_grad():
+        for k, gr in zip(names, grads):
+            R.adam_l2_step(P[k], gr * coef, torch.zeros_like(gr), torch.zeros_like(gr), 1, 1e-3, 1e-6)
+    dt = time.perf_counter() - t0
+    frames = int(tl.sum())
+    return dict(value=frames / dt, unit="mel-frames/s", cores=cores, kind="port",
+                sample=f"oracle/tacotron2_ref.py, 1 train step (fwd+loss+bwd+clip+Adam), first {b_cap} utterances of the "
+                       f"bench batch, frames capped at {t_cap} (L={L}, T={T}, {frames} valid frames), {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fixed-shape", action="store_true", help="every utterance L=160, T=860 (roofline accounting variant)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from tacotron2_amd.build import build
+    if rank == 0:
+        build(verbose=False)
+    if world > 1:
+        dist.barrier()
+    from tacotron2_amd.init import init_parameters
+    from tacotron2_amd.params import ParamStore
+    from tacotron2_amd.synthetic import ljspeech_batch
+    from tacotron2_amd.trainer import Trainer
+
+    ps = ParamStore(VANILLA, dev)
+    init_parameters(ps, seed=0)           # identical replicas on every rank
+    tr = Trainer(ps, lr=1e-3, weight_decay=1e-6, scheduler_milestones=(50000, 75000))
+    cpu_batch = ljspeech_batch(args.batch, seed=1234 + rank, num_speakers=4,
+                               fixed_shape=(160, 860) if args.fixed_shape else None)
+    batch = {k: v.to(dev) for k, v in cpu_batch.items()}
+    batch = tr.global_pad(batch)
+    B, L = batch["chars_idx"].shape
+    T = batch["mel_spectrogram"].shape[1]
+    frames = torch.tensor([float(batch["mel_spectrogram_len"].sum()), float(B * T)], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(frames)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.train_step(batch)
+    sync()
+    tr.engine.profile = True
+    seg_acc = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss3, _ = tr.train_step(batch)
+    sync()
+    dt = time.perf_counter() - t0
+    tr.engine.profile = False
+    seg = tr.engine.segment_times_ms()       # last timed step (events recorded inside the timed region)
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+
+    if rank == 0:
+        Ef = 512
+        ms_step = dt / args.steps * 1e3
+        value = float(frames[0]) * args.steps / dt
+        # roofline of the teacher-forced decoder frame loop (north_star's "fused decoder step"): T decoder steps are
+        # executed by {pre_att GEMM, attention chain, pre_dec GEMM, decoder-LSTM chain, projection GEMM}
+        dec_fwd_ms = sum(v for k, v in seg.items() if k.startswith("fwd.dec."))
+        alg = decoder_step_bytes(B, L, Ef) * T
+        achieved = alg / (dec_fwd_ms * 1e-3) / 1e9 if dec_fwd_ms > 0 else 0.0
+        out = dict(metric="mel-frames/sec (node), LJSpeech-shaped teacher-forced train step, b=32/GPU, fp32",
+                   value=value, unit="mel-frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=ms_step, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
+                   data="synthetic",
+                   config=dict(workload="LJSpeech single-speaker train (vanilla-lj-hifi-stop.json dims), batch 32 per GPU, fp32",
+                               global_batch=B * world, L=L, T=T, valid_frames_per_step=float(frames[0]),
+                               padded_frames_per_step=float(frames[1]), parallelism=f"dp{world}"),
+                   padded_frames_per_s=float(frames[1]) * args.steps / dt,
+                   loss=[float(x) for x in loss3.cpu()],
+                   roofline=dict(bound="hbm", kernel="teacher-forced decoder frame loop, forward (pre_att GEMM + attention "
+                                 "chain + pre_dec GEMM + decoder-LSTM chain + projection GEMM = T fused decoder steps)",
+                                 achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                                 traffic=None, algorithmic_bytes_per_step=decoder_step_bytes(B, L, Ef),
+                                 us_per_decoder_step=dec_fwd_ms * 1e3 / T if T else None),
+                   segments_ms={k: round(v, 3) for k, v in seg.items()})
+        if world == 1 and not args.no_cpu_baseline:
+            dims = {k: v for k, v in VANILLA.items()}
+            out["cpu_baseline"] = cpu_baseline(dims, cpu_batch, t_cap=60, b_cap=8)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -56,6 +56,48 @@ class Engine:
         self.d = ps.dims
         self.dev = ps.device
         self._ws: Dict[str, torch.Tensor] = {}
+        self.profile = False          # when True, mark() records HIP events at segment boundaries
+        self.marks = []               # [(name, event)] of the current step
+
+    def mark(self, name: str):
+        if self.profile:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream())
+            self.marks.append((name, ev))
+
+    def segment_times_ms(self):
+        """Durations between consecutive marks of the last profiled step: {segment: ms} (summed per name)."""
+        out: Dict[str, float] = {}
+        for (n0, e0), (n1, e1) in zip(self.marks[:-1], self.marks[1:]):
+            out[n1] = out.get(n1, 0.0) + e0.elapsed_time(e1)
+        return out
+
+    def make_masks(self, B: int, L: int, T: int, training: bool, seed: int, step: int) -> dict:
+        """Dropout scale masks for one step from the device Philox generator (t2_philox_mask).  Sites and rates as
+        the reference: encoder/postnet p, prenet p always on (model/modules.py), LSTMCell outputs 0.1 (model/decoder.py:29,43)."""
+        d = self.d
+        p = float(d["dropout"])
+        E, Pd, A, D, M, Pn = d["encoded_dim"], d["prenet_dim"], d["att_rnn_dim"], d["rnn_hidden_dim"], d["num_mels"], d["postnet_dim"]
+        st = _stream()
+        sid = [step * 64]
+
+        def gen(name, n, rate):
+            m = self.buf("mask." + name, n)
+            call("t2_philox_mask", m, n, rate, seed, sid[0], st)
+            sid[0] += 1
+            return m
+
+        masks = {}
+        if p > 0.0:
+            masks["prenet_drop"] = [gen(f"pre{i}", (T + 1) * B * Pd, p).view(T + 1, B, Pd) for i in range(2)]
+        if training:
+            if p > 0.0:
+                masks["enc_drop"] = [gen(f"enc{i}", B * L * E, p).view(B, L, E) for i in range(3)]
+                chans = [Pn, Pn, Pn, Pn, M]
+                masks["post_drop"] = [gen(f"post{i}", B * T * c, p).view(B, T, c) for i, c in enumerate(chans)]
+            masks["att_drop"] = gen("att", T * B * A, 0.1).view(T, B, A)
+            masks["dec_drop"] = gen("dec", T * B * D, 0.1).view(T, B, D)
+        return masks
 
     # ---- workspace --------------------------------------------------------------------------------
     def buf(self, name: str, *shape, dtype=torch.float32, zero: bool = False) -> torch.Tensor:
@@ -166,7 +208,9 @@ class Engine:
         mlen32 = mel_len.to(torch.int32)
         ctx["len32"], ctx["mlen32"], ctx["chars_idx"] = len32, mlen32, chars_idx
 
+        self.mark("start")
         enc = self.encoder_fwd(chars_idx, len32, training, masks, ctx)
+        self.mark("fwd.encoder")
 
         # conditioning (model/tacotron2.py:201-229)
         memory = self.buf("memory", B, L, Ef)
@@ -183,6 +227,7 @@ class Engine:
         pmT = self.buf("pmT", B, Ad, L)   # processed memory, transposed: one batched GEMM W_att x memory[b]^T
         gemm(P["att_encoder.weight"], memory, pmT, Ad, L, Ef, Ef, Ef, L, batch=B, sA=0, sB=L * Ef, sC=Ad * L)
 
+        self.mark("fwd.condition")
         # prenet on all frames, time-major (model/tacotron2.py:255-258)
         mel_tm = self.buf("mel_tm", T + 1, B, M)
         call("t2_mel_to_tm", mel, mel_tm, B, T, M, st)
@@ -193,12 +238,14 @@ class Engine:
         gemm(mel_tm, P["prenet.0.weight"], p1, R1, Pd, M, M, M, Pd, relu=1, mulmask=pd[0] if pd else None, ldmask=Pd)
         gemm(p1, P["prenet.3.weight"], p2, R1, Pd, Pd, Pd, Pd, Pd, relu=1, mulmask=pd[1] if pd else None, ldmask=Pd)
 
+        self.mark("fwd.prenet")
         # hoisted prenet part of the attention-RNN input projection + both biases
         R = T * B
         pre_att = self.buf("pre_att", T, B, 4 * A)
         gemm(p2, P["decoder.att_rnn.weight_ih"], pre_att, R, 4 * A, Pd, Pd, Pd + Ef, 4 * A,
              bias=P["decoder.att_rnn.bias_ih"], bias2=P["decoder.att_rnn.bias_hh"])
 
+        self.mark("fwd.dec.pre_att_gemm")
         # attention chain
         U = self.buf("U", Ad, 2, KL)
         call("t2_attn_fold_location", P["decoder.attention.location_dense.weight"],
@@ -222,11 +269,13 @@ class Engine:
                    att_drop=masks.get("att_drop"), xdec=xdec, att_c=att_c, gates=gates_att, align=align, cum=cum, th=th,
                    xproj_ctx=_ptr(xproj, B * (D + Ef) + D), ld_xproj=D + Ef, e_part=e_part)
         call("t2_attn_seq_fwd", seq, st)
+        self.mark("fwd.dec.attn_chain")
 
         # decoder-LSTM chain: hoisted input projection, then T recurrent steps
         pre_dec = self.buf("pre_dec", T, B, 4 * D)
         gemm(_ptr(xdec, B * (A + Ef)), P["decoder.lstm.weight_ih"], pre_dec, R, 4 * D, A + Ef, A + Ef, A + Ef, 4 * D,
              bias=P["decoder.lstm.bias_ih"], bias2=P["decoder.lstm.bias_hh"])
+        self.mark("fwd.dec.pre_dec_gemm")
         dec_c = self.buf("dec_c", T + 1, B, D)
         dec_c[0].zero_()
         gates_dec = self.buf("gates_dec", T, B, 4 * D) if save_for_backward else None
@@ -241,12 +290,14 @@ class Engine:
                    gates_out=B * 4 * D, dt=0)
         inc.seg_x[0] = B * ldp
         call("t2_lstm_seq_fwd", stp, inc, 1, T, st)
+        self.mark("fwd.dec.lstm_chain")
 
         # mel + stop projection over all frames: [mel_out.weight ; gate.weight] is one (M+1, D+Ef) matrix
         wproj = ps.cat_view("decoder.mel_out.weight", M + 1, D + Ef)
         bproj = ps.cat_view("decoder.mel_out.bias", M + 1, 0)
         proj = self.buf("proj", T, B, M + 1)
         gemm(_ptr(xproj, B * ldp), wproj, proj, R, M + 1, ldp, ldp, ldp, M + 1, bias=bproj)
+        self.mark("fwd.dec.proj_gemm")
         mels = torch.empty(B, T, M, dtype=torch.float32, device=self.dev)
         gates = torch.empty(B, T, 1, dtype=torch.float32, device=self.dev)
         post_in = self.buf("post.x0", B, T + 4, M)
@@ -266,6 +317,7 @@ class Engine:
                                  y=post if last else None, Lp_y=T if last else None, pad_y=0 if last else 2,
                                  res=post_in if last else None, Lp_res=T + 4, pad_res=2,
                                  length=mlen32 if last else None, fill=0.0)
+        self.mark("fwd.postnet")
         ctx.update(pmT=pmT, mel_tm=mel_tm, p1=p1, p2=p2, pd=pd, pre_att=pre_att, U=U, xdec=xdec, att_c=att_c, cum=cum,
                    xproj=xproj, gates_att=gates_att, th=th, align=align, pre_dec=pre_dec, dec_c=dec_c,
                    gates_dec=gates_dec, proj=proj, post_in=post_in, masks=masks, training=training)
@@ -330,6 +382,7 @@ class Engine:
                                   chans[li], chans[li + 1], 0 if li == 4 else 2, training)
             Lp_dy = T + 4
         call("t2_finalize_bwd", dy, dproj, B, T, M, st)
+        self.mark("bwd.postnet")
 
         # ---- mel/stop projection ----------------------------------------------------------------------
         xproj, xdec = ctx["xproj"], ctx["xdec"]
@@ -340,6 +393,7 @@ class Engine:
                     ldp, M + 1, ldp, R)
         call("t2_colsum", dproj, M + 1, R, M + 1, ps.cat_view("decoder.mel_out.bias", M + 1, 0, grad=True), st)
 
+        self.mark("bwd.dec.proj")
         # ---- decoder-LSTM chain, back-propagation through time ----------------------------------------------
         dgd = self.buf("dgd", T, B, 4 * D)
         dc_dec = self.buf("dc_dec", B, D, zero=True)
@@ -353,6 +407,7 @@ class Engine:
         inc = make("T2LstmBwdStride", dg=-B * 4 * D, ext1=-B * ldp, drop=-B * D, gates=-B * 4 * D, c_prev=-B * D,
                    c_cur=-B * D, dt=0)
         call("t2_lstm_seq_bwd", s, inc, 1, T, st)
+        self.mark("bwd.dec.lstm_chain")
         self._wgrad(dgd, 4 * D, _ptr(xdec, B * ldx), ldx, G["decoder.lstm.weight_ih"], ldx, 4 * D, ldx, R)
         self._wgrad(dgd, 4 * D, xproj, ldp, G["decoder.lstm.weight_hh"], D, 4 * D, D, R)
         call("t2_colsum", dgd, 4 * D, R, 4 * D, G["decoder.lstm.bias_ih"], st)
@@ -360,6 +415,7 @@ class Engine:
         dxdec = self.buf("dxdec", T, B, ldx)
         gemm(dgd, P["decoder.lstm.weight_ih"], dxdec, R, ldx, 4 * D, 4 * D, ldx, ldx, a_k=1, b_k=0)
 
+        self.mark("bwd.dec.lstm_gemms")
         # ---- attention chain, back-propagation through time ---------------------------------------------------
         dga = self.buf("dga", T, B, 4 * A)
         dctx_tot = self.buf("dctx_tot", T, B, Ef)
@@ -380,6 +436,7 @@ class Engine:
                   dgates=dga, dctx_tot=dctx_tot, dq=dq, dpmT=dpmT, dv_part=dv_part, dU_part=dU_part,
                   dc=dc_att, G=Gc, de=de, din_part=din_part)
         call("t2_attn_seq_bwd", sb, st)
+        self.mark("bwd.dec.attn_chain")
 
         # weight gradients of the attention chain (large GEMMs over all frames)
         gWih = G["decoder.att_rnn.weight_ih"]
@@ -405,6 +462,7 @@ class Engine:
         gemm(dpmT, ctx["memory"], G["att_encoder.weight"], Ad, Ef, L, L, Ef, Ef, a_k=1, b_k=0, accumulate=2, batch=B,
              sA=Ad * L, sB=L * Ef, sC=0)
 
+        self.mark("bwd.dec.attn_gemms")
         # ---- prenet -----------------------------------------------------------------------------------------
         dp2 = self.buf("dp2", T + 1, B, Pd)
         dp2[T].zero_()
@@ -419,6 +477,7 @@ class Engine:
         call("t2_relu_mask_bwd", dp1, ctx["p1"], pd[0] if pd else None, g1, R1 * Pd, st)
         self._wgrad(g1, Pd, ctx["mel_tm"], M, G["prenet.0.weight"], M, Pd, M, R1)
 
+        self.mark("bwd.prenet")
         # ---- conditioning ---------------------------------------------------------------------------------------
         denc = self.buf("denc", B, L, E)
         ddesc = self.buf("ddesc", B, 128) if d.get("description_embeddings") else None
@@ -472,12 +531,14 @@ class Engine:
         dx = self.buf("enc.dx3", B * Lp, E)
         gemm(dpre, ps.cat_view("encoder.lstm.weight_ih_l0", 8 * H, E), dx, Rr, E, 8 * H, 8 * H, E, E, a_k=1, b_k=0)
 
+        self.mark("bwd.bilstm")
         # ---- encoder convolutions + embedding -----------------------------------------------------------------
         for li, i in reversed(list(enumerate((0, 4, 8)))):
             dx = self.conv_bn_bwd(f"enc.conv{li}", ctx, dx, Lp, 0, P[f"encoder.convolutions.{i}.weight"],
                                   G[f"encoder.convolutions.{i}.weight"], G[f"encoder.convolutions.{i}.bias"],
                                   f"encoder.convolutions.{i + 1}", B, L, E, E, 1, training)
         call("t2_embedding_bwd", ctx["chars_idx"], dx, G["encoder.embedding.weight"], B, L, E, Lp, 0, st)
+        self.mark("bwd.encoder_convs")
 
     # =============================================================================================
     # loss + one optimisation step

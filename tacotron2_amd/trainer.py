@@ -1,0 +1,85 @@
+"""Training step driver: forward + 3-term loss + backward + (data-parallel gradient all-reduce) + global-norm clip +
+Adam(L2) + MultiStepLR, i.e. what Lightning does around TTSModel.training_step in the reference
+(run/train.py:210-243, model/tts_model.py:78-91,165-253), on the HIP engine.
+
+Data parallelism (new relative to the reference, which is single-device): one process per GPU, utterances sharded
+across ranks, ONE all-reduce of the flat fp32 gradient buffer per step over RCCL/xGMI (torch.distributed backend
+"nccl"), then identical clip + Adam on every rank.  Shards are padded to the global (L, T) maxima so that the mean of
+the per-rank loss means equals the single-device loss on the concatenated batch (the loss is a plain mean over padded
+tensors, model/tts_model.py:197-199).  BatchNorm statistics are per shard (the reference has no multi-device
+behaviour to match).
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from .engine import Engine
+from .params import ParamStore
+
+
+class Trainer:
+    def __init__(self, ps: ParamStore, lr: float, weight_decay: float, scheduler_milestones: Sequence[int] = (),
+                 max_norm: float = 1.0, seed: int = 1234):
+        self.ps = ps
+        self.engine = Engine(ps)
+        self.base_lr, self.weight_decay, self.max_norm = lr, weight_decay, max_norm
+        self.milestones = sorted(int(m) for m in scheduler_milestones)
+        self.global_step = 0
+        self.seed = seed
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.frozen: set = set()   # parameter names excluded from updates (fine-tuning, run/train.py:229-233)
+
+    def lr_at(self, step: int) -> float:
+        """MultiStepLR(gamma=0.1), stepped once per optimiser step (model/tts_model.py:83-88)."""
+        return self.base_lr * (0.1 ** sum(1 for m in self.milestones if step >= m))
+
+    def global_pad(self, batch: dict) -> dict:
+        """Pad this rank's shard to the global (L, T) maxima (no-op on one rank)."""
+        if self.world == 1:
+            return batch
+        dev = batch["chars_idx"].device
+        lt = torch.tensor([batch["chars_idx"].shape[1], batch["mel_spectrogram"].shape[1]], device=dev)
+        dist.all_reduce(lt, op=dist.ReduceOp.MAX)
+        Lg, Tg = int(lt[0]), int(lt[1])
+        out = dict(batch)
+        B, L = batch["chars_idx"].shape
+        T, M = batch["mel_spectrogram"].shape[1:]
+        if L < Lg:
+            out["chars_idx"] = torch.nn.functional.pad(batch["chars_idx"], (0, Lg - L))
+        if T < Tg:
+            out["mel_spectrogram"] = torch.nn.functional.pad(batch["mel_spectrogram"], (0, 0, 0, Tg - T))
+            out["gate"] = torch.nn.functional.pad(batch["gate"], (0, 0, 0, Tg - T))
+        return out
+
+    def train_step(self, batch: dict, masks: Optional[dict] = None):
+        """One optimisation step on this rank's shard.  Returns the device tensor loss3 = (gate, mel, post) means."""
+        eng, ps = self.engine, self.ps
+        batch = self.global_pad(batch)
+        ci, mel = batch["chars_idx"], batch["mel_spectrogram"]
+        B, L = ci.shape
+        T = mel.shape[1]
+        eng.marks = []
+        if masks is None:
+            masks = eng.make_masks(B, L, T, True, self.seed + 7919 * self.rank, self.global_step)
+        eng.mark("masks")
+        outs, ctx = eng.forward_tf(ci, batch["chars_idx_len"], mel, batch["mel_spectrogram_len"],
+                                   speaker_id=batch.get("speaker_id"),
+                                   description_embeddings=batch.get("description_embeddings"), training=True, masks=masks)
+        ps.grad.zero_()
+        loss3 = eng.loss_and_grads(outs, ctx, mel, batch["gate"])
+        if self.world > 1:
+            dist.all_reduce(ps.grad)              # ONE flat fp32 buffer over RCCL/xGMI
+            eng.mark("allreduce")
+        saved = {name: ps.P[name].clone() for name in self.frozen}   # frozen tensors take no update at all
+        self.global_step += 1
+        # MultiStepLR: the k-th optimiser step (k = global_step, 1-based) runs after k-1 scheduler steps
+        eng.adam_step(self.global_step, self.lr_at(self.global_step - 1), self.weight_decay, self.max_norm,
+                      grad_scale=1.0 / self.world)
+        for name, v in saved.items():
+            ps.P[name].copy_(v)
+        eng.mark("optimizer")
+        return loss3, outs

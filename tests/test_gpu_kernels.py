@@ -190,3 +190,23 @@ def test_philox_mask_statistics(dev):
     m2 = torch.empty(n, device=dev)
     _lib.call("t2_philox_mask", m2, n, 0.5, 1234, 8, torch.cuda.current_stream().cuda_stream)
     assert float((m != m2).float().mean()) > 0.4
+
+
+def test_adam_clip_step_matches_oracle(dev):
+    """t2_sumsq + t2_adam_step (global-norm clip 1.0, L2-in-gradient weight decay, bias correction) vs the oracle."""
+    from tacotron2_amd import _lib
+    n = 100003
+    g_ = torch.Generator().manual_seed(2)
+    p = torch.randn(n, generator=g_); grad = torch.randn(n, generator=g_) * 0.05
+    m = torch.zeros(n); v = torch.zeros(n)
+    pd_, gd, md, vd = p.to(dev), grad.to(dev), m.to(dev), v.to(dev)
+    ss = torch.zeros(1, dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for step in (1, 2, 3):
+        coef, tot = R.clip_coef([grad], 1.0)
+        p, m, v = R.adam_l2_step(p, grad * coef, m, v, step, 1e-3, 1e-6)
+        _lib.call("t2_sumsq", gd, n, ss, st)
+        _lib.call("t2_adam_step", pd_, gd, md, vd, n, ss, 1.0, 1e-3, 0.9, 0.999, 1e-8, 1e-6, step, 1.0, st)
+        torch.cuda.synchronize()
+        assert abs(float(ss.sqrt()) - tot) < 1e-6 * tot
+        assert float((pd_.cpu() - p).abs().max()) < 2e-6
