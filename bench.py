@@ -45,8 +45,8 @@ def cpu_baseline(dims, batch, t_cap, b_cap):
     torch.set_num_threads(cores)
     d = R.default_dims(**dims)
     P = R.init_params(d, seed=0)
-    for v in P.values():
-        if v.is_floating_point():
+    for k, v in P.items():
+        if v.is_floating_point() and not R.is_buffer(k):
             v.requires_grad_(True)
     ci = batch["chars_idx"][:b_cap]; cl = batch["chars_idx_len"][:b_cap]
     L = int(cl.max()); ci = ci[:, :L]
@@ -168,7 +168,7 @@ def main():
                    segments_ms={k: round(v, 3) for k, v in seg.items()})
         if world == 1 and not args.no_cpu_baseline:
             dims = {k: v for k, v in VANILLA.items()}
-            out["cpu_baseline"] = cpu_baseline(dims, cpu_batch, t_cap=60, b_cap=8)
+            out["cpu_baseline"] = cpu_baseline(dims, cpu_batch, t_cap=200, b_cap=32)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

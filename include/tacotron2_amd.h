@@ -72,6 +72,7 @@ typedef struct { const float* x; int64_t ldx; const float* w; int64_t ldw; int K
 typedef struct {
     int B, H;
     int nseg; T2Seg seg[3];
+    const float* wpacked;            /* optional lane-contiguous copy of the segment weights (t2_lstm_pack_fwd) */
     const float* pre; int64_t ldpre;
     const float* bias1; const float* bias2;
     const float* c_prev; int64_t ldc_prev;
@@ -84,6 +85,12 @@ typedef struct {
 } T2LstmStep;
 /* n = 1 or 2 independent cells in one launch (the two directions of the encoder BiLSTM). */
 int t2_lstm_step_fwd(const T2LstmStep* steps, int n, void* stream);
+/* Weight streams re-laid once per optimisation step so that every wave-instruction of the step kernels reads one
+ * contiguous 1 KB block (16 B per lane) instead of 16 rows with a power-of-two stride:
+ *   fwd: out[H/4][NT][64][4],  NT = sum_s K_s/16;   bwd: out[ceil(ncols/16)][N4/16 + N2/16][64][4] (transposed). */
+int t2_lstm_pack_fwd(const T2Seg* segs, int nseg, int H, float* out, void* stream);
+int t2_lstm_pack_bwd(const float* W, int64_t ldw, int N4, const float* W2, int64_t ldw2, int N2, int ncols, float* out,
+                     void* stream);
 
 /* S consecutive steps of a recurrence: step s uses base[i] with every non-NULL pointer advanced by
  * s * inc[i].<field> ELEMENTS (negative = time-descending, the reverse BiLSTM direction) and t += s*dt.
@@ -105,6 +112,7 @@ typedef struct {
     const float* dg_next; int64_t lddg;
     const float* W; int64_t ldw;
     const float* dg2; int64_t lddg2; const float* W2; int64_t ldw2; int N2;  /* optional second K segment (+= dg2 . W2) */
+    const float* wtpacked;           /* optional lane-contiguous transposed copy of W (and W2) (t2_lstm_pack_bwd) */
     int ncols; int epi;
     const float* ext1; int64_t ldx1; const float* ext2; int64_t ldx2;
     float* dx_out; int64_t lddx;
@@ -156,6 +164,7 @@ typedef struct {
     int B, L, T, A, Ad, Ef, Kl;
     const float* W_ih_ctx; int64_t ld_wih;
     const float* W_hh; const float* Wq; const float* U; const float* v;
+    const float* wpacked;            /* optional t2_lstm_pack_fwd of segments (W_ih_ctx, Ef), (W_hh, A) */
     const float* pre; const float* pmT; const float* memory; const int32_t* len;
     const float* att_drop;
     float* xdec; float* att_c; float* gates; float* align; float* cum; float* th;
@@ -175,6 +184,8 @@ typedef struct {
     int B, L, T, A, Ad, Ef, Kl;
     const float* W_ih_ctx; int64_t ld_wih;
     const float* W_hh; const float* Wq; const float* U; const float* v;
+    const float* wtp_ctx;            /* optional t2_lstm_pack_bwd(W_ih_ctx, ncols = Ef) */
+    const float* wtp_h;              /* optional t2_lstm_pack_bwd(W_hh, 4A, Wq, Ad, ncols = A) */
     const float* memory; const float* xdec; const float* att_c; const float* gates; const float* align;
     const float* cum; const float* th; const float* att_drop;
     const float* dh_ext; int64_t ld_dh;

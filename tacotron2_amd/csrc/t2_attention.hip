@@ -35,6 +35,10 @@ struct AttnK {
     float* ctx_out; long ldctx; float* ctx_out2; long ldctx2;
 };
 
+// All global loads of a phase are issued before anything waits on them (one workgroup of 4 waves per CU has no other
+// latency hiding): query rows + att_h, the first round of processed-memory values, then the LDS staging.
+constexpr int MAXI = 3;   // work items (4 positions each) per thread per round: one round covers L <= 192
+
 __global__ __launch_bounds__(256) void attn_energy_kernel(AttnK p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x, j = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -43,22 +47,48 @@ __global__ __launch_bounds__(256) void attn_energy_kernel(AttnK p) {
     float* Us = inp + 2 * Lp;    // [16][64]  folded location filter rows of this slice
     float* qs = Us + 16 * 64;    // [16]
     float* ec = qs + 16;         // [16][4*NG] per-dim energy contributions
+    const int items = 16 * NG;
 
-    {   // phase 1: query projection for this slice (4 dims per wave)
-        const float* h = p.att_h + (long)b * p.ldh;
-        for (int aa = 0; aa < 4; ++aa) {
-            const int a = j * 16 + w * 4 + aa;
-            const float* wq = p.Wq + (long)a * p.A;
-            float s = 0.f;
-            for (int k = lane * 4; k < p.A; k += 256) {
-                const f32x4 hv = *reinterpret_cast<const f32x4*>(h + k);
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wq + k);
-                s += hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + hv[3] * wv[3];
-            }
-            s = t2_wave_sum(s);
-            if (lane == 0) qs[w * 4 + aa] = s;
+    // ---- issue: query projection operands (4 dims per wave) ----
+    float qacc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* h = p.att_h + (long)b * p.ldh;
+    const float* wq0 = p.Wq + (long)(j * 16 + w * 4) * p.A;
+    // ---- issue: first round of processed-memory values + v ----
+    float pmv[MAXI][4], vv[MAXI];
+#pragma unroll
+    for (int it = 0; it < MAXI; ++it) {
+        const int item = tid + 256 * it;
+        vv[it] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pmv[it][i] = 0.f;
+        if (item < items) {
+            const int al = item / NG, lg = item - al * NG;
+            const int a = j * 16 + al;
+            vv[it] = p.v[a];
+            const float* pr = p.pmT + ((long)b * p.Ad + a) * L + 4 * lg;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (4 * lg + i < L) pmv[it][i] = pr[i];
         }
     }
+    for (int k0 = lane * 4; k0 < p.A; k0 += 1024) {
+        f32x4 hv[4], wv[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + 256 * i;
+            const bool ok = k < p.A;
+            hv[i] = ok ? *reinterpret_cast<const f32x4*>(h + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa)
+                wv[aa][i] = ok ? *reinterpret_cast<const f32x4*>(wq0 + (long)aa * p.A + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                qacc[aa] += hv[i][0] * wv[aa][i][0] + hv[i][1] * wv[aa][i][1] + hv[i][2] * wv[aa][i][2] + hv[i][3] * wv[aa][i][3];
+    }
+    // ---- LDS staging ----
     for (int idx = tid; idx < 2 * Lp; idx += 256) {
         const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
         float val = 0.f;
@@ -73,39 +103,62 @@ __global__ __launch_bounds__(256) void attn_energy_kernel(AttnK p) {
         const int al = idx >> 6, kk = idx & 63;
         Us[idx] = kk < 2 * KL ? p.U[(long)(j * 16 + al) * 2 * KL + kk] : 0.f;
     }
+#pragma unroll
+    for (int aa = 0; aa < 4; ++aa) {
+        const float sq = t2_wave_sum(qacc[aa]);
+        if (lane == 0) qs[w * 4 + aa] = sq;
+    }
     __syncthreads();
 
-    const int items = 16 * NG;
-    for (int item = tid; item < items; item += 256) {
-        const int al = item / NG, lg = item - al * NG;
-        const int a = j * 16 + al;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int base = 0; base < items; base += 256 * MAXI) {
+        if (base > 0) {   // later rounds (L > 192): fetch their processed-memory values now
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            float win[36];
-            const f32x4* wp = reinterpret_cast<const f32x4*>(inp + c * Lp + 4 * lg);
+            for (int it = 0; it < MAXI; ++it) {
+                const int item = base + tid + 256 * it;
+                if (item < items) {
+                    const int al = item / NG, lg = item - al * NG;
+                    const int a = j * 16 + al;
+                    vv[it] = p.v[a];
+                    const float* pr = p.pmT + ((long)b * p.Ad + a) * L + 4 * lg;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                const f32x4 t = wp[i];
-                win[4 * i] = t[0]; win[4 * i + 1] = t[1]; win[4 * i + 2] = t[2]; win[4 * i + 3] = t[3];
-            }
-            const float* u = Us + al * 64 + c * KL;
-#pragma unroll
-            for (int k = 0; k < KL; ++k) {
-                const float uk = u[k];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = fmaf(uk, win[i + k], acc[i]);
+                    for (int i = 0; i < 4; ++i) pmv[it][i] = (4 * lg + i < L) ? pr[i] : 0.f;
+                }
             }
         }
-        const float qa = qs[al], va = p.v[a];
-        const long rowoff = ((long)b * p.Ad + a) * L;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int l = 4 * lg + i;
-            if (l < L) {
-                const float th = tanhf(qa + acc[i] + p.pmT[rowoff + l]);
-                if (p.th_out) p.th_out[rowoff + l] = th;
-                ec[al * 4 * NG + l] = va * th;
+        for (int it = 0; it < MAXI; ++it) {
+            const int item = base + tid + 256 * it;
+            if (item >= items) continue;
+            const int al = item / NG, lg = item - al * NG;
+            const int a = j * 16 + al;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float win[36];
+                const f32x4* wp = reinterpret_cast<const f32x4*>(inp + c * Lp + 4 * lg);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    const f32x4 t = wp[i];
+                    win[4 * i] = t[0]; win[4 * i + 1] = t[1]; win[4 * i + 2] = t[2]; win[4 * i + 3] = t[3];
+                }
+                const float* u = Us + al * 64 + c * KL;
+#pragma unroll
+                for (int k = 0; k < KL; ++k) {
+                    const float uk = u[k];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(uk, win[i + k], acc[i]);
+                }
+            }
+            const float qa = qs[al];
+            const long rowoff = ((long)b * p.Ad + a) * L;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int l = 4 * lg + i;
+                if (l < L) {
+                    const float th = tanhf(qa + acc[i] + pmv[it][i]);
+                    if (p.th_out) p.th_out[rowoff + l] = th;
+                    ec[al * 4 * NG + l] = vv[it] * th;
+                }
             }
         }
     }
@@ -126,6 +179,16 @@ __global__ __launch_bounds__(256) void attn_context_kernel(AttnK p) {
     float* red = ws + ((L + 3) & ~3);     // [8]
     float* part = red + 8;                // [8][32]
     const int len = p.len[b];
+    // ---- issue the encoder-memory reads of the first 192 positions now; they do not depend on the softmax ----
+    constexpr int NR = 24;
+    const int el = tid & 31, lg = tid >> 5;
+    const float* mp = p.memory + (long)b * L * p.Ef + es0 + el;
+    float mv[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int l = lg + 8 * i;
+        mv[i] = l < L ? mp[(long)l * p.Ef] : 0.f;
+    }
     float mx = -INFINITY;
     for (int l = tid; l < L; l += 256) {
         float e = 0.f;
@@ -151,10 +214,14 @@ __global__ __launch_bounds__(256) void attn_context_kernel(AttnK p) {
         }
     }
     __syncthreads();
-    const int el = tid & 31, lg = tid >> 5;
     float acc = 0.f;
-    const float* mp = p.memory + (long)b * L * p.Ef + es0 + el;
-    for (int l = lg; l < L; l += 8) acc = fmaf(ws[l], mp[(long)l * p.Ef], acc);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int l = lg + 8 * i;
+        if (l < L) acc = fmaf(ws[l], mv[i], acc);
+    }
+#pragma unroll 8
+    for (int l = lg + 8 * NR; l < L; l += 8) acc = fmaf(ws[l], mp[(long)l * p.Ef], acc);
     part[lg * 32 + el] = acc;
     __syncthreads();
     if (tid < 32) {
@@ -241,6 +308,7 @@ extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
         float* slot1 = a->xdec + (long)(t + 1) * B * ldx;
         s.seg[0].x = slot + A; s.seg[0].ldx = ldx; s.seg[0].w = a->W_ih_ctx; s.seg[0].ldw = a->ld_wih; s.seg[0].K = Ef;
         s.seg[1].x = slot; s.seg[1].ldx = ldx; s.seg[1].w = a->W_hh; s.seg[1].ldw = A; s.seg[1].K = A;
+        s.wpacked = a->wpacked;
         s.pre = a->pre + (long)t * B * 4 * A; s.ldpre = 4 * A;
         s.c_prev = a->att_c + (long)t * B * A; s.ldc_prev = A;
         if (a->att_drop) { s.drop = a->att_drop + (long)t * B * A; s.lddrop = A; }
@@ -303,32 +371,45 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdK p) {
     float* dctx_s = sm;                    // [Ef]
     float* dwx_s = dctx_s + Ef;            // [L rounded]
     float* red = dwx_s + ((L + 3) & ~3);   // [8]
+    // issue this thread's share of its memory row first (8 lanes per position, 16 B each, stride 128 B)
+    constexpr int NEV = 20;                // covers Ef <= 640 in registers
+    const int l = l0 + (tid >> 3), sub = tid & 7;
+    const float* mp = p.memory + ((long)b * L + (l < L ? l : 0)) * Ef;
+    f32x4 mv[NEV];
+#pragma unroll
+    for (int i = 0; i < NEV; ++i) {
+        const int e = sub * 4 + 32 * i;
+        mv[i] = (l < L && e < Ef) ? *reinterpret_cast<const f32x4*>(mp + e) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     float part = 0.f;
     for (int e = tid; e < Ef; e += 256) {
         const float dv = p.dctx[(long)b * p.lddctx + e];
         dctx_s[e] = dv;
         part = fmaf(dv, p.ctx[(long)b * p.ldctx + e], part);
     }
-    for (int l = tid; l < L; l += 256) {
+    for (int ll = tid; ll < L; ll += 256) {
         float g0 = 0.f, g1 = 0.f;
         if (p.din_part) {
             for (int j = 0; j < NA; ++j) {
-                g0 += p.din_part[(((long)b * NA + j) * 2 + 0) * L + l];
-                g1 += p.din_part[(((long)b * NA + j) * 2 + 1) * L + l];
+                g0 += p.din_part[(((long)b * NA + j) * 2 + 0) * L + ll];
+                g1 += p.din_part[(((long)b * NA + j) * 2 + 1) * L + ll];
             }
         }
-        const float Gn = g1 + (p.G_in ? p.G_in[(long)b * L + l] : 0.f);
+        const float Gn = g1 + (p.G_in ? p.G_in[(long)b * L + ll] : 0.f);
         const float dx = g0 + Gn;
-        dwx_s[l] = dx;
-        if (blockIdx.y == 0) p.G_out[(long)b * L + l] = Gn;
-        part = fmaf(p.w[(long)b * p.ldw + l], dx, part);
+        dwx_s[ll] = dx;
+        if (blockIdx.y == 0) p.G_out[(long)b * L + ll] = Gn;
+        part = fmaf(p.w[(long)b * p.ldw + ll], dx, part);
     }
     const float sigma = t2_block_sum(part, red);
-    const int l = l0 + (tid >> 3), sub = tid & 7;
     float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < NEV; ++i) {
+        const int e = sub * 4 + 32 * i;
+        if (e < Ef) acc += mv[i][0] * dctx_s[e] + mv[i][1] * dctx_s[e + 1] + mv[i][2] * dctx_s[e + 2] + mv[i][3] * dctx_s[e + 3];
+    }
     if (l < L) {
-        const float* mp = p.memory + ((long)b * L + l) * Ef;
-        for (int e = sub * 4; e < Ef; e += 32) {
+        for (int e = sub * 4 + 32 * NEV; e < Ef; e += 32) {
             const f32x4 m = *reinterpret_cast<const f32x4*>(mp + e);
             acc += m[0] * dctx_s[e] + m[1] * dctx_s[e + 1] + m[2] * dctx_s[e + 2] + m[3] * dctx_s[e + 3];
         }
@@ -348,6 +429,25 @@ __global__ __launch_bounds__(256) void attn_bwd_ds_kernel(AttnBwdK p) {
     float* tvs = dsp + 16 * Lp;    // [16][L4] de*th, later reused for the d_in partials [4][2][L4]
     float* Us = tvs + 16 * L4;     // [16][64]
     float* des = Us + 16 * 64;     // [L4]
+    const int items = 16 * NG;
+    // issue the tanh-stash reads of the first round before the LDS staging
+    float thv[MAXI][4], vv[MAXI];
+#pragma unroll
+    for (int it = 0; it < MAXI; ++it) {
+        const int item = tid + 256 * it;
+        vv[it] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) thv[it][i] = 0.f;
+        if (item < items) {
+            const int al = item / NG, lg = item - al * NG;
+            const int a = j * 16 + al;
+            vv[it] = p.v[a];
+            const float* tr = p.th + ((long)b * p.Ad + a) * L + 4 * lg;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (4 * lg + i < L) thv[it][i] = tr[i];
+        }
+    }
     for (int idx = tid; idx < 2 * Lp; idx += 256) {
         const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
         float val = 0.f;
@@ -367,24 +467,32 @@ __global__ __launch_bounds__(256) void attn_bwd_ds_kernel(AttnBwdK p) {
     __syncthreads();
 
     // phase A: ds, dpmT accumulation
-    const int items = 16 * NG;
-    for (int item = tid; item < items; item += 256) {
-        const int al = item / NG, lg = item - al * NG;
-        const int a = j * 16 + al;
-        const float va = p.v[a];
-        const long rowoff = ((long)b * p.Ad + a) * L;
+    for (int base = 0; base < items; base += 256 * MAXI) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int l = 4 * lg + i;
-            float d = 0.f, tv = 0.f;
-            if (l < L) {
-                const float th = p.th[rowoff + l];
-                d = des[l] * va * (1.f - th * th);
-                tv = des[l] * th;
-                p.dpmT[rowoff + l] += d;
+        for (int it = 0; it < MAXI; ++it) {
+            const int item = base + tid + 256 * it;
+            if (item >= items) continue;
+            const int al = item / NG, lg = item - al * NG;
+            const int a = j * 16 + al;
+            const long rowoff = ((long)b * p.Ad + a) * L;
+            if (base > 0) {
+                vv[it] = p.v[a];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) thv[it][i] = (4 * lg + i < L) ? p.th[rowoff + 4 * lg + i] : 0.f;
             }
-            dsp[al * Lp + KPAD + l] = d;
-            tvs[al * L4 + l] = tv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int l = 4 * lg + i;
+                float d = 0.f, tv = 0.f;
+                if (l < L) {
+                    const float th = thv[it][i];
+                    d = des[l] * vv[it] * (1.f - th * th);
+                    tv = des[l] * th;
+                    p.dpmT[rowoff + l] += d;
+                }
+                dsp[al * Lp + KPAD + l] = d;
+                tvs[al * L4 + l] = tv;
+            }
         }
     }
     __syncthreads();
@@ -483,7 +591,7 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         T2LstmBwdStep s;
         memset(&s, 0, sizeof(s));
         s.B = B; s.H = A; s.N4 = 4 * A; s.dg_next = dg_next; s.lddg = 4 * A; s.W = a->W_ih_ctx; s.ldw = a->ld_wih;
-        s.ncols = Ef; s.epi = 0;
+        s.ncols = Ef; s.epi = 0; s.wtpacked = a->wtp_ctx;
         s.ext1 = a->dctx_ext1 + (long)t * B * a->ld_dc1; s.ldx1 = a->ld_dc1;
         s.ext2 = a->dctx_ext2 + (long)t * B * a->ld_dc2; s.ldx2 = a->ld_dc2;
         s.dx_out = a->dctx_tot + (long)t * B * Ef; s.lddx = Ef;
@@ -512,7 +620,7 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         memset(&c, 0, sizeof(c));
         c.B = B; c.H = A; c.N4 = 4 * A; c.dg_next = dg_next; c.lddg = 4 * A; c.W = a->W_hh; c.ldw = A;
         c.dg2 = a->dq + (long)t * B * Ad; c.lddg2 = Ad; c.W2 = a->Wq; c.ldw2 = A; c.N2 = Ad;
-        c.ncols = A; c.epi = 1;
+        c.ncols = A; c.epi = 1; c.wtpacked = a->wtp_h;
         c.ext1 = a->dh_ext + (long)t * B * a->ld_dh; c.ldx1 = a->ld_dh;
         if (a->att_drop) { c.drop = a->att_drop + (long)t * B * A; c.lddrop = A; }
         c.gates = a->gates + (long)t * B * 4 * A; c.ldgs = 4 * A;

@@ -21,6 +21,7 @@ struct Seg { const float* x; long ldx; const float* w; long ldw; int K; };
 struct LstmK {
     int B, H, nseg;
     Seg seg[3];
+    const float* wpacked;               // optional: [H/4][NT][64 lanes][4] lane-contiguous weight stream
     const float* pre; long ldpre;
     const float* bias1; const float* bias2;
     const float* c_prev; long ldc_prev;
@@ -69,7 +70,8 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmK2 pp) {
                 const float* sx = sgi == 0 ? p.seg[0].x : (sgi == 1 ? p.seg[1].x : p.seg[2].x);
                 const long ldw = sgi == 0 ? p.seg[0].ldw : (sgi == 1 ? p.seg[1].ldw : p.seg[2].ldw);
                 const long ldx = sgi == 0 ? p.seg[0].ldx : (sgi == 1 ? p.seg[1].ldx : p.seg[2].ldx);
-                bw[j] = *reinterpret_cast<const f32x4*>(sw + wrow * ldw + 16 * lc + 4 * q);
+                if (p.wpacked) bw[j] = *reinterpret_cast<const f32x4*>(p.wpacked + ((long)blockIdx.x * NT + c) * 256 + lane * 4);
+                else bw[j] = *reinterpret_cast<const f32x4*>(sw + wrow * ldw + 16 * lc + 4 * q);
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     ax[j][m] = *reinterpret_cast<const f32x4*>(sx + xrow[m] * ldx + 16 * lc + 4 * q);
@@ -152,8 +154,9 @@ int check_step(const T2LstmStep& s) {
     T2_REQUIRE(s.nseg >= 0 && s.nseg <= 3, "lstm step: 0..3 input segments");
     for (int i = 0; i < s.nseg; ++i) {
         T2_REQUIRE(s.seg[i].K % 16 == 0 && s.seg[i].K > 0, "lstm step: segment K must be a multiple of 16");
-        T2_REQUIRE(s.seg[i].ldx % 4 == 0 && s.seg[i].ldw % 4 == 0 && t2_aligned16(s.seg[i].x) && t2_aligned16(s.seg[i].w),
-                   "lstm step: segment pointers/strides must be 16-byte aligned");
+        T2_REQUIRE(s.seg[i].ldx % 4 == 0 && t2_aligned16(s.seg[i].x), "lstm step: segment x must be 16-byte aligned");
+        T2_REQUIRE(s.wpacked || (s.seg[i].ldw % 4 == 0 && t2_aligned16(s.seg[i].w)),
+                   "lstm step: segment weights must be 16-byte aligned");
     }
     T2_REQUIRE(s.h_out != nullptr, "lstm step: h_out required");
     return T2_OK;
@@ -165,6 +168,7 @@ void to_k(const T2LstmStep& s, LstmK& k, int b0, int bn) {
         k.seg[i].x = (i < s.nseg && s.seg[i].x) ? s.seg[i].x + (long)b0 * s.seg[i].ldx : nullptr;
         k.seg[i].ldx = s.seg[i].ldx; k.seg[i].w = s.seg[i].w; k.seg[i].ldw = s.seg[i].ldw; k.seg[i].K = s.seg[i].K;
     }
+    k.wpacked = s.wpacked;
     k.pre = s.pre ? s.pre + (long)b0 * s.ldpre : nullptr; k.ldpre = s.ldpre;
     k.bias1 = s.bias1; k.bias2 = s.bias2;
     k.c_prev = s.c_prev ? s.c_prev + (long)b0 * s.ldc_prev : nullptr; k.ldc_prev = s.ldc_prev;
@@ -203,6 +207,7 @@ struct BwdK {
     const float* dg_next; long lddg;    // [b][N4] or null (no recurrent contribution)
     const float* W; long ldw;           // element (n,u) at W[n*ldw + u]
     const float* dg2; long lddg2; const float* W2; long ldw2; int N2;   // optional second K segment
+    const float* wtpacked;              // optional: [ncols/16][NCH][64 lanes][4] lane-contiguous transposed weights
     int ncols;                          // number of output columns u (H for the recurrent path)
     int epi;                            // 0: plain store of dx (+ext), 1: LSTM pointwise backward
     const float* ext1; long ldx1; const float* ext2; long ldx2;
@@ -246,7 +251,11 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(BwdK2 pp) {
                     const long ldw = s2 ? p.ldw2 : p.ldw;
                     const float* bq = (s2 ? p.W2 : p.W) + (long)(16 * lc + 4 * q) * ldw + ucol;
                     if (rin) a[j] = *reinterpret_cast<const f32x4*>(ap);
-                    if (cin) { b[j][0] = bq[0]; b[j][1] = bq[ldw]; b[j][2] = bq[2 * ldw]; b[j][3] = bq[3 * ldw]; }
+                    if (p.wtpacked) {   // packed stream is laid out over BOTH segments even when dg_next is absent
+                        const int pk1 = p.N4 >> 4, pkn = pk1 + (p.N2 >> 4);
+                        b[j] = *reinterpret_cast<const f32x4*>(p.wtpacked + (((long)blockIdx.x * pkn + (s2 ? pk1 + lc : lc)) * 64 + lane) * 4);
+                    }
+                    else if (cin) { b[j][0] = bq[0]; b[j][1] = bq[ldw]; b[j][2] = bq[2 * ldw]; b[j][3] = bq[3 * ldw]; }
                 }
             }
         };
@@ -320,6 +329,7 @@ void to_bk(const T2LstmBwdStep& s, BwdK& k) {
     k.B = s.B; k.H = s.H; k.N4 = s.N4;
     k.dg_next = s.dg_next; k.lddg = s.lddg; k.W = s.W; k.ldw = s.ldw; k.ncols = s.ncols; k.epi = s.epi;
     k.dg2 = s.dg2; k.lddg2 = s.lddg2; k.W2 = s.W2; k.ldw2 = s.ldw2; k.N2 = s.N2; k.dg_out2 = s.dg_out2; k.ldgo2 = s.ldgo2;
+    k.wtpacked = s.wtpacked;
     k.ext1 = s.ext1; k.ldx1 = s.ldx1; k.ext2 = s.ext2; k.ldx2 = s.ldx2;
     k.dx_out = s.dx_out; k.lddx = s.lddx; k.drop = s.drop; k.lddrop = s.lddrop;
     k.gates = s.gates; k.ldgs = s.ldgs; k.c_prev = s.c_prev; k.ldcp = s.ldcp; k.c_cur = s.c_cur; k.ldcc = s.ldcc;
@@ -330,10 +340,10 @@ int check_bwd(const T2LstmBwdStep& s) {
     T2_REQUIRE(s.B >= 1 && s.ncols >= 1, "lstm bwd step: empty");
     if (s.dg_next) {
         T2_REQUIRE(s.N4 % 16 == 0 && s.lddg % 4 == 0 && t2_aligned16(s.dg_next), "lstm bwd step: dg_next alignment");
-        T2_REQUIRE(s.W != nullptr, "lstm bwd step: W required with dg_next");
+        T2_REQUIRE(s.W != nullptr || s.wtpacked != nullptr, "lstm bwd step: W required with dg_next");
     }
     if (s.dg2) {
-        T2_REQUIRE(s.N2 % 16 == 0 && s.lddg2 % 4 == 0 && t2_aligned16(s.dg2) && s.W2, "lstm bwd step: dg2 alignment");
+        T2_REQUIRE(s.N2 % 16 == 0 && s.lddg2 % 4 == 0 && t2_aligned16(s.dg2) && (s.W2 || s.wtpacked), "lstm bwd step: dg2 alignment");
     }
     if (s.epi == 1) {
         T2_REQUIRE(s.gates && s.c_cur && s.dc && s.dg_out && s.ncols == s.H, "lstm bwd step: epilogue operands");
@@ -353,6 +363,49 @@ int launch_bwd(const T2LstmBwdStep* steps, int n, hipStream_t st) {
     hipLaunchKernelGGL(lstm_step_bwd_kernel, grid, block, 0, st, kk);
     T2_CHECK_LAUNCH();
     return T2_OK;
+}
+
+struct PackSegs { int nseg; const float* w[3]; long ldw[3]; int K[3]; };
+
+// out[((j*NT + c)*64 + lane)*4 + e] = W_seg[(g*H + 4j + uu)*ldw + 16*lc + 4q + e],  lane = q*16 + (g*4 + uu)
+__global__ void lstm_pack_fwd_kernel(PackSegs s, int H, int NT, float* out) {
+    const long total = (long)(H / 4) * NT * 64;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const long rem = idx >> 6;
+        const int c = (int)(rem % NT), j = (int)(rem / NT);
+        const int r = lane & 15, q = lane >> 4;
+        int sgi = 0, lc = c;
+        while (sgi < s.nseg - 1 && lc >= (s.K[sgi] >> 4)) { lc -= s.K[sgi] >> 4; ++sgi; }
+        const long row = (long)(r >> 2) * H + 4 * j + (r & 3);
+        const float* src = s.w[sgi] + row * s.ldw[sgi] + 16 * lc + 4 * q;
+        f32x4 v; v[0] = src[0]; v[1] = src[1]; v[2] = src[2]; v[3] = src[3];
+        *reinterpret_cast<f32x4*>(out + idx * 4) = v;
+    }
+}
+
+// out[((ut*NCH + c)*64 + lane)*4 + s] = Wx[(16*lc + 4q + s)*ldwx + 16*ut + j],  lane = q*16 + j  (0 past ncols)
+__global__ void lstm_pack_bwd_kernel(const float* W, long ldw, int N4, const float* W2, long ldw2, int N2, int ncols,
+                                     float* out) {
+    const int nch1 = N4 >> 4, nch = nch1 + (W2 ? (N2 >> 4) : 0);
+    const int tiles = (ncols + 15) / 16;
+    const long total = (long)tiles * nch * 64;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const long rem = idx >> 6;
+        const int c = (int)(rem % nch), ut = (int)(rem / nch);
+        const int j = lane & 15, q = lane >> 4, u = 16 * ut + j;
+        const bool s2 = c >= nch1;
+        const int lc = s2 ? c - nch1 : c;
+        const float* Wx = s2 ? W2 : W;
+        const long ld = s2 ? ldw2 : ldw;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (u < ncols) {
+            const float* src = Wx + (long)(16 * lc + 4 * q) * ld + u;
+            v[0] = src[0]; v[1] = src[ld]; v[2] = src[2 * ld]; v[3] = src[3 * ld];
+        }
+        *reinterpret_cast<f32x4*>(out + idx * 4) = v;
+    }
 }
 
 template <typename T>
@@ -408,5 +461,30 @@ extern "C" int t2_lstm_seq_bwd(const T2LstmBwdStep* base, const T2LstmBwdStride*
             cur[i].t += inc[i].dt;
         }
     }
+    return T2_OK;
+}
+
+extern "C" int t2_lstm_pack_fwd(const T2Seg* segs, int nseg, int H, float* out, void* stream) {
+    T2_REQUIRE(segs && out && nseg >= 1 && nseg <= 3 && H % 4 == 0, "t2_lstm_pack_fwd: bad arguments");
+    PackSegs s; s.nseg = nseg;
+    int NT = 0;
+    for (int i = 0; i < nseg; ++i) {
+        T2_REQUIRE(segs[i].K % 16 == 0 && segs[i].w, "t2_lstm_pack_fwd: segment K must be a multiple of 16");
+        s.w[i] = segs[i].w; s.ldw[i] = segs[i].ldw; s.K[i] = segs[i].K; NT += segs[i].K >> 4;
+    }
+    const long total = (long)(H / 4) * NT * 64;
+    hipLaunchKernelGGL(lstm_pack_fwd_kernel, dim3(t2_cdiv(total, 256) > 2048 ? 2048 : t2_cdiv(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, s, H, NT, out);
+    T2_CHECK_LAUNCH();
+    return T2_OK;
+}
+
+extern "C" int t2_lstm_pack_bwd(const float* W, int64_t ldw, int N4, const float* W2, int64_t ldw2, int N2, int ncols,
+                                float* out, void* stream) {
+    T2_REQUIRE(W && out && N4 % 16 == 0 && (!W2 || N2 % 16 == 0) && ncols >= 1, "t2_lstm_pack_bwd: bad arguments");
+    const long total = (long)t2_cdiv(ncols, 16) * ((N4 >> 4) + (W2 ? (N2 >> 4) : 0)) * 64;
+    hipLaunchKernelGGL(lstm_pack_bwd_kernel, dim3(t2_cdiv(total, 256) > 2048 ? 2048 : t2_cdiv(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, W, (long)ldw, N4, W2, (long)ldw2, N2, ncols, out);
+    T2_CHECK_LAUNCH();
     return T2_OK;
 }

@@ -113,6 +113,25 @@ class Engine:
             v.zero_()
         return v
 
+    # ---- lane-contiguous weight streams for the LSTM step kernels (re-laid once per step) ------------
+    def pack_fwd(self, name, segs, H):
+        """segs: [(weight pointer, ld, K)], returns the packed buffer (t2_lstm_pack_fwd)."""
+        arr = (_lib.S["T2Seg"] * len(segs))()
+        ktot = 0
+        for i, (w, ld, K) in enumerate(segs):
+            arr[i].w = w if isinstance(w, int) else w.data_ptr()
+            arr[i].ldw = ld; arr[i].K = K
+            ktot += K
+        out = self.buf("pack." + name, 4 * H * ktot)
+        call("t2_lstm_pack_fwd", arr, len(segs), H, out, _stream())
+        return out
+
+    def pack_bwd(self, name, W, ldw, N4, ncols, W2=None, ldw2=0, N2=0):
+        tiles = (ncols + 15) // 16
+        out = self.buf("pack." + name, tiles * 16 * (N4 + N2))
+        call("t2_lstm_pack_bwd", W, ldw, N4, W2, ldw2, N2, ncols, out, _stream())
+        return out
+
     # ---- encoder ----------------------------------------------------------------------------------
     def conv_bn_fwd(self, tag, x_pad, w, bias, bn_prefix, B, L, Ci, Co, act, drop, training, ctx,
                     y=None, Lp_y=None, pad_y=2, res=None, Lp_res=0, pad_res=0, length=None, fill=0.0):
@@ -173,6 +192,7 @@ class Engine:
             slot_out = 1 if dr == 0 else S - 1
             st = steps[dr]
             st.B, st.H, st.nseg = B, H, 1
+            st.wpacked = self.pack_fwd(f"enc.whh{dr}", [(whh, H, H)], H).data_ptr()
             st.seg[0].x = _ptr(hs[dr, slot_in]); st.seg[0].ldx = H
             st.seg[0].w = whh.data_ptr(); st.seg[0].ldw = H; st.seg[0].K = H
             st.pre = _ptr(pre, t0 * 8 * H + dr * 4 * H); st.ldpre = Lp * 8 * H
@@ -262,7 +282,9 @@ class Engine:
         th = self.buf("th", T, B, Ad, L) if save_for_backward else None
         align = torch.empty(B, T, L, dtype=torch.float32, device=self.dev)
         e_part = self.buf("e_part", B, Ad // 16, L)
-        seq = make("T2AttnSeq", B=B, L=L, T=T, A=A, Ad=Ad, Ef=Ef, Kl=KL,
+        wp_att = self.pack_fwd("att", [(_ptr(P["decoder.att_rnn.weight_ih"], Pd), Pd + Ef, Ef),
+                                       (P["decoder.att_rnn.weight_hh"], A, A)], A)
+        seq = make("T2AttnSeq", B=B, L=L, T=T, A=A, Ad=Ad, Ef=Ef, Kl=KL, wpacked=wp_att,
                    W_ih_ctx=_ptr(P["decoder.att_rnn.weight_ih"], Pd), ld_wih=Pd + Ef,
                    W_hh=P["decoder.att_rnn.weight_hh"], Wq=P["decoder.attention.query_layer.weight"], U=U,
                    v=P["decoder.attention.v.weight"], pre=pre_att, pmT=pmT, memory=memory, len=len32,
@@ -281,7 +303,8 @@ class Engine:
         gates_dec = self.buf("gates_dec", T, B, 4 * D) if save_for_backward else None
         dd = masks.get("dec_drop")
         ldp = D + Ef
-        stp = make("T2LstmStep", B=B, H=D, nseg=1, pre=pre_dec, ldpre=4 * D, c_prev=dec_c, ldc_prev=D,
+        wp_dec = self.pack_fwd("dec", [(P["decoder.lstm.weight_hh"], D, D)], D)
+        stp = make("T2LstmStep", B=B, H=D, nseg=1, wpacked=wp_dec, pre=pre_dec, ldpre=4 * D, c_prev=dec_c, ldc_prev=D,
                    drop=dd, lddrop=D, h_out=_ptr(xproj, B * ldp), ldh=ldp, c_out=_ptr(dec_c, B * D), ldc_out=D,
                    gates_out=gates_dec, ldg=4 * D)
         stp.seg[0].x = xproj.data_ptr(); stp.seg[0].ldx = ldp
@@ -398,7 +421,8 @@ class Engine:
         dgd = self.buf("dgd", T, B, 4 * D)
         dc_dec = self.buf("dc_dec", B, D, zero=True)
         dd = masks.get("dec_drop")
-        s = make("T2LstmBwdStep", B=B, H=D, N4=4 * D, W=P["decoder.lstm.weight_hh"], ldw=D, ncols=D, epi=1,
+        wtp_dec = self.pack_bwd("dec.t", P["decoder.lstm.weight_hh"], D, 4 * D, D)
+        s = make("T2LstmBwdStep", B=B, H=D, N4=4 * D, W=P["decoder.lstm.weight_hh"], ldw=D, wtpacked=wtp_dec, ncols=D, epi=1,
                  ext1=_ptr(dxproj, (T - 1) * B * ldp), ldx1=ldp,
                  drop=_ptr(dd, (T - 1) * B * D) if dd is not None else None, lddrop=D,
                  gates=_ptr(ctx["gates_dec"], (T - 1) * B * 4 * D), ldgs=4 * D,
@@ -427,7 +451,10 @@ class Engine:
         Gc = self.buf("Gcum", 2, B, L)
         de = self.buf("de", B, L)
         din_part = self.buf("din_part", B, Ad // 16, 2, L)
-        sb = make("T2AttnSeqBwd", B=B, L=L, T=T, A=A, Ad=Ad, Ef=Ef, Kl=KL,
+        wtp_ctx = self.pack_bwd("att.ctx.t", _ptr(P["decoder.att_rnn.weight_ih"], Pd), Pd + Ef, 4 * A, Ef)
+        wtp_h = self.pack_bwd("att.h.t", P["decoder.att_rnn.weight_hh"], A, 4 * A, A,
+                              P["decoder.attention.query_layer.weight"], A, Ad)
+        sb = make("T2AttnSeqBwd", B=B, L=L, T=T, A=A, Ad=Ad, Ef=Ef, Kl=KL, wtp_ctx=wtp_ctx, wtp_h=wtp_h,
                   W_ih_ctx=_ptr(P["decoder.att_rnn.weight_ih"], Pd), ld_wih=Pd + Ef, W_hh=P["decoder.att_rnn.weight_hh"],
                   Wq=P["decoder.attention.query_layer.weight"], U=ctx["U"], v=P["decoder.attention.v.weight"],
                   memory=ctx["memory"], xdec=xdec, att_c=ctx["att_c"], gates=ctx["gates_att"], align=ctx["align"],
@@ -507,6 +534,7 @@ class Engine:
             sp = steps[dr]
             sp.B, sp.H, sp.N4, sp.ncols, sp.epi = B, H, 4 * H, H, 1
             sp.W = whh.data_ptr(); sp.ldw = H
+            sp.wtpacked = self.pack_bwd(f"enc.whh{dr}.t", whh, H, 4 * H, H).data_ptr()
             sp.ext1 = _ptr(denc, t0 * E + dr * H); sp.ldx1 = L * E
             sp.gates = _ptr(gs[dr, t0]); sp.ldgs = 4 * H
             sp.c_prev = _ptr(cs[dr, t0 if dr == 0 else t0 + 1]); sp.ldcp = H
