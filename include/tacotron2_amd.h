@@ -87,7 +87,8 @@ typedef struct {
 int t2_lstm_step_fwd(const T2LstmStep* steps, int n, void* stream);
 /* Weight streams re-laid once per optimisation step so that every wave-instruction of the step kernels reads one
  * contiguous 1 KB block (16 B per lane) instead of 16 rows with a power-of-two stride:
- *   fwd: out[H/4][NT][64][4],  NT = sum_s K_s/16;   bwd: out[ceil(ncols/16)][N4/16 + N2/16][64][4] (transposed). */
+ *   fwd: out[H/4][NTpad][64][4],  NT = sum_s K_s/16;   bwd: out[ceil(ncols/16)][NCHpad][64][4] (transposed),
+ *   NCH = N4/16 + N2/16; both chunk counts are zero-padded to a multiple of 16 (branch-free kernel main loops). */
 int t2_lstm_pack_fwd(const T2Seg* segs, int nseg, int H, float* out, void* stream);
 int t2_lstm_pack_bwd(const float* W, int64_t ldw, int N4, const float* W2, int64_t ldw2, int N2, int ncols, float* out,
                      void* stream);
@@ -126,7 +127,8 @@ typedef struct {
 } T2LstmBwdStep;
 int t2_lstm_step_bwd(const T2LstmBwdStep* steps, int n, void* stream);
 typedef struct { int64_t dg, dg2, ext1, ext2, drop, gates, c_prev, c_cur; int dt; } T2LstmBwdStride;
-/* S steps; base[i].dg_next == NULL at entry, afterwards each step consumes the dg_out of the previous one. */
+/* S steps; every pointer advances by its stride each step.  The caller lays the dgates stash out with one extra
+ * zero-filled slot so that base[i].dg_next (the slot 'after' the first processed step) is valid and zero. */
 int t2_lstm_seq_bwd(const T2LstmBwdStep* base, const T2LstmBwdStride* inc, int n, int S, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -176,8 +178,9 @@ int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream);
 /* Back-propagation through the attention chain, frames T-1 .. 0 (autograd of t2_attn_seq_fwd), 4 launches / frame:
  *   dctx_tot[t] = dctx_ext1[t] + dctx_ext2[t] + dgates[t+1] . W_ih_ctx ; attention backward (weights/energies,
  *   then per attention-dim slice) ; attention-LSTM cell backward with dh = dh_ext[t] + dgates[t+1].W_hh + dq[t].Wq.
- * Upstream gradients are time-major rows (t,b) with their own leading dimensions.  Outputs: dgates [T][B][4A],
- * dctx_tot [T][B][Ef], dq [T][B][Ad] (inputs of the post-loop weight-gradient GEMMs) and the per-sample
+ * Upstream gradients are time-major rows (t,b) with their own leading dimensions.  Outputs: dgates = Z [T+1][B][4A+Ad]
+ * with Z[s][b] = [dgates_s (4A) | dq_{s-1} (Ad)] (the caller zero-fills slot T's first 4A columns; `dq` is unused),
+ * dctx_tot [T][B][Ef] (inputs of the post-loop weight-gradient GEMMs) and the per-sample
  * accumulators dpmT [B][Ad][L], dv_part [B][Ad], dU_part [B][Ad][2][Kl] (caller zero-fills; summed over b after).
  * Workspaces: dc [B][A] (zero-filled), G [2][B][L], de [B][L], din_part [B][Ad/16][2][L]. */
 typedef struct {

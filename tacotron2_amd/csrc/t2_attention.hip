@@ -303,11 +303,17 @@ extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
     for (int t = 0; t < T; ++t) {
         T2LstmStep s;
         memset(&s, 0, sizeof(s));
-        s.B = B; s.H = A; s.nseg = 2;
+        s.B = B; s.H = A;
         const float* slot = a->xdec + (long)t * B * ldx;
         float* slot1 = a->xdec + (long)(t + 1) * B * ldx;
-        s.seg[0].x = slot + A; s.seg[0].ldx = ldx; s.seg[0].w = a->W_ih_ctx; s.seg[0].ldw = a->ld_wih; s.seg[0].K = Ef;
-        s.seg[1].x = slot; s.seg[1].ldx = ldx; s.seg[1].w = a->W_hh; s.seg[1].ldw = A; s.seg[1].K = A;
+        if (a->wpacked) {   // fast path: the xdec row [att_h | ctx] is ONE K = A+Ef segment against the packed stream
+            s.nseg = 1;
+            s.seg[0].x = slot; s.seg[0].ldx = ldx; s.seg[0].w = a->W_hh; s.seg[0].ldw = A; s.seg[0].K = A + Ef;
+        } else {
+            s.nseg = 2;
+            s.seg[0].x = slot; s.seg[0].ldx = ldx; s.seg[0].w = a->W_hh; s.seg[0].ldw = A; s.seg[0].K = A;
+            s.seg[1].x = slot + A; s.seg[1].ldx = ldx; s.seg[1].w = a->W_ih_ctx; s.seg[1].ldw = a->ld_wih; s.seg[1].K = Ef;
+        }
         s.wpacked = a->wpacked;
         s.pre = a->pre + (long)t * B * 4 * A; s.ldpre = 4 * A;
         s.c_prev = a->att_c + (long)t * B * A; s.ldc_prev = A;
@@ -584,13 +590,18 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
     const size_t sm_dw = (size_t)(Ef + ((L + 3) & ~3) + 8) * sizeof(float);
     const size_t sm_ds = (size_t)(2 * Lp + 16 * Lp + 16 * L4 + 16 * 64 + L4) * sizeof(float);
     T2_REQUIRE(sm_ds <= 64 * 1024, "t2_attn_seq_bwd: LDS budget exceeded");
+    T2_REQUIRE(a->wtp_ctx && a->wtp_h, "t2_attn_seq_bwd: packed weight streams (t2_lstm_pack_bwd) are required");
+    // Z[s][b] = [ dgates_s (4A) | dq_{s-1} (Ad) ], s = 0..T; slot T's dgates part is zero-filled by the caller, so the
+    // backward step of frame t always reads ONE contiguous row Z[t+1] (no special case for the last frame).
+    const long ldz = 4 * A + Ad;
+    float* Z = a->dgates;
     for (int t = T - 1; t >= 0; --t) {
         const bool last = (t == T - 1);
-        const float* dg_next = last ? nullptr : a->dgates + (long)(t + 1) * B * 4 * A;
+        const float* zrow = Z + (long)(t + 1) * B * ldz;
         // (1) total gradient w.r.t. context_t
         T2LstmBwdStep s;
         memset(&s, 0, sizeof(s));
-        s.B = B; s.H = A; s.N4 = 4 * A; s.dg_next = dg_next; s.lddg = 4 * A; s.W = a->W_ih_ctx; s.ldw = a->ld_wih;
+        s.B = B; s.H = A; s.N4 = 4 * A; s.dg_next = zrow; s.lddg = ldz; s.W = a->W_ih_ctx; s.ldw = a->ld_wih;
         s.ncols = Ef; s.epi = 0; s.wtpacked = a->wtp_ctx;
         s.ext1 = a->dctx_ext1 + (long)t * B * a->ld_dc1; s.ldx1 = a->ld_dc1;
         s.ext2 = a->dctx_ext2 + (long)t * B * a->ld_dc2; s.ldx2 = a->ld_dc2;
@@ -611,15 +622,14 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         k.th = a->th + (long)t * B * Ad * L; k.v = a->v; k.U = a->U;
         if (t > 0) { k.w_prev = a->align + (long)(t - 1) * L; k.ldwp = (long)T * L; }
         k.cum_prev = a->cum + (long)t * B * L; k.ldcp = L;
-        k.dpmT = a->dpmT; k.dq = a->dq + (long)t * B * Ad; k.lddq = Ad;
+        k.dpmT = a->dpmT; k.dq = Z + (long)(t + 1) * B * ldz + 4 * A; k.lddq = ldz;
         k.dv_part = a->dv_part; k.dU_part = a->dU_part; k.din_part_out = a->din_part;
         hipLaunchKernelGGL(attn_bwd_dw_kernel, dim3(B, t2_cdiv(L, 32)), dim3(256), sm_dw, st, k);
         hipLaunchKernelGGL(attn_bwd_ds_kernel, dim3(B, NA), dim3(256), sm_ds, st, k);
-        // (4) attention-LSTM cell backward: dh = dh_ext + dgates_{t+1}.W_hh + dq_t.Wq
+        // (4) attention-LSTM cell backward: dh = dh_ext + [dgates_{t+1} | dq_t] . [W_hh ; Wq]
         T2LstmBwdStep c;
         memset(&c, 0, sizeof(c));
-        c.B = B; c.H = A; c.N4 = 4 * A; c.dg_next = dg_next; c.lddg = 4 * A; c.W = a->W_hh; c.ldw = A;
-        c.dg2 = a->dq + (long)t * B * Ad; c.lddg2 = Ad; c.W2 = a->Wq; c.ldw2 = A; c.N2 = Ad;
+        c.B = B; c.H = A; c.N4 = 4 * A; c.N2 = Ad; c.dg_next = zrow; c.lddg = ldz; c.W = a->W_hh; c.ldw = A;
         c.ncols = A; c.epi = 1; c.wtpacked = a->wtp_h;
         c.ext1 = a->dh_ext + (long)t * B * a->ld_dh; c.ldx1 = a->ld_dh;
         if (a->att_drop) { c.drop = a->att_drop + (long)t * B * A; c.lddrop = A; }
@@ -627,7 +637,7 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         c.c_prev = a->att_c + (long)t * B * A; c.ldcp = A;
         c.c_cur = a->att_c + (long)(t + 1) * B * A; c.ldcc = A;
         c.dc = a->dc; c.lddc = A;
-        c.dg_out = a->dgates + (long)t * B * 4 * A; c.ldgo = 4 * A;
+        c.dg_out = Z + (long)t * B * ldz; c.ldgo = ldz;
         T2_TRY(t2_lstm_step_bwd_launch(&c, 1, st));
     }
     T2_CHECK_LAUNCH();

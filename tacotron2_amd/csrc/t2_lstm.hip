@@ -38,7 +38,10 @@ template <int MT>
 __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmK2 pp) {
     const LstmK& p = pp.s[blockIdx.y];
     __shared__ float red[4 * MT * 256];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave id as a SCALAR: keeps the chunk -> segment lookup and the tail guards on the scalar unit, so the
+    // vector loads below are unconditional and stay in flight across groups
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
     const int u0 = blockIdx.x * 4;
     const int H = p.H;
@@ -53,30 +56,31 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmK2 pp) {
     const int cb1 = p.nseg > 0 ? (p.seg[0].K >> 4) : 0;
     const int cb2 = cb1 + (p.nseg > 1 ? (p.seg[1].K >> 4) : 0);
     const int NT = cb2 + (p.nseg > 2 ? (p.seg[2].K >> 4) : 0);
-    bool xin[MT];
+    // rows >= B are clamped to row 0: their products land in accumulator rows that the epilogue never reads
     long xrow[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) { xin[m] = (m * 16 + r) < p.B; xrow[m] = xin[m] ? (m * 16 + r) : 0; }
+    for (int m = 0; m < MT; ++m) xrow[m] = (m * 16 + r) < p.B ? (m * 16 + r) : 0;
 
     constexpr int U = 4;
     auto load_group = [&](int c0, f32x4 (&bw)[U], f32x4 (&ax)[U][MT]) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const int c = c0 + 4 * j;
+            const int c = c0 + 4 * j;           // scalar
             if (c < NT) {
                 const int sgi = (c >= cb1 ? 1 : 0) + (c >= cb2 ? 1 : 0);
                 const int lc = c - (sgi == 0 ? 0 : (sgi == 1 ? cb1 : cb2));
-                const float* sw = sgi == 0 ? p.seg[0].w : (sgi == 1 ? p.seg[1].w : p.seg[2].w);
                 const float* sx = sgi == 0 ? p.seg[0].x : (sgi == 1 ? p.seg[1].x : p.seg[2].x);
-                const long ldw = sgi == 0 ? p.seg[0].ldw : (sgi == 1 ? p.seg[1].ldw : p.seg[2].ldw);
                 const long ldx = sgi == 0 ? p.seg[0].ldx : (sgi == 1 ? p.seg[1].ldx : p.seg[2].ldx);
-                if (p.wpacked) bw[j] = *reinterpret_cast<const f32x4*>(p.wpacked + ((long)blockIdx.x * NT + c) * 256 + lane * 4);
-                else bw[j] = *reinterpret_cast<const f32x4*>(sw + wrow * ldw + 16 * lc + 4 * q);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    ax[j][m] = *reinterpret_cast<const f32x4*>(sx + xrow[m] * ldx + 16 * lc + 4 * q);
-                    if (!xin[m]) ax[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (p.wpacked) {
+                    bw[j] = *reinterpret_cast<const f32x4*>(p.wpacked + ((long)blockIdx.x * ((NT + 15) & ~15) + c) * 256 + lane * 4);
+                } else {
+                    const float* sw = sgi == 0 ? p.seg[0].w : (sgi == 1 ? p.seg[1].w : p.seg[2].w);
+                    const long ldw = sgi == 0 ? p.seg[0].ldw : (sgi == 1 ? p.seg[1].ldw : p.seg[2].ldw);
+                    bw[j] = *reinterpret_cast<const f32x4*>(sw + wrow * ldw + 16 * lc + 4 * q);
                 }
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    ax[j][m] = *reinterpret_cast<const f32x4*>(sx + xrow[m] * ldx + 16 * lc + 4 * q);
             } else {
                 bw[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -115,6 +119,119 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmK2 pp) {
         for (int g = 0; g < 4; ++g) red[((w * MT + m) * 16 + (q * 4 + g)) * 16 + r] = acc[m][g];
     __syncthreads();
 
+    if (tid < MT * 64) {
+        const int b = tid >> 2, uu = tid & 3;
+        if (b < p.B) {
+            const int u = u0 + uu;
+            float gsum[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float s = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) s += red[((ww * MT + (b >> 4)) * 16 + (b & 15)) * 16 + g * 4 + uu];
+                const int n = g * H + u;
+                if (p.pre) s += p.pre[(long)b * p.ldpre + n];
+                if (p.bias1) s += p.bias1[n];
+                if (p.bias2) s += p.bias2[n];
+                gsum[g] = s;
+            }
+            const bool active = (p.len == nullptr) || (p.t < p.len[b]);
+            float gi = t2_sigmoid(gsum[0]), gf = t2_sigmoid(gsum[1]), gg = tanhf(gsum[2]), go = t2_sigmoid(gsum[3]);
+            const float cp = p.c_prev ? p.c_prev[(long)b * p.ldc_prev + u] : 0.f;
+            float cn = gf * cp + gi * gg;
+            float hn = go * tanhf(cn);
+            if (p.drop) hn *= p.drop[(long)b * p.lddrop + u];
+            if (!active) { hn = 0.f; cn = 0.f; gi = gf = gg = go = 0.f; }
+            p.h_out[(long)b * p.ldh + u] = hn;
+            if (p.h_out2) p.h_out2[(long)b * p.ldh2 + u] = hn;
+            if (p.c_out) p.c_out[(long)b * p.ldc_out + u] = cn;
+            if (p.gates_out) {
+                float* go_ = p.gates_out + (long)b * p.ldg + u;
+                go_[0] = gi; go_[H] = gf; go_[2 * H] = gg; go_[3 * H] = go;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fast path: packed, zero-padded weight stream + ONE contiguous activation segment.  Branch-free main loop:
+// every wave runs NTpad/16 groups of 4 chunks; chunk c of group g is 16g + 4j + w.  Chunks past the real K multiply the
+// all-zero padding chunks of the weight stream with (clamped, finite) activations, so no guard, select or wait sits
+// between a load and the next load: two groups (2 x 12 x 1 KB per wave) are in flight while one is in the MFMAs.
+// ---------------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256, 1) void lstm_step_fwd_fast_kernel(LstmK2 pp) {
+    const LstmK& p = pp.s[blockIdx.y];
+    __shared__ float red[4 * MT * 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int u0 = blockIdx.x * 4;
+    const int H = p.H;
+    const int NT = p.seg[0].K >> 4, NTpad = (NT + 15) & ~15, G = NTpad >> 4;
+    const float* wb = p.wpacked + (long)blockIdx.x * NTpad * 256 + lane * 4;
+    const float* xb[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int row = m * 16 + r;
+        xb[m] = p.seg[0].x + (long)(row < p.B ? row : 0) * p.seg[0].ldx + 4 * q;
+    }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 4;
+    auto load_group = [&](int g, f32x4 (&bw)[U], f32x4 (&ax)[U][MT]) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int c = 16 * g + 4 * j + w;
+            const int cx = c < NT ? c : NT - 1;     // padding chunks: any finite activations x the zero weight chunk
+            bw[j] = *reinterpret_cast<const f32x4*>(wb + (long)c * 256);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                ax[j][m] = *reinterpret_cast<const f32x4*>(xb[m] + 16 * cx);
+            }
+        }
+    };
+    auto mma_group = [&](const f32x4 (&bw)[U], const f32x4 (&ax)[U][MT]) {
+#pragma unroll
+        for (int j = 0; j < U; ++j)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[j][m][s], bw[j][s], acc[m], 0, 0, 0);
+    };
+    {
+        f32x4 bwA[U], bwB[U], axA[U][MT], axB[U][MT];
+        // steady state issues its loads unconditionally (counted vmcnt waits need straight-line load issue)
+        load_group(0, bwA, axA);
+        int g = 0;
+        // sched_barrier(0): keep each group's 12 loads issued together AHEAD of the previous group's MFMAs (the
+        // scheduler otherwise sinks loads next to their uses and leaves only 2-3 in flight)
+        for (; g + 2 < G; g += 2) {
+            load_group(g + 1, bwB, axB);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_group(bwA, axA);
+            __builtin_amdgcn_sched_barrier(0);
+            load_group(g + 2, bwA, axA);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_group(bwB, axB);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (g + 1 < G) {
+            load_group(g + 1, bwB, axB);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_group(bwA, axA);
+            mma_group(bwB, axB);
+        } else {
+            mma_group(bwA, axA);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) red[((w * MT + m) * 16 + (q * 4 + g)) * 16 + r] = acc[m][g];
+    __syncthreads();
     if (tid < MT * 64) {
         const int b = tid >> 2, uu = tid & 3;
         if (b < p.B) {
@@ -191,9 +308,17 @@ int launch_fwd(const T2LstmStep* steps, int n, hipStream_t st) {
         for (int i = 0; i < n; ++i) to_k(steps[i], kk.s[i], b0, bn);
         if (n == 1) kk.s[1] = kk.s[0];
         dim3 grid(steps[0].H / 4, n), block(256);
-        if (bn <= 16) hipLaunchKernelGGL((lstm_step_fwd_kernel<1>), grid, block, 0, st, kk);
-        else if (bn <= 32) hipLaunchKernelGGL((lstm_step_fwd_kernel<2>), grid, block, 0, st, kk);
-        else hipLaunchKernelGGL((lstm_step_fwd_kernel<4>), grid, block, 0, st, kk);
+        bool fast = true;
+        for (int i = 0; i < n; ++i) fast = fast && steps[i].wpacked && steps[i].nseg == 1;
+        if (fast) {
+            if (bn <= 16) hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<1>), grid, block, 0, st, kk);
+            else if (bn <= 32) hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<2>), grid, block, 0, st, kk);
+            else hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<4>), grid, block, 0, st, kk);
+        } else {
+            if (bn <= 16) hipLaunchKernelGGL((lstm_step_fwd_kernel<1>), grid, block, 0, st, kk);
+            else if (bn <= 32) hipLaunchKernelGGL((lstm_step_fwd_kernel<2>), grid, block, 0, st, kk);
+            else hipLaunchKernelGGL((lstm_step_fwd_kernel<4>), grid, block, 0, st, kk);
+        }
     }
     T2_CHECK_LAUNCH();
     return T2_OK;
@@ -222,71 +347,7 @@ struct BwdK {
 };
 struct BwdK2 { BwdK s[2]; };
 
-__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(BwdK2 pp) {
-    const BwdK& p = pp.s[blockIdx.z];
-    __shared__ float red[4 * 256];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int r = lane & 15, q = lane >> 4;
-    const int u0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    {
-        const int row = b0 + r;
-        const bool rin = row < p.B;
-        const bool cin = (u0 + r) < p.ncols;
-        const long arow = rin ? row : 0;
-        const int ucol = u0 + (cin ? r : 0);
-        const int nch1 = p.dg_next ? (p.N4 >> 4) : 0;
-        const int nch = nch1 + (p.dg2 ? (p.N2 >> 4) : 0);
-        constexpr int U = 4;
-        auto load_group = [&](int c0, f32x4 (&a)[U], f32x4 (&b)[U]) {
-#pragma unroll
-            for (int j = 0; j < U; ++j) {
-                const int c = c0 + 4 * j;
-                a[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                b[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (c < nch) {
-                    const bool s2 = c >= nch1;
-                    const int lc = s2 ? c - nch1 : c;
-                    const float* ap = (s2 ? p.dg2 + arow * p.lddg2 : p.dg_next + arow * p.lddg) + 16 * lc + 4 * q;
-                    const long ldw = s2 ? p.ldw2 : p.ldw;
-                    const float* bq = (s2 ? p.W2 : p.W) + (long)(16 * lc + 4 * q) * ldw + ucol;
-                    if (rin) a[j] = *reinterpret_cast<const f32x4*>(ap);
-                    if (p.wtpacked) {   // packed stream is laid out over BOTH segments even when dg_next is absent
-                        const int pk1 = p.N4 >> 4, pkn = pk1 + (p.N2 >> 4);
-                        b[j] = *reinterpret_cast<const f32x4*>(p.wtpacked + (((long)blockIdx.x * pkn + (s2 ? pk1 + lc : lc)) * 64 + lane) * 4);
-                    }
-                    else if (cin) { b[j][0] = bq[0]; b[j][1] = bq[ldw]; b[j][2] = bq[2 * ldw]; b[j][3] = bq[3 * ldw]; }
-                }
-            }
-        };
-        auto mma_group = [&](const f32x4 (&a)[U], const f32x4 (&b)[U]) {
-#pragma unroll
-            for (int j = 0; j < U; ++j) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][0], b[j][0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][1], b[j][1], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][2], b[j][2], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][3], b[j][3], acc1, 0, 0, 0);
-            }
-        };
-        if (nch > 0) {
-            f32x4 aA[U], bA[U], aB[U], bB[U];
-            int c = w;
-            load_group(c, aA, bA); c += 4 * U;
-            while (true) {
-                load_group(c, aB, bB);
-                mma_group(aA, bA);
-                if (c >= nch) break;
-                c += 4 * U;
-                load_group(c, aA, bA);
-                mma_group(aB, bB);
-                if (c >= nch) break;
-                c += 4 * U;
-            }
-        }
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) red[(w * 16 + (q * 4 + g)) * 16 + r] = acc0[g] + acc1[g];
-    __syncthreads();
+__device__ __forceinline__ void bwd_epilogue(const BwdK& p, const float* red, int tid, int u0, int b0) {
     {
         const int bl = tid >> 4, ul = tid & 15;
         const int b = b0 + bl, u = u0 + ul;
@@ -325,6 +386,139 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(BwdK2 pp) {
     }
 }
 
+__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(BwdK2 pp) {
+    const BwdK& p = pp.s[blockIdx.z];
+    __shared__ float red[4 * 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar wave id (see the forward kernel)
+    const int r = lane & 15, q = lane >> 4;
+    const int u0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int row = b0 + r;
+        const bool cin = (u0 + r) < p.ncols;
+        const long arow = row < p.B ? row : 0;
+        const int ucol = u0 + (cin ? r : 0);
+        const int nch1 = p.dg_next ? (p.N4 >> 4) : 0;
+        const int nch = nch1 + (p.dg2 ? (p.N2 >> 4) : 0);
+        constexpr int U = 4;
+        auto load_group = [&](int c0, f32x4 (&a)[U], f32x4 (&b)[U]) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int c = c0 + 4 * j;       // scalar
+                if (c < nch) {
+                    const bool s2 = c >= nch1;
+                    const int lc = s2 ? c - nch1 : c;
+                    // rows >= B are clamped (arow): their results are never stored
+                    const float* ap = (s2 ? p.dg2 + arow * p.lddg2 : p.dg_next + arow * p.lddg) + 16 * lc + 4 * q;
+                    a[j] = *reinterpret_cast<const f32x4*>(ap);
+                    if (p.wtpacked) {   // packed stream is laid out over BOTH segments even when dg_next is absent
+                        const int pk1 = p.N4 >> 4, pkn = (pk1 + (p.N2 >> 4) + 15) & ~15;
+                        b[j] = *reinterpret_cast<const f32x4*>(p.wtpacked + (((long)blockIdx.x * pkn + (s2 ? pk1 + lc : lc)) * 64 + lane) * 4);
+                    } else {
+                        const long ldw = s2 ? p.ldw2 : p.ldw;
+                        const float* bq = (s2 ? p.W2 : p.W) + (long)(16 * lc + 4 * q) * ldw + ucol;
+                        b[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (cin) { b[j][0] = bq[0]; b[j][1] = bq[ldw]; b[j][2] = bq[2 * ldw]; b[j][3] = bq[3 * ldw]; }
+                    }
+                } else {
+                    a[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    b[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        };
+        auto mma_group = [&](const f32x4 (&a)[U], const f32x4 (&b)[U]) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][0], b[j][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][1], b[j][1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][2], b[j][2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][3], b[j][3], acc1, 0, 0, 0);
+            }
+        };
+        if (nch > 0) {
+            f32x4 aA[U], bA[U], aB[U], bB[U];
+            int c = w;
+            load_group(c, aA, bA); c += 4 * U;
+            while (true) {
+                load_group(c, aB, bB);
+                mma_group(aA, bA);
+                if (c >= nch) break;
+                c += 4 * U;
+                load_group(c, aA, bA);
+                mma_group(aB, bB);
+                if (c >= nch) break;
+                c += 4 * U;
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) red[(w * 16 + (q * 4 + g)) * 16 + r] = acc0[g] + acc1[g];
+    __syncthreads();
+    bwd_epilogue(p, red, tid, u0, b0);
+}
+
+// Fast path of the backward step: ONE contiguous gradient row block dg[b][0:K) (K = N4 + N2) against the packed,
+// zero-padded transposed weight stream; same branch-free double-buffered structure as the forward fast path.
+__global__ __launch_bounds__(256, 1) void lstm_step_bwd_fast_kernel(BwdK2 pp) {
+    const BwdK& p = pp.s[blockIdx.z];
+    __shared__ float red[4 * 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int u0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const int NCH = (p.N4 + p.N2) >> 4, NCHpad = (NCH + 15) & ~15, G = NCHpad >> 4;
+    const float* wb = p.wtpacked + (long)blockIdx.x * NCHpad * 256 + lane * 4;
+    const float* ab = p.dg_next + (long)((b0 + r) < p.B ? (b0 + r) : 0) * p.lddg + 4 * q;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 4;
+    auto load_group = [&](int g, f32x4 (&a)[U], f32x4 (&b)[U]) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int c = 16 * g + 4 * j + w;
+            const int cx = c < NCH ? c : NCH - 1;   // padding chunks: finite gradients x the zero weight chunk
+            b[j] = *reinterpret_cast<const f32x4*>(wb + (long)c * 256);
+            a[j] = *reinterpret_cast<const f32x4*>(ab + 16 * cx);
+        }
+    };
+    auto mma_group = [&](const f32x4 (&a)[U], const f32x4 (&b)[U]) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][0], b[j][0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][1], b[j][1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][2], b[j][2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][3], b[j][3], acc1, 0, 0, 0);
+        }
+    };
+    {
+        f32x4 aA[U], bA[U], aB[U], bB[U];
+        load_group(0, aA, bA);
+        int g = 0;
+        for (; g + 2 < G; g += 2) {
+            load_group(g + 1, aB, bB);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_group(aA, bA);
+            __builtin_amdgcn_sched_barrier(0);
+            load_group(g + 2, aA, bA);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_group(aB, bB);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (g + 1 < G) {
+            load_group(g + 1, aB, bB);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_group(aA, bA);
+            mma_group(aB, bB);
+        } else {
+            mma_group(aA, bA);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) red[(w * 16 + (q * 4 + g)) * 16 + r] = acc0[g] + acc1[g];
+    __syncthreads();
+    bwd_epilogue(p, red, tid, u0, b0);
+}
+
 void to_bk(const T2LstmBwdStep& s, BwdK& k) {
     k.B = s.B; k.H = s.H; k.N4 = s.N4;
     k.dg_next = s.dg_next; k.lddg = s.lddg; k.W = s.W; k.ldw = s.ldw; k.ncols = s.ncols; k.epi = s.epi;
@@ -360,7 +554,10 @@ int launch_bwd(const T2LstmBwdStep* steps, int n, hipStream_t st) {
     if (n == 2) T2_REQUIRE(steps[0].B == steps[1].B && steps[0].ncols == steps[1].ncols, "lstm bwd step: shapes differ");
     if (n == 1) kk.s[1] = kk.s[0];
     dim3 grid(t2_cdiv(steps[0].ncols, 16), t2_cdiv(steps[0].B, 16), n), block(256);
-    hipLaunchKernelGGL(lstm_step_bwd_kernel, grid, block, 0, st, kk);
+    bool fast = true;
+    for (int i = 0; i < n; ++i) fast = fast && steps[i].wtpacked && steps[i].dg_next && !steps[i].dg2;
+    if (fast) hipLaunchKernelGGL(lstm_step_bwd_fast_kernel, grid, block, 0, st, kk);
+    else hipLaunchKernelGGL(lstm_step_bwd_kernel, grid, block, 0, st, kk);
     T2_CHECK_LAUNCH();
     return T2_OK;
 }
@@ -369,12 +566,14 @@ struct PackSegs { int nseg; const float* w[3]; long ldw[3]; int K[3]; };
 
 // out[((j*NT + c)*64 + lane)*4 + e] = W_seg[(g*H + 4j + uu)*ldw + 16*lc + 4q + e],  lane = q*16 + (g*4 + uu)
 __global__ void lstm_pack_fwd_kernel(PackSegs s, int H, int NT, float* out) {
-    const long total = (long)(H / 4) * NT * 64;
+    const int NTpad = (NT + 15) & ~15;
+    const long total = (long)(H / 4) * NTpad * 64;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int lane = (int)(idx & 63);
         const long rem = idx >> 6;
-        const int c = (int)(rem % NT), j = (int)(rem / NT);
+        const int c = (int)(rem % NTpad), j = (int)(rem / NTpad);
         const int r = lane & 15, q = lane >> 4;
+        if (c >= NT) { *reinterpret_cast<f32x4*>(out + idx * 4) = (f32x4){0.f, 0.f, 0.f, 0.f}; continue; }
         int sgi = 0, lc = c;
         while (sgi < s.nseg - 1 && lc >= (s.K[sgi] >> 4)) { lc -= s.K[sgi] >> 4; ++sgi; }
         const long row = (long)(r >> 2) * H + 4 * j + (r & 3);
@@ -387,13 +586,14 @@ __global__ void lstm_pack_fwd_kernel(PackSegs s, int H, int NT, float* out) {
 // out[((ut*NCH + c)*64 + lane)*4 + s] = Wx[(16*lc + 4q + s)*ldwx + 16*ut + j],  lane = q*16 + j  (0 past ncols)
 __global__ void lstm_pack_bwd_kernel(const float* W, long ldw, int N4, const float* W2, long ldw2, int N2, int ncols,
                                      float* out) {
-    const int nch1 = N4 >> 4, nch = nch1 + (W2 ? (N2 >> 4) : 0);
+    const int nch1 = N4 >> 4, nch = nch1 + (W2 ? (N2 >> 4) : 0), nchpad = (nch + 15) & ~15;
     const int tiles = (ncols + 15) / 16;
-    const long total = (long)tiles * nch * 64;
+    const long total = (long)tiles * nchpad * 64;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int lane = (int)(idx & 63);
         const long rem = idx >> 6;
-        const int c = (int)(rem % nch), ut = (int)(rem / nch);
+        const int c = (int)(rem % nchpad), ut = (int)(rem / nchpad);
+        if (c >= nch) { *reinterpret_cast<f32x4*>(out + idx * 4) = (f32x4){0.f, 0.f, 0.f, 0.f}; continue; }
         const int j = lane & 15, q = lane >> 4, u = 16 * ut + j;
         const bool s2 = c >= nch1;
         const int lc = s2 ? c - nch1 : c;
@@ -451,9 +651,7 @@ extern "C" int t2_lstm_seq_bwd(const T2LstmBwdStep* base, const T2LstmBwdStride*
     for (int s = 0; s < S; ++s) {
         T2_TRY(launch_bwd(cur, n, (hipStream_t)stream));
         for (int i = 0; i < n; ++i) {
-            // after the first step the recurrent operand is the dgates just produced
-            if (s == 0 && cur[i].dg_next == nullptr) { cur[i].dg_next = cur[i].dg_out; cur[i].lddg = cur[i].ldgo; }
-            else adv(cur[i].dg_next, inc[i].dg);
+            adv(cur[i].dg_next, inc[i].dg);
             adv(cur[i].ext1, inc[i].ext1); adv(cur[i].ext2, inc[i].ext2); adv(cur[i].drop, inc[i].drop);
             adv(cur[i].gates, inc[i].gates); adv(cur[i].c_prev, inc[i].c_prev); adv(cur[i].c_cur, inc[i].c_cur);
             adv(cur[i].dg_out, inc[i].dg);
@@ -472,7 +670,7 @@ extern "C" int t2_lstm_pack_fwd(const T2Seg* segs, int nseg, int H, float* out, 
         T2_REQUIRE(segs[i].K % 16 == 0 && segs[i].w, "t2_lstm_pack_fwd: segment K must be a multiple of 16");
         s.w[i] = segs[i].w; s.ldw[i] = segs[i].ldw; s.K[i] = segs[i].K; NT += segs[i].K >> 4;
     }
-    const long total = (long)(H / 4) * NT * 64;
+    const long total = (long)(H / 4) * ((NT + 15) & ~15) * 64;
     hipLaunchKernelGGL(lstm_pack_fwd_kernel, dim3(t2_cdiv(total, 256) > 2048 ? 2048 : t2_cdiv(total, 256)), dim3(256), 0,
                        (hipStream_t)stream, s, H, NT, out);
     T2_CHECK_LAUNCH();
@@ -482,7 +680,7 @@ extern "C" int t2_lstm_pack_fwd(const T2Seg* segs, int nseg, int H, float* out, 
 extern "C" int t2_lstm_pack_bwd(const float* W, int64_t ldw, int N4, const float* W2, int64_t ldw2, int N2, int ncols,
                                 float* out, void* stream) {
     T2_REQUIRE(W && out && N4 % 16 == 0 && (!W2 || N2 % 16 == 0) && ncols >= 1, "t2_lstm_pack_bwd: bad arguments");
-    const long total = (long)t2_cdiv(ncols, 16) * ((N4 >> 4) + (W2 ? (N2 >> 4) : 0)) * 64;
+    const long total = (long)t2_cdiv(ncols, 16) * ((((N4 >> 4) + (W2 ? (N2 >> 4) : 0)) + 15) & ~15) * 64;
     hipLaunchKernelGGL(lstm_pack_bwd_kernel, dim3(t2_cdiv(total, 256) > 2048 ? 2048 : t2_cdiv(total, 256)), dim3(256), 0,
                        (hipStream_t)stream, W, (long)ldw, N4, W2, (long)ldw2, N2, ncols, out);
     T2_CHECK_LAUNCH();

@@ -122,13 +122,15 @@ class Engine:
             arr[i].w = w if isinstance(w, int) else w.data_ptr()
             arr[i].ldw = ld; arr[i].K = K
             ktot += K
-        out = self.buf("pack." + name, 4 * H * ktot)
+        ntpad = (ktot // 16 + 15) // 16 * 16
+        out = self.buf("pack." + name, H // 4 * ntpad * 256)
         call("t2_lstm_pack_fwd", arr, len(segs), H, out, _stream())
         return out
 
     def pack_bwd(self, name, W, ldw, N4, ncols, W2=None, ldw2=0, N2=0):
         tiles = (ncols + 15) // 16
-        out = self.buf("pack." + name, tiles * 16 * (N4 + N2))
+        nchpad = ((N4 + N2) // 16 + 15) // 16 * 16
+        out = self.buf("pack." + name, tiles * nchpad * 256)
         call("t2_lstm_pack_bwd", W, ldw, N4, W2, ldw2, N2, ncols, out, _stream())
         return out
 
@@ -282,8 +284,9 @@ class Engine:
         th = self.buf("th", T, B, Ad, L) if save_for_backward else None
         align = torch.empty(B, T, L, dtype=torch.float32, device=self.dev)
         e_part = self.buf("e_part", B, Ad // 16, L)
-        wp_att = self.pack_fwd("att", [(_ptr(P["decoder.att_rnn.weight_ih"], Pd), Pd + Ef, Ef),
-                                       (P["decoder.att_rnn.weight_hh"], A, A)], A)
+        # packed in the column order of the xdec row [att_h | ctx], so each step reads ONE contiguous activation segment
+        wp_att = self.pack_fwd("att", [(P["decoder.att_rnn.weight_hh"], A, A),
+                                       (_ptr(P["decoder.att_rnn.weight_ih"], Pd), Pd + Ef, Ef)], A)
         seq = make("T2AttnSeq", B=B, L=L, T=T, A=A, Ad=Ad, Ef=Ef, Kl=KL, wpacked=wp_att,
                    W_ih_ctx=_ptr(P["decoder.att_rnn.weight_ih"], Pd), ld_wih=Pd + Ef,
                    W_hh=P["decoder.att_rnn.weight_hh"], Wq=P["decoder.attention.query_layer.weight"], U=U,
@@ -418,11 +421,13 @@ class Engine:
 
         self.mark("bwd.dec.proj")
         # ---- decoder-LSTM chain, back-propagation through time ----------------------------------------------
-        dgd = self.buf("dgd", T, B, 4 * D)
+        dgd = self.buf("dgd", T + 1, B, 4 * D)
+        dgd[T].zero_()
         dc_dec = self.buf("dc_dec", B, D, zero=True)
         dd = masks.get("dec_drop")
         wtp_dec = self.pack_bwd("dec.t", P["decoder.lstm.weight_hh"], D, 4 * D, D)
-        s = make("T2LstmBwdStep", B=B, H=D, N4=4 * D, W=P["decoder.lstm.weight_hh"], ldw=D, wtpacked=wtp_dec, ncols=D, epi=1,
+        s = make("T2LstmBwdStep", B=B, H=D, N4=4 * D, dg_next=_ptr(dgd, T * B * 4 * D), lddg=4 * D,
+                 W=P["decoder.lstm.weight_hh"], ldw=D, wtpacked=wtp_dec, ncols=D, epi=1,
                  ext1=_ptr(dxproj, (T - 1) * B * ldp), ldx1=ldp,
                  drop=_ptr(dd, (T - 1) * B * D) if dd is not None else None, lddrop=D,
                  gates=_ptr(ctx["gates_dec"], (T - 1) * B * 4 * D), ldgs=4 * D,
@@ -441,9 +446,12 @@ class Engine:
 
         self.mark("bwd.dec.lstm_gemms")
         # ---- attention chain, back-propagation through time ---------------------------------------------------
-        dga = self.buf("dga", T, B, 4 * A)
+        ldz = 4 * A + Ad
+        Z = self.buf("Zatt", T + 1, B, ldz)       # Z[s][b] = [dgates_s | dq_{s-1}]
+        Z[T, :, :4 * A].zero_()
+        dga = Z                                   # dgates_t = Z[t][:, :4A]   (row stride ldz)
+        dq = _ptr(Z, B * ldz + 4 * A)             # dq_t     = Z[t+1][:, 4A:] (row stride ldz)
         dctx_tot = self.buf("dctx_tot", T, B, Ef)
-        dq = self.buf("dq", T, B, Ad)
         dpmT = self.buf("dpmT", B, Ad, L, zero=True)
         dv_part = self.buf("dv_part", B, Ad, zero=True)
         dU_part = self.buf("dU_part", B, Ad * 2 * KL, zero=True)
@@ -460,19 +468,19 @@ class Engine:
                   memory=ctx["memory"], xdec=xdec, att_c=ctx["att_c"], gates=ctx["gates_att"], align=ctx["align"],
                   cum=ctx["cum"], th=ctx["th"], att_drop=masks.get("att_drop"),
                   dh_ext=dxdec, ld_dh=ldx, dctx_ext1=_ptr(dxdec, A), ld_dc1=ldx, dctx_ext2=_ptr(dxproj, D), ld_dc2=ldp,
-                  dgates=dga, dctx_tot=dctx_tot, dq=dq, dpmT=dpmT, dv_part=dv_part, dU_part=dU_part,
+                  dgates=Z, dctx_tot=dctx_tot, dq=None, dpmT=dpmT, dv_part=dv_part, dU_part=dU_part,
                   dc=dc_att, G=Gc, de=de, din_part=din_part)
         call("t2_attn_seq_bwd", sb, st)
         self.mark("bwd.dec.attn_chain")
 
         # weight gradients of the attention chain (large GEMMs over all frames)
         gWih = G["decoder.att_rnn.weight_ih"]
-        self._wgrad(dga, 4 * A, ctx["p2"], Pd, gWih, Pd + Ef, 4 * A, Pd, R)
-        self._wgrad(dga, 4 * A, _ptr(xdec, A), ldx, _ptr(gWih, Pd), Pd + Ef, 4 * A, Ef, R)
-        self._wgrad(dga, 4 * A, xdec, ldx, G["decoder.att_rnn.weight_hh"], A, 4 * A, A, R)
-        call("t2_colsum", dga, 4 * A, R, 4 * A, G["decoder.att_rnn.bias_ih"], st)
-        call("t2_colsum", dga, 4 * A, R, 4 * A, G["decoder.att_rnn.bias_hh"], st)
-        self._wgrad(dq, Ad, _ptr(xdec, B * ldx), ldx, G["decoder.attention.query_layer.weight"], A, Ad, A, R)
+        self._wgrad(dga, ldz, ctx["p2"], Pd, gWih, Pd + Ef, 4 * A, Pd, R)
+        self._wgrad(dga, ldz, _ptr(xdec, A), ldx, _ptr(gWih, Pd), Pd + Ef, 4 * A, Ef, R)
+        self._wgrad(dga, ldz, xdec, ldx, G["decoder.att_rnn.weight_hh"], A, 4 * A, A, R)
+        call("t2_colsum", dga, ldz, R, 4 * A, G["decoder.att_rnn.bias_ih"], st)
+        call("t2_colsum", dga, ldz, R, 4 * A, G["decoder.att_rnn.bias_hh"], st)
+        self._wgrad(dq, ldz, _ptr(xdec, B * ldx), ldx, G["decoder.attention.query_layer.weight"], A, Ad, A, R)
         call("t2_colsum", dv_part, Ad, B, Ad, G["decoder.attention.v.weight"], st)
         dU = self.buf("dU", Ad, 2 * KL, zero=True)
         call("t2_colsum", dU_part, Ad * 2 * KL, B, Ad * 2 * KL, dU, st)
@@ -493,7 +501,7 @@ class Engine:
         # ---- prenet -----------------------------------------------------------------------------------------
         dp2 = self.buf("dp2", T + 1, B, Pd)
         dp2[T].zero_()
-        gemm(dga, P["decoder.att_rnn.weight_ih"], dp2, R, Pd, 4 * A, 4 * A, Pd + Ef, Pd, a_k=1, b_k=0)
+        gemm(dga, P["decoder.att_rnn.weight_ih"], dp2, R, Pd, 4 * A, ldz, Pd + Ef, Pd, a_k=1, b_k=0)
         pd = ctx["pd"]
         g2 = self.buf("g2", T + 1, B, Pd)
         call("t2_relu_mask_bwd", dp2, ctx["p2"], pd[1] if pd else None, g2, R1 * Pd, st)
@@ -521,7 +529,8 @@ class Engine:
         e = ctx["enc_stash"]
         S, Lp = L, L + 4
         hs, cs, gs = e["hs"], e["cs"], e["gs"]
-        dgt = self.buf("enc.dgt", 2, S, B, 4 * H)
+        dgt = self.buf("enc.dgt", 2, S + 1, B, 4 * H)   # dir 0: dgates_t at slot t (zero slot S); dir 1: at slot t+1 (zero slot 0)
+        dgt[0, S].zero_(); dgt[1, 0].zero_()
         dpre = self.buf("enc.dpre", B * Lp, 8 * H, zero=True)
         dc_enc = self.buf("enc.dc", 2, B, H, zero=True)
         steps = (_lib.S["T2LstmBwdStep"] * 2)()
@@ -540,7 +549,8 @@ class Engine:
             sp.c_prev = _ptr(cs[dr, t0 if dr == 0 else t0 + 1]); sp.ldcp = H
             sp.c_cur = _ptr(cs[dr, t0 + 1 if dr == 0 else t0]); sp.ldcc = H
             sp.dc = _ptr(dc_enc[dr]); sp.lddc = H
-            sp.dg_out = _ptr(dgt[dr, t0]); sp.ldgo = 4 * H
+            sp.dg_next = _ptr(dgt[dr, S if dr == 0 else 0]); sp.lddg = 4 * H
+            sp.dg_out = _ptr(dgt[dr, t0 if dr == 0 else t0 + 1]); sp.ldgo = 4 * H
             sp.dg_out2 = _ptr(dpre, t0 * 8 * H + dr * 4 * H); sp.ldgo2 = Lp * 8 * H
             sp.len = len32.data_ptr(); sp.t = t0
             ic = incs[dr]
@@ -550,7 +560,7 @@ class Engine:
         for dr in range(2):
             nm = "encoder.lstm.weight_hh_l0" + ("" if dr == 0 else "_reverse")
             hprev = hs[0, 0] if dr == 0 else hs[1, 1]
-            self._wgrad(_ptr(dgt[dr]), 4 * H, hprev, H, G[nm], H, 4 * H, H, S * B)
+            self._wgrad(_ptr(dgt[dr, 0 if dr == 0 else 1]), 4 * H, hprev, H, G[nm], H, 4 * H, H, S * B)
         Rr = B * Lp - 4
         x3 = e["x3"]
         self._wgrad(dpre, 8 * H, _ptr(x3, 2 * E), E, ps.cat_view("encoder.lstm.weight_ih_l0", 8 * H, E, grad=True), E, 8 * H, E, Rr)
