@@ -35,13 +35,55 @@ struct AttnK {
     float* ctx_out; long ldctx; float* ctx_out2; long ldctx2;
 };
 
-// All global loads of a phase are issued before anything waits on them (one workgroup of 4 waves per CU has no other
-// latency hiding): query rows + att_h, the first round of processed-memory values, then the LDS staging.
+// Load discipline for these one-workgroup-per-CU kernels: every global load of a phase is ISSUED (unconditionally, from a
+// clamped in-range address) before anything waits on one; out-of-range lanes are zeroed by a select afterwards.  A
+// `load -> wait -> use` loop with a run-time trip count costs one full memory round trip (~1 us) per iteration.
 constexpr int MAXI = 3;   // work items (4 positions each) per thread per round: one round covers L <= 192
 
-__global__ __launch_bounds__(256) void attn_energy_kernel(AttnK p) {
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+
+// Stage the haloed location inputs (w_prev, cum_prev) and this slice's folded filter rows into LDS.
+__device__ __forceinline__ void stage_inp_U(float* inp, float* Us, const float* w_prev, long ldw, const float* cum_prev,
+                                            long ldcum, const float* U, const float* dummy, int b, int j, int L, int Lp,
+                                            int tid) {
+    const float* wsrc = w_prev ? w_prev + (long)b * ldw : dummy;
+    const float* csrc = cum_prev ? cum_prev + (long)b * ldcum : dummy;
+    const bool wz = w_prev == nullptr, cz = cum_prev == nullptr;
+    float uv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i, al = idx >> 6, kk = idx & 63;
+        uv[i] = U[(long)(j * 16 + al) * 2 * KL + imin(kk, 2 * KL - 1)];
+    }
+    for (int base = 0; base < 2 * Lp; base += 1024) {
+        float iv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = base + tid + 256 * i;
+            const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
+            const int lc = imin(imax(l, 0), L - 1);
+            iv[i] = (c ? csrc : wsrc)[lc];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = base + tid + 256 * i;
+            const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
+            const bool ok = l >= 0 && l < L && !(c ? cz : wz);
+            if (idx < 2 * Lp) inp[idx] = ok ? iv[i] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
+        Us[idx] = (idx & 63) < 2 * KL ? uv[i] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void attn_energy_kernel(AttnK p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int b = blockIdx.x, j = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.x, j = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int L = p.L, NG = (L + 3) >> 2, Lp = 4 * NG + 36;
     float* inp = sm;             // [2][Lp]   zero-haloed (w_prev, cum_prev)
     float* Us = inp + 2 * Lp;    // [16][64]  folded location filter rows of this slice
@@ -49,60 +91,41 @@ __global__ __launch_bounds__(256) void attn_energy_kernel(AttnK p) {
     float* ec = qs + 16;         // [16][4*NG] per-dim energy contributions
     const int items = 16 * NG;
 
-    // ---- issue: query projection operands (4 dims per wave) ----
-    float qacc[4] = {0.f, 0.f, 0.f, 0.f};
-    const float* h = p.att_h + (long)b * p.ldh;
-    const float* wq0 = p.Wq + (long)(j * 16 + w * 4) * p.A;
     // ---- issue: first round of processed-memory values + v ----
     float pmv[MAXI][4], vv[MAXI];
 #pragma unroll
     for (int it = 0; it < MAXI; ++it) {
-        const int item = tid + 256 * it;
-        vv[it] = 0.f;
+        const int item = imin(tid + 256 * it, items - 1);
+        const int al = item / NG, lg = item - al * NG;
+        const int a = j * 16 + al;
+        vv[it] = p.v[a];
+        const float* pr = p.pmT + ((long)b * p.Ad + a) * L;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pmv[it][i] = 0.f;
-        if (item < items) {
-            const int al = item / NG, lg = item - al * NG;
-            const int a = j * 16 + al;
-            vv[it] = p.v[a];
-            const float* pr = p.pmT + ((long)b * p.Ad + a) * L + 4 * lg;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (4 * lg + i < L) pmv[it][i] = pr[i];
-        }
+        for (int i = 0; i < 4; ++i) pmv[it][i] = pr[imin(4 * lg + i, L - 1)];
     }
+    // ---- issue + accumulate: query projection (4 dims per wave, 16-byte loads) ----
+    float qacc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* h = p.att_h + (long)b * p.ldh;
+    const float* wq0 = p.Wq + (long)(j * 16 + w * 4) * p.A;
     for (int k0 = lane * 4; k0 < p.A; k0 += 1024) {
         f32x4 hv[4], wv[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int k = k0 + 256 * i;
-            const bool ok = k < p.A;
-            hv[i] = ok ? *reinterpret_cast<const f32x4*>(h + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int k = imin(k0 + 256 * i, p.A - 4);
+            hv[i] = *reinterpret_cast<const f32x4*>(h + k);
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa) wv[aa][i] = *reinterpret_cast<const f32x4*>(wq0 + (long)aa * p.A + k);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float okf = (k0 + 256 * i) < p.A ? 1.f : 0.f;
 #pragma unroll
             for (int aa = 0; aa < 4; ++aa)
-                wv[aa][i] = ok ? *reinterpret_cast<const f32x4*>(wq0 + (long)aa * p.A + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                qacc[aa] += okf * (hv[i][0] * wv[aa][i][0] + hv[i][1] * wv[aa][i][1] + hv[i][2] * wv[aa][i][2] +
+                                   hv[i][3] * wv[aa][i][3]);
         }
-#pragma unroll
-        for (int aa = 0; aa < 4; ++aa)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                qacc[aa] += hv[i][0] * wv[aa][i][0] + hv[i][1] * wv[aa][i][1] + hv[i][2] * wv[aa][i][2] + hv[i][3] * wv[aa][i][3];
     }
-    // ---- LDS staging ----
-    for (int idx = tid; idx < 2 * Lp; idx += 256) {
-        const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
-        float val = 0.f;
-        if (l >= 0 && l < L) {
-            const float* src = c == 0 ? p.w_prev : p.cum_prev;
-            const long ld = c == 0 ? p.ldw : p.ldcum;
-            if (src) val = src[(long)b * ld + l];
-        }
-        inp[idx] = val;
-    }
-    for (int idx = tid; idx < 16 * 64; idx += 256) {
-        const int al = idx >> 6, kk = idx & 63;
-        Us[idx] = kk < 2 * KL ? p.U[(long)(j * 16 + al) * 2 * KL + kk] : 0.f;
-    }
+    stage_inp_U(inp, Us, p.w_prev, p.ldw, p.cum_prev, p.ldcum, p.U, p.pmT, b, j, L, Lp, tid);
 #pragma unroll
     for (int aa = 0; aa < 4; ++aa) {
         const float sq = t2_wave_sum(qacc[aa]);
@@ -114,15 +137,13 @@ __global__ __launch_bounds__(256) void attn_energy_kernel(AttnK p) {
         if (base > 0) {   // later rounds (L > 192): fetch their processed-memory values now
 #pragma unroll
             for (int it = 0; it < MAXI; ++it) {
-                const int item = base + tid + 256 * it;
-                if (item < items) {
-                    const int al = item / NG, lg = item - al * NG;
-                    const int a = j * 16 + al;
-                    vv[it] = p.v[a];
-                    const float* pr = p.pmT + ((long)b * p.Ad + a) * L + 4 * lg;
+                const int item = imin(base + tid + 256 * it, items - 1);
+                const int al = item / NG, lg = item - al * NG;
+                const int a = j * 16 + al;
+                vv[it] = p.v[a];
+                const float* pr = p.pmT + ((long)b * p.Ad + a) * L;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) pmv[it][i] = (4 * lg + i < L) ? pr[i] : 0.f;
-                }
+                for (int i = 0; i < 4; ++i) pmv[it][i] = pr[imin(4 * lg + i, L - 1)];
             }
         }
 #pragma unroll
@@ -171,31 +192,43 @@ __global__ __launch_bounds__(256) void attn_energy_kernel(AttnK p) {
     }
 }
 
-__global__ __launch_bounds__(256) void attn_context_kernel(AttnK p) {
+__global__ __launch_bounds__(256, 1) void attn_context_kernel(AttnK p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x, es0 = blockIdx.y * 32, tid = threadIdx.x;
     const int L = p.L, NA = p.Ad >> 4;
     float* ws = sm;                       // [L rounded to 4]
     float* red = ws + ((L + 3) & ~3);     // [8]
     float* part = red + 8;                // [8][32]
-    const int len = p.len[b];
-    // ---- issue the encoder-memory reads of the first 192 positions now; they do not depend on the softmax ----
+    // ---- issue: encoder-memory slice of the first 192 positions (independent of the softmax) ----
     constexpr int NR = 24;
     const int el = tid & 31, lg = tid >> 5;
     const float* mp = p.memory + (long)b * L * p.Ef + es0 + el;
     float mv[NR];
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const int l = lg + 8 * i;
-        mv[i] = l < L ? mp[(long)l * p.Ef] : 0.f;
-    }
+    for (int i = 0; i < NR; ++i) mv[i] = mp[(long)imin(lg + 8 * i, L - 1) * p.Ef];
+    // ---- issue: partial energies of this thread's position(s), previous cumulative weights, length ----
+    const int len = p.len[b];
     float mx = -INFINITY;
-    for (int l = tid; l < L; l += 256) {
+    for (int l0 = 0; l0 < L; l0 += 256) {
+        const int l = l0 + tid, lc = imin(l, L - 1);
+        float ev[8];
         float e = 0.f;
-        for (int j = 0; j < NA; ++j) e += p.e_part[((long)b * NA + j) * L + l];
-        if (l >= len) e = -INFINITY;
-        ws[l] = e;
-        mx = fmaxf(mx, e);
+        for (int j0 = 0; j0 < NA; j0 += 8) {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) ev[jj] = p.e_part[((long)b * NA + imin(j0 + jj, NA - 1)) * L + lc];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) e += (j0 + jj) < NA ? ev[jj] : 0.f;
+        }
+        if (l < L) {
+            if (l >= len) e = -INFINITY;
+            ws[l] = e;
+            mx = fmaxf(mx, e);
+        }
+    }
+    float cprev[2] = {0.f, 0.f};   // previous cumulative weights for the (<= 2) positions this thread writes
+    if (blockIdx.y == 0 && p.cum_prev) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) cprev[r] = p.cum_prev[(long)b * p.ldcum + imin(tid + 256 * r, L - 1)];
     }
     mx = t2_block_max(mx, red);
     float sum = 0.f;
@@ -205,12 +238,15 @@ __global__ __launch_bounds__(256) void attn_context_kernel(AttnK p) {
         sum += pe;
     }
     sum = t2_block_sum(sum, red);
-    for (int l = tid; l < L; l += 256) {
+    for (int l = tid, r = 0; l < L; l += 256, ++r) {
         const float wv = ws[l] / sum;
         ws[l] = wv;
         if (blockIdx.y == 0) {
             p.w_out[(long)b * p.ldwo + l] = wv;
-            if (p.cum_out) p.cum_out[(long)b * p.ldco + l] = (p.cum_prev ? p.cum_prev[(long)b * p.ldcum + l] : 0.f) + wv;
+            if (p.cum_out) {
+                const float cp = r < 2 ? cprev[r] : (p.cum_prev ? p.cum_prev[(long)b * p.ldcum + l] : 0.f);
+                p.cum_out[(long)b * p.ldco + l] = cp + wv;
+            }
         }
     }
     __syncthreads();
@@ -225,11 +261,11 @@ __global__ __launch_bounds__(256) void attn_context_kernel(AttnK p) {
     part[lg * 32 + el] = acc;
     __syncthreads();
     if (tid < 32) {
-        float s = 0.f;
+        float s2 = 0.f;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) s += part[g * 32 + tid];
-        p.ctx_out[(long)b * p.ldctx + es0 + tid] = s;
-        if (p.ctx_out2) p.ctx_out2[(long)b * p.ldctx2 + es0 + tid] = s;
+        for (int g = 0; g < 8; ++g) s2 += part[g * 32 + tid];
+        p.ctx_out[(long)b * p.ldctx + es0 + tid] = s2;
+        if (p.ctx_out2) p.ctx_out2[(long)b * p.ldctx2 + es0 + tid] = s2;
     }
 }
 
@@ -370,43 +406,65 @@ struct AttnBwdK {
 
 namespace {
 
-__global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdK p) {
+__global__ __launch_bounds__(256, 1) void attn_bwd_dw_kernel(AttnBwdK p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x, l0 = blockIdx.y * 32, tid = threadIdx.x;
     const int L = p.L, Ef = p.Ef, NA = p.Ad >> 4;
     float* dctx_s = sm;                    // [Ef]
     float* dwx_s = dctx_s + Ef;            // [L rounded]
     float* red = dwx_s + ((L + 3) & ~3);   // [8]
-    // issue this thread's share of its memory row first (8 lanes per position, 16 B each, stride 128 B)
+    // ---- issue: this thread's share of its memory row (8 lanes per position, 16 B each, stride 128 B) ----
     constexpr int NEV = 20;                // covers Ef <= 640 in registers
     const int l = l0 + (tid >> 3), sub = tid & 7;
-    const float* mp = p.memory + ((long)b * L + (l < L ? l : 0)) * Ef;
+    const float* mp = p.memory + ((long)b * L + imin(l, L - 1)) * Ef;
     f32x4 mv[NEV];
 #pragma unroll
-    for (int i = 0; i < NEV; ++i) {
-        const int e = sub * 4 + 32 * i;
-        mv[i] = (l < L && e < Ef) ? *reinterpret_cast<const f32x4*>(mp + e) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+    for (int i = 0; i < NEV; ++i) mv[i] = *reinterpret_cast<const f32x4*>(mp + imin(sub * 4 + 32 * i, Ef - 4));
+    // ---- issue: dctx / ctx (<= 4 per thread per pass) ----
     float part = 0.f;
-    for (int e = tid; e < Ef; e += 256) {
-        const float dv = p.dctx[(long)b * p.lddctx + e];
-        dctx_s[e] = dv;
-        part = fmaf(dv, p.ctx[(long)b * p.ldctx + e], part);
+    for (int e0 = 0; e0 < Ef; e0 += 1024) {
+        float dv[4], cv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = imin(e0 + tid + 256 * i, Ef - 1);
+            dv[i] = p.dctx[(long)b * p.lddctx + e];
+            cv[i] = p.ctx[(long)b * p.ldctx + e];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = e0 + tid + 256 * i;
+            if (e < Ef) { dctx_s[e] = dv[i]; part = fmaf(dv[i], cv[i], part); }
+        }
     }
-    for (int ll = tid; ll < L; ll += 256) {
+    // ---- location-path gradient of every position (needed for sigma), partials of frame t+1 ----
+    for (int ll0 = 0; ll0 < L; ll0 += 256) {
+        const int ll = ll0 + tid, lc = imin(ll, L - 1);
         float g0 = 0.f, g1 = 0.f;
         if (p.din_part) {
-            for (int j = 0; j < NA; ++j) {
-                g0 += p.din_part[(((long)b * NA + j) * 2 + 0) * L + ll];
-                g1 += p.din_part[(((long)b * NA + j) * 2 + 1) * L + ll];
+            for (int j0 = 0; j0 < NA; j0 += 8) {
+                float a0[8], a1[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const long o = (((long)b * NA + imin(j0 + jj, NA - 1)) * 2) * L + lc;
+                    a0[jj] = p.din_part[o];
+                    a1[jj] = p.din_part[o + L];
+                }
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj)
+                    if (j0 + jj < NA) { g0 += a0[jj]; g1 += a1[jj]; }
             }
         }
-        const float Gn = g1 + (p.G_in ? p.G_in[(long)b * L + ll] : 0.f);
-        const float dx = g0 + Gn;
-        dwx_s[ll] = dx;
-        if (blockIdx.y == 0) p.G_out[(long)b * L + ll] = Gn;
-        part = fmaf(p.w[(long)b * p.ldw + ll], dx, part);
+        const float gin = p.G_in ? p.G_in[(long)b * L + lc] : 0.f;
+        const float wl = p.w[(long)b * p.ldw + lc];
+        if (ll < L) {
+            const float Gn = g1 + gin;
+            const float dx = g0 + Gn;
+            dwx_s[ll] = dx;
+            if (blockIdx.y == 0) p.G_out[(long)b * L + ll] = Gn;
+            part = fmaf(wl, dx, part);
+        }
     }
+    const float wme = p.w[(long)b * p.ldw + imin(l, L - 1)];
     const float sigma = t2_block_sum(part, red);
     float acc = 0.f;
 #pragma unroll
@@ -423,10 +481,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdK p) {
     acc += __shfl_xor(acc, 1, 64);
     acc += __shfl_xor(acc, 2, 64);
     acc += __shfl_xor(acc, 4, 64);
-    if (sub == 0 && l < L) p.de[(long)b * L + l] = p.w[(long)b * p.ldw + l] * (acc + dwx_s[l] - sigma);
+    if (sub == 0 && l < L) p.de[(long)b * L + l] = wme * (acc + dwx_s[l] - sigma);
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_ds_kernel(AttnBwdK p) {
+__global__ __launch_bounds__(256, 1) void attn_bwd_ds_kernel(AttnBwdK p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
     const int L = p.L, NG = (L + 3) >> 2, Lp = 4 * NG + 36, L4 = 4 * NG;
@@ -440,36 +498,25 @@ __global__ __launch_bounds__(256) void attn_bwd_ds_kernel(AttnBwdK p) {
     float thv[MAXI][4], vv[MAXI];
 #pragma unroll
     for (int it = 0; it < MAXI; ++it) {
-        const int item = tid + 256 * it;
-        vv[it] = 0.f;
+        const int item = imin(tid + 256 * it, items - 1);
+        const int al = item / NG, lg = item - al * NG;
+        const int a = j * 16 + al;
+        vv[it] = p.v[a];
+        const float* tr = p.th + ((long)b * p.Ad + a) * L;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) thv[it][i] = 0.f;
-        if (item < items) {
-            const int al = item / NG, lg = item - al * NG;
-            const int a = j * 16 + al;
-            vv[it] = p.v[a];
-            const float* tr = p.th + ((long)b * p.Ad + a) * L + 4 * lg;
+        for (int i = 0; i < 4; ++i) thv[it][i] = tr[imin(4 * lg + i, L - 1)];
+    }
+    float dev[4];   // de for up to 1024 positions per pass
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (4 * lg + i < L) thv[it][i] = tr[i];
-        }
-    }
-    for (int idx = tid; idx < 2 * Lp; idx += 256) {
-        const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
-        float val = 0.f;
-        if (l >= 0 && l < L) {
-            const float* src = c == 0 ? p.w_prev : p.cum_prev;
-            const long ld = c == 0 ? p.ldwp : p.ldcp;
-            if (src) val = src[(long)b * ld + l];
-        }
-        inp[idx] = val;
-    }
+    for (int i = 0; i < 4; ++i) dev[i] = p.de[(long)b * L + imin(tid + 256 * i, L - 1)];
+    stage_inp_U(inp, Us, p.w_prev, p.ldwp, p.cum_prev, p.ldcp, p.U, p.th, b, j, L, Lp, tid);
     for (int idx = tid; idx < 16 * Lp; idx += 256) dsp[idx] = 0.f;
-    for (int idx = tid; idx < 16 * 64; idx += 256) {
-        const int al = idx >> 6, kk = idx & 63;
-        Us[idx] = kk < 2 * KL ? p.U[(long)(j * 16 + al) * 2 * KL + kk] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int l = tid + 256 * i;
+        if (l < L4) des[l] = l < L ? dev[i] : 0.f;
     }
-    for (int l = tid; l < L4; l += 256) des[l] = l < L ? p.de[(long)b * L + l] : 0.f;
+    for (int l = tid + 1024; l < L4; l += 256) des[l] = l < L ? p.de[(long)b * L + l] : 0.f;
     __syncthreads();
 
     // phase A: ds, dpmT accumulation

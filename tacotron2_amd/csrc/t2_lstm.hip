@@ -51,6 +51,27 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmK2 pp) {
     f32x4 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // Epilogue operands (hoisted: issued now, consumed after the GEMM, so they never add a memory round trip)
+    const int eb = tid >> 2, euu = tid & 3, eu = u0 + euu;
+    const long ebc = eb < p.B ? eb : p.B - 1;
+    float e_pre[4] = {0.f, 0.f, 0.f, 0.f}, e_b1[4] = {0.f, 0.f, 0.f, 0.f}, e_b2[4] = {0.f, 0.f, 0.f, 0.f};
+    float e_cp = 0.f, e_drop = 1.f;
+    int e_len = 0x7fffffff;
+    if (p.pre) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) e_pre[g] = p.pre[ebc * p.ldpre + g * H + eu];
+    }
+    if (p.bias1) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) e_b1[g] = p.bias1[g * H + eu];
+    }
+    if (p.bias2) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) e_b2[g] = p.bias2[g * H + eu];
+    }
+    if (p.c_prev) e_cp = p.c_prev[ebc * p.ldc_prev + eu];
+    if (p.drop) e_drop = p.drop[ebc * p.lddrop + eu];
+    if (p.len) e_len = p.len[ebc];
 
     // Flattened 16-deep chunk list over the input segments; wave w owns chunks w, w+4, ...
     const int cb1 = p.nseg > 0 ? (p.seg[0].K >> 4) : 0;
@@ -179,6 +200,27 @@ __global__ __launch_bounds__(256, 1) void lstm_step_fwd_fast_kernel(LstmK2 pp) {
     f32x4 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // Epilogue operands (hoisted: issued now, consumed after the GEMM, so they never add a memory round trip)
+    const int eb = tid >> 2, euu = tid & 3, eu = u0 + euu;
+    const long ebc = eb < p.B ? eb : p.B - 1;
+    float e_pre[4] = {0.f, 0.f, 0.f, 0.f}, e_b1[4] = {0.f, 0.f, 0.f, 0.f}, e_b2[4] = {0.f, 0.f, 0.f, 0.f};
+    float e_cp = 0.f, e_drop = 1.f;
+    int e_len = 0x7fffffff;
+    if (p.pre) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) e_pre[g] = p.pre[ebc * p.ldpre + g * H + eu];
+    }
+    if (p.bias1) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) e_b1[g] = p.bias1[g * H + eu];
+    }
+    if (p.bias2) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) e_b2[g] = p.bias2[g * H + eu];
+    }
+    if (p.c_prev) e_cp = p.c_prev[ebc * p.ldc_prev + eu];
+    if (p.drop) e_drop = p.drop[ebc * p.lddrop + eu];
+    if (p.len) e_len = p.len[ebc];
     constexpr int U = 4;
     auto load_group = [&](int g, f32x4 (&bw)[U], f32x4 (&ax)[U][MT]) {
 #pragma unroll
@@ -233,27 +275,21 @@ __global__ __launch_bounds__(256, 1) void lstm_step_fwd_fast_kernel(LstmK2 pp) {
         for (int g = 0; g < 4; ++g) red[((w * MT + m) * 16 + (q * 4 + g)) * 16 + r] = acc[m][g];
     __syncthreads();
     if (tid < MT * 64) {
-        const int b = tid >> 2, uu = tid & 3;
+        const int b = eb, uu = euu;
         if (b < p.B) {
-            const int u = u0 + uu;
+            const int u = eu;
             float gsum[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float s = 0.f;
 #pragma unroll
                 for (int ww = 0; ww < 4; ++ww) s += red[((ww * MT + (b >> 4)) * 16 + (b & 15)) * 16 + g * 4 + uu];
-                const int n = g * H + u;
-                if (p.pre) s += p.pre[(long)b * p.ldpre + n];
-                if (p.bias1) s += p.bias1[n];
-                if (p.bias2) s += p.bias2[n];
-                gsum[g] = s;
+                gsum[g] = s + e_pre[g] + e_b1[g] + e_b2[g];
             }
-            const bool active = (p.len == nullptr) || (p.t < p.len[b]);
+            const bool active = p.t < e_len;
             float gi = t2_sigmoid(gsum[0]), gf = t2_sigmoid(gsum[1]), gg = tanhf(gsum[2]), go = t2_sigmoid(gsum[3]);
-            const float cp = p.c_prev ? p.c_prev[(long)b * p.ldc_prev + u] : 0.f;
-            float cn = gf * cp + gi * gg;
-            float hn = go * tanhf(cn);
-            if (p.drop) hn *= p.drop[(long)b * p.lddrop + u];
+            float cn = gf * e_cp + gi * gg;
+            float hn = go * tanhf(cn) * e_drop;
             if (!active) { hn = 0.f; cn = 0.f; gi = gf = gg = go = 0.f; }
             p.h_out[(long)b * p.ldh + u] = hn;
             if (p.h_out2) p.h_out2[(long)b * p.ldh2 + u] = hn;
@@ -460,6 +496,60 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(BwdK2 pp) {
 
 // Fast path of the backward step: ONE contiguous gradient row block dg[b][0:K) (K = N4 + N2) against the packed,
 // zero-padded transposed weight stream; same branch-free double-buffered structure as the forward fast path.
+struct BwdEpi { float ext, drop, gi, gf, gg, go, cp, cc, dc; int len; };
+
+__device__ __forceinline__ BwdEpi bwd_epi_load(const BwdK& p, int tid, int u0, int b0) {
+    BwdEpi e;
+    const int bl = tid >> 4, ul = tid & 15;
+    const long b = (b0 + bl) < p.B ? (b0 + bl) : p.B - 1;
+    const int u = (u0 + ul) < p.ncols ? (u0 + ul) : p.ncols - 1;
+    e.ext = 0.f; e.drop = 1.f; e.gi = e.gf = e.gg = e.go = 0.f; e.cp = 0.f; e.cc = 0.f; e.dc = 0.f; e.len = 0x7fffffff;
+    if (p.ext1) e.ext = p.ext1[b * p.ldx1 + u];
+    if (p.ext2) e.ext += p.ext2[b * p.ldx2 + u];
+    if (p.epi == 1) {
+        const int H = p.H;
+        if (p.drop) e.drop = p.drop[b * p.lddrop + u];
+        const float* gs = p.gates + b * p.ldgs + u;
+        e.gi = gs[0]; e.gf = gs[H]; e.gg = gs[2 * H]; e.go = gs[3 * H];
+        if (p.c_prev) e.cp = p.c_prev[b * p.ldcp + u];
+        e.cc = p.c_cur[b * p.ldcc + u];
+        e.dc = p.dc[b * p.lddc + u];
+        if (p.len) e.len = p.len[b];
+    }
+    return e;
+}
+
+__device__ __forceinline__ void bwd_epi_apply(const BwdK& p, const BwdEpi& e, const float* red, int tid, int u0, int b0) {
+    const int bl = tid >> 4, ul = tid & 15;
+    const int b = b0 + bl, u = u0 + ul;
+    if (b < p.B && u < p.ncols) {
+        const float dx = red[(0 * 16 + bl) * 16 + ul] + red[(1 * 16 + bl) * 16 + ul] + red[(2 * 16 + bl) * 16 + ul] +
+                         red[(3 * 16 + bl) * 16 + ul] + e.ext;
+        if (p.epi == 0) {
+            p.dx_out[(long)b * p.lddx + u] = dx;
+        } else {
+            const int H = p.H;
+            const bool active = p.t < e.len;
+            const float dh = dx * e.drop;
+            const float tc = tanhf(e.cc);
+            const float dcv = e.dc + dh * e.go * (1.f - tc * tc);
+            float d_o = dh * tc * e.go * (1.f - e.go);
+            float d_i = dcv * e.gg * e.gi * (1.f - e.gi);
+            float d_f = dcv * e.cp * e.gf * (1.f - e.gf);
+            float d_g = dcv * e.gi * (1.f - e.gg * e.gg);
+            float dcp = dcv * e.gf;
+            if (!active) { d_i = d_f = d_g = d_o = 0.f; dcp = 0.f; }
+            p.dc[(long)b * p.lddc + u] = dcp;
+            float* dgo = p.dg_out + (long)b * p.ldgo + u;
+            dgo[0] = d_i; dgo[H] = d_f; dgo[2 * H] = d_g; dgo[3 * H] = d_o;
+            if (p.dg_out2) {
+                float* dg2o = p.dg_out2 + (long)b * p.ldgo2 + u;
+                dg2o[0] = d_i; dg2o[H] = d_f; dg2o[2 * H] = d_g; dg2o[3 * H] = d_o;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256, 1) void lstm_step_bwd_fast_kernel(BwdK2 pp) {
     const BwdK& p = pp.s[blockIdx.z];
     __shared__ float red[4 * 256];
@@ -470,6 +560,7 @@ __global__ __launch_bounds__(256, 1) void lstm_step_bwd_fast_kernel(BwdK2 pp) {
     const int NCH = (p.N4 + p.N2) >> 4, NCHpad = (NCH + 15) & ~15, G = NCHpad >> 4;
     const float* wb = p.wtpacked + (long)blockIdx.x * NCHpad * 256 + lane * 4;
     const float* ab = p.dg_next + (long)((b0 + r) < p.B ? (b0 + r) : 0) * p.lddg + 4 * q;
+    const BwdEpi epi = bwd_epi_load(p, tid, u0, b0);   // hoisted: in flight during the GEMM
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     constexpr int U = 4;
     auto load_group = [&](int g, f32x4 (&a)[U], f32x4 (&b)[U]) {
@@ -516,7 +607,7 @@ __global__ __launch_bounds__(256, 1) void lstm_step_bwd_fast_kernel(BwdK2 pp) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) red[(w * 16 + (q * 4 + g)) * 16 + r] = acc0[g] + acc1[g];
     __syncthreads();
-    bwd_epilogue(p, red, tid, u0, b0);
+    bwd_epi_apply(p, epi, red, tid, u0, b0);
 }
 
 void to_bk(const T2LstmBwdStep& s, BwdK& k) {
