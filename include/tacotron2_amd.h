@@ -88,7 +88,8 @@ int t2_lstm_step_fwd(const T2LstmStep* steps, int n, void* stream);
 /* Weight streams re-laid once per optimisation step so that every wave-instruction of the step kernels reads one
  * contiguous 1 KB block (16 B per lane) instead of 16 rows with a power-of-two stride:
  *   fwd: out[H/4][NTpad][64][4],  NT = sum_s K_s/16;   bwd: out[ceil(ncols/16)][NCHpad][64][4] (transposed),
- *   NCH = N4/16 + N2/16; both chunk counts are zero-padded to a multiple of 16 (branch-free kernel main loops). */
+ *   NCH = N4/16 + N2/16; chunk counts are zero-padded (fwd: multiple of 16, bwd: multiple of 32) so the kernels' main
+ *   loops are branch-free. */
 int t2_lstm_pack_fwd(const T2Seg* segs, int nseg, int H, float* out, void* stream);
 int t2_lstm_pack_bwd(const float* W, int64_t ldw, int N4, const float* W2, int64_t ldw2, int N2, int ncols, float* out,
                      void* stream);

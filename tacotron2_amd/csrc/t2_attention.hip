@@ -43,47 +43,52 @@ constexpr int MAXI = 3;   // work items (4 positions each) per thread per round:
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
-// Stage the haloed location inputs (w_prev, cum_prev) and this slice's folded filter rows into LDS.
+// Stage the haloed location inputs (w_prev, cum_prev) and this slice's folded filter rows into LDS (NTH threads).
+template <int NTH>
 __device__ __forceinline__ void stage_inp_U(float* inp, float* Us, const float* w_prev, long ldw, const float* cum_prev,
                                             long ldcum, const float* U, const float* dummy, int b, int j, int L, int Lp,
                                             int tid) {
+    constexpr int PER = 1024 / NTH;
     const float* wsrc = w_prev ? w_prev + (long)b * ldw : dummy;
     const float* csrc = cum_prev ? cum_prev + (long)b * ldcum : dummy;
     const bool wz = w_prev == nullptr, cz = cum_prev == nullptr;
-    float uv[4];
+    float uv[PER];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = tid + 256 * i, al = idx >> 6, kk = idx & 63;
+    for (int i = 0; i < PER; ++i) {
+        const int idx = tid + NTH * i, al = idx >> 6, kk = idx & 63;
         uv[i] = U[(long)(j * 16 + al) * 2 * KL + imin(kk, 2 * KL - 1)];
     }
     for (int base = 0; base < 2 * Lp; base += 1024) {
-        float iv[4];
+        float iv[PER];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = base + tid + 256 * i;
+        for (int i = 0; i < PER; ++i) {
+            const int idx = base + tid + NTH * i;
             const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
             const int lc = imin(imax(l, 0), L - 1);
             iv[i] = (c ? csrc : wsrc)[lc];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = base + tid + 256 * i;
+        for (int i = 0; i < PER; ++i) {
+            const int idx = base + tid + NTH * i;
             const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
             const bool ok = l >= 0 && l < L && !(c ? cz : wz);
             if (idx < 2 * Lp) inp[idx] = ok ? iv[i] : 0.f;
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = tid + 256 * i;
+    for (int i = 0; i < PER; ++i) {
+        const int idx = tid + NTH * i;
         Us[idx] = (idx & 63) < 2 * KL ? uv[i] : 0.f;
     }
 }
 
-__global__ __launch_bounds__(256, 1) void attn_energy_kernel(AttnK p) {
+constexpr int ENT = 512;   // threads of the energy / ds kernels: two waves per SIMD double the VALU issue rate
+constexpr int EMAXI = 2;   // work items per thread per round: one round covers L <= 256
+
+__global__ __launch_bounds__(ENT, 2) void attn_energy_kernel(AttnK p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x, j = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
     const int L = p.L, NG = (L + 3) >> 2, Lp = 4 * NG + 36;
     float* inp = sm;             // [2][Lp]   zero-haloed (w_prev, cum_prev)
     float* Us = inp + 2 * Lp;    // [16][64]  folded location filter rows of this slice
@@ -92,10 +97,10 @@ __global__ __launch_bounds__(256, 1) void attn_energy_kernel(AttnK p) {
     const int items = 16 * NG;
 
     // ---- issue: first round of processed-memory values + v ----
-    float pmv[MAXI][4], vv[MAXI];
+    float pmv[EMAXI][4], vv[EMAXI];
 #pragma unroll
-    for (int it = 0; it < MAXI; ++it) {
-        const int item = imin(tid + 256 * it, items - 1);
+    for (int it = 0; it < EMAXI; ++it) {
+        const int item = imin(tid + ENT * it, items - 1);
         const int al = item / NG, lg = item - al * NG;
         const int a = j * 16 + al;
         vv[it] = p.v[a];
@@ -103,41 +108,41 @@ __global__ __launch_bounds__(256, 1) void attn_energy_kernel(AttnK p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) pmv[it][i] = pr[imin(4 * lg + i, L - 1)];
     }
-    // ---- issue + accumulate: query projection (4 dims per wave, 16-byte loads) ----
-    float qacc[4] = {0.f, 0.f, 0.f, 0.f};
+    // ---- issue + accumulate: query projection (2 dims per wave, 16-byte loads) ----
+    float qacc[2] = {0.f, 0.f};
     const float* h = p.att_h + (long)b * p.ldh;
-    const float* wq0 = p.Wq + (long)(j * 16 + w * 4) * p.A;
+    const float* wq0 = p.Wq + (long)(j * 16 + w * 2) * p.A;
     for (int k0 = lane * 4; k0 < p.A; k0 += 1024) {
-        f32x4 hv[4], wv[4][4];
+        f32x4 hv[4], wv[2][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = imin(k0 + 256 * i, p.A - 4);
             hv[i] = *reinterpret_cast<const f32x4*>(h + k);
 #pragma unroll
-            for (int aa = 0; aa < 4; ++aa) wv[aa][i] = *reinterpret_cast<const f32x4*>(wq0 + (long)aa * p.A + k);
+            for (int aa = 0; aa < 2; ++aa) wv[aa][i] = *reinterpret_cast<const f32x4*>(wq0 + (long)aa * p.A + k);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float okf = (k0 + 256 * i) < p.A ? 1.f : 0.f;
 #pragma unroll
-            for (int aa = 0; aa < 4; ++aa)
+            for (int aa = 0; aa < 2; ++aa)
                 qacc[aa] += okf * (hv[i][0] * wv[aa][i][0] + hv[i][1] * wv[aa][i][1] + hv[i][2] * wv[aa][i][2] +
                                    hv[i][3] * wv[aa][i][3]);
         }
     }
-    stage_inp_U(inp, Us, p.w_prev, p.ldw, p.cum_prev, p.ldcum, p.U, p.pmT, b, j, L, Lp, tid);
+    stage_inp_U<ENT>(inp, Us, p.w_prev, p.ldw, p.cum_prev, p.ldcum, p.U, p.pmT, b, j, L, Lp, tid);
 #pragma unroll
-    for (int aa = 0; aa < 4; ++aa) {
+    for (int aa = 0; aa < 2; ++aa) {
         const float sq = t2_wave_sum(qacc[aa]);
-        if (lane == 0) qs[w * 4 + aa] = sq;
+        if (lane == 0) qs[w * 2 + aa] = sq;
     }
     __syncthreads();
 
-    for (int base = 0; base < items; base += 256 * MAXI) {
-        if (base > 0) {   // later rounds (L > 192): fetch their processed-memory values now
+    for (int base = 0; base < items; base += ENT * EMAXI) {
+        if (base > 0) {   // later rounds (L > 256): fetch their processed-memory values now
 #pragma unroll
-            for (int it = 0; it < MAXI; ++it) {
-                const int item = imin(base + tid + 256 * it, items - 1);
+            for (int it = 0; it < EMAXI; ++it) {
+                const int item = imin(base + tid + ENT * it, items - 1);
                 const int al = item / NG, lg = item - al * NG;
                 const int a = j * 16 + al;
                 vv[it] = p.v[a];
@@ -147,28 +152,29 @@ __global__ __launch_bounds__(256, 1) void attn_energy_kernel(AttnK p) {
             }
         }
 #pragma unroll
-        for (int it = 0; it < MAXI; ++it) {
-            const int item = base + tid + 256 * it;
+        for (int it = 0; it < EMAXI; ++it) {
+            const int item = base + tid + ENT * it;
             if (item >= items) continue;
             const int al = item / NG, lg = item - al * NG;
             const int a = j * 16 + al;
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                float win[36];
+                float win[36], uk[32];
                 const f32x4* wp = reinterpret_cast<const f32x4*>(inp + c * Lp + 4 * lg);
 #pragma unroll
                 for (int i = 0; i < 9; ++i) {
                     const f32x4 t = wp[i];
                     win[4 * i] = t[0]; win[4 * i + 1] = t[1]; win[4 * i + 2] = t[2]; win[4 * i + 3] = t[3];
                 }
+                // filter taps of (dim al, channel c): Us row is 64 floats, channel 1 starts at 31 -> read taps singly
                 const float* u = Us + al * 64 + c * KL;
 #pragma unroll
-                for (int k = 0; k < KL; ++k) {
-                    const float uk = u[k];
+                for (int k = 0; k < KL; ++k) uk[k] = u[k];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(uk, win[i + k], acc[i]);
-                }
+                for (int k = 0; k < KL; ++k)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(uk[k], win[i + k], acc[i]);
             }
             const float qa = qs[al];
             const long rowoff = ((long)b * p.Ad + a) * L;
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(256, 1) void attn_energy_kernel(AttnK p) {
             for (int i = 0; i < 4; ++i) {
                 const int l = 4 * lg + i;
                 if (l < L) {
-                    const float th = tanhf(qa + acc[i] + pmv[it][i]);
+                    const float th = t2_tanh(qa + acc[i] + pmv[it][i]);
                     if (p.th_out) p.th_out[rowoff + l] = th;
                     ec[al * 4 * NG + l] = vv[it] * th;
                 }
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void attn_energy_kernel(AttnK p) {
         }
     }
     __syncthreads();
-    for (int l = tid; l < L; l += 256) {
+    for (int l = tid; l < L; l += ENT) {
         float s = 0.f;
 #pragma unroll
         for (int al = 0; al < 16; ++al) s += ec[al * 4 * NG + l];
@@ -303,7 +309,7 @@ int launch_attn(const T2AttnStep& s, hipStream_t st) {
     const int NG = (s.L + 3) >> 2, Lp = 4 * NG + 36;
     const size_t sm_e = (size_t)(2 * Lp + 16 * 64 + 16 + 16 * 4 * NG) * sizeof(float);
     const size_t sm_c = (size_t)(((s.L + 3) & ~3) + 8 + 256) * sizeof(float);
-    hipLaunchKernelGGL(attn_energy_kernel, dim3(s.B, s.Ad / 16), dim3(256), sm_e, st, k);
+    hipLaunchKernelGGL(attn_energy_kernel, dim3(s.B, s.Ad / 16), dim3(ENT), sm_e, st, k);
     hipLaunchKernelGGL(attn_context_kernel, dim3(s.B, s.Ef / 32), dim3(256), sm_c, st, k);
     T2_CHECK_LAUNCH();
     return T2_OK;
@@ -484,7 +490,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dw_kernel(AttnBwdK p) {
     if (sub == 0 && l < L) p.de[(long)b * L + l] = wme * (acc + dwx_s[l] - sigma);
 }
 
-__global__ __launch_bounds__(256, 1) void attn_bwd_ds_kernel(AttnBwdK p) {
+__global__ __launch_bounds__(ENT, 2) void attn_bwd_ds_kernel(AttnBwdK p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
     const int L = p.L, NG = (L + 3) >> 2, Lp = 4 * NG + 36, L4 = 4 * NG;
@@ -494,11 +500,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_ds_kernel(AttnBwdK p) {
     float* Us = tvs + 16 * L4;     // [16][64]
     float* des = Us + 16 * 64;     // [L4]
     const int items = 16 * NG;
-    // issue the tanh-stash reads of the first round before the LDS staging
-    float thv[MAXI][4], vv[MAXI];
+    // ---- issue: tanh stash of the first round, de, location inputs, filter rows ----
+    float thv[EMAXI][4], vv[EMAXI];
 #pragma unroll
-    for (int it = 0; it < MAXI; ++it) {
-        const int item = imin(tid + 256 * it, items - 1);
+    for (int it = 0; it < EMAXI; ++it) {
+        const int item = imin(tid + ENT * it, items - 1);
         const int al = item / NG, lg = item - al * NG;
         const int a = j * 16 + al;
         vv[it] = p.v[a];
@@ -506,24 +512,24 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_ds_kernel(AttnBwdK p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) thv[it][i] = tr[imin(4 * lg + i, L - 1)];
     }
-    float dev[4];   // de for up to 1024 positions per pass
+    float dev[2];   // de for up to 1024 positions
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dev[i] = p.de[(long)b * L + imin(tid + 256 * i, L - 1)];
-    stage_inp_U(inp, Us, p.w_prev, p.ldwp, p.cum_prev, p.ldcp, p.U, p.th, b, j, L, Lp, tid);
-    for (int idx = tid; idx < 16 * Lp; idx += 256) dsp[idx] = 0.f;
+    for (int i = 0; i < 2; ++i) dev[i] = p.de[(long)b * L + imin(tid + ENT * i, L - 1)];
+    stage_inp_U<ENT>(inp, Us, p.w_prev, p.ldwp, p.cum_prev, p.ldcp, p.U, p.th, b, j, L, Lp, tid);
+    for (int idx = tid; idx < 16 * Lp; idx += ENT) dsp[idx] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int l = tid + 256 * i;
+    for (int i = 0; i < 2; ++i) {
+        const int l = tid + ENT * i;
         if (l < L4) des[l] = l < L ? dev[i] : 0.f;
     }
-    for (int l = tid + 1024; l < L4; l += 256) des[l] = l < L ? p.de[(long)b * L + l] : 0.f;
+    for (int l = tid + 1024; l < L4; l += ENT) des[l] = l < L ? p.de[(long)b * L + l] : 0.f;
     __syncthreads();
 
     // phase A: ds, dpmT accumulation
-    for (int base = 0; base < items; base += 256 * MAXI) {
+    for (int base = 0; base < items; base += ENT * EMAXI) {
 #pragma unroll
-        for (int it = 0; it < MAXI; ++it) {
-            const int item = base + tid + 256 * it;
+        for (int it = 0; it < EMAXI; ++it) {
+            const int item = base + tid + ENT * it;
             if (item >= items) continue;
             const int al = item / NG, lg = item - al * NG;
             const int a = j * 16 + al;
@@ -550,12 +556,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_ds_kernel(AttnBwdK p) {
     }
     __syncthreads();
 
-    {   // phase B: dq[a], dv[a]: 16 lanes per attention dim
-        const int al = tid >> 4, sub = tid & 15;
+    {   // phase B: dq[a], dv[a]: 32 lanes per attention dim
+        const int al = tid >> 5, sub = tid & 31;
         float sq = 0.f, sv = 0.f;
-        for (int l = sub; l < L; l += 16) { sq += dsp[al * Lp + KPAD + l]; sv += tvs[al * L4 + l]; }
+        for (int l = sub; l < L; l += 32) { sq += dsp[al * Lp + KPAD + l]; sv += tvs[al * L4 + l]; }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { sq += __shfl_xor(sq, o, 64); sv += __shfl_xor(sv, o, 64); }
+        for (int o = 16; o > 0; o >>= 1) { sq += __shfl_xor(sq, o, 64); sv += __shfl_xor(sv, o, 64); }
         if (sub == 0) {
             const int a = j * 16 + al;
             p.dq[(long)b * p.lddq + a] = sq;
@@ -563,35 +569,33 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_ds_kernel(AttnBwdK p) {
         }
     }
 
-    {   // phase C: dU partial; thread = (dim al, channel c, tap group kg of 4)
-        const int al = tid >> 4, c = (tid >> 3) & 1, kg = tid & 7, k0 = 4 * kg;
-        float out[4] = {0.f, 0.f, 0.f, 0.f};
+    {   // phase C: dU partial; thread = (dim al, channel c, tap pair kg): taps k0 = 2*kg, 2*kg + 1
+        const int al = tid >> 5, c = (tid >> 4) & 1, kg = tid & 15, k0 = 2 * kg;
+        float out[2] = {0.f, 0.f};
         const float* dsr = dsp + al * Lp + KPAD;
         const float* inr = inp + c * Lp + k0;
         for (int l = 0; l < L4; l += 4) {
-            float d4[4], wv[8];
+            float d4[4], wv[5];
 #pragma unroll
             for (int i = 0; i < 4; ++i) d4[i] = dsr[l + i];
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(inr + l);
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(inr + l + 4);
-            wv[0] = w0[0]; wv[1] = w0[1]; wv[2] = w0[2]; wv[3] = w0[3];
-            wv[4] = w1[0]; wv[5] = w1[1]; wv[6] = w1[2]; wv[7] = w1[3];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 5; ++i) wv[i] = inr[l + i];
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) out[kk] = fmaf(d4[i], wv[i + kk], out[kk]);
+            for (int i = 0; i < 4; ++i) {
+                out[0] = fmaf(d4[i], wv[i], out[0]);
+                out[1] = fmaf(d4[i], wv[i + 1], out[1]);
+            }
         }
         float* dst = p.dU_part + (((long)b * p.Ad + j * 16 + al) * 2 + c) * KL + k0;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-            if (k0 + kk < KL) dst[kk] += out[kk];
+        if (k0 < KL) dst[0] += out[0];
+        if (k0 + 1 < KL) dst[1] += out[1];
     }
     __syncthreads();   // tvs is reused below
 
     // phase D: d_in partials; item = ((aq*2 + c)*NG + lg), 4 dims per item
     float* dinq = tvs;   // [4][2][L4]
     const int items_d = 8 * NG;
-    for (int item = tid; item < items_d; item += 256) {
+    for (int item = tid; item < items_d; item += ENT) {
         const int lg = item % NG, ac = item / NG, c = ac & 1, aq = ac >> 1;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
@@ -616,11 +620,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_ds_kernel(AttnBwdK p) {
         for (int i = 0; i < 4; ++i) dinq[(aq * 2 + c) * L4 + 4 * lg + i] = acc[i];
     }
     __syncthreads();
-    for (int idx = tid; idx < 2 * L; idx += 256) {
+    for (int idx = tid; idx < 2 * L; idx += ENT) {
         const int c = idx >= L ? 1 : 0, l = idx - c * L;
-        const float s = dinq[(0 * 2 + c) * L4 + l] + dinq[(1 * 2 + c) * L4 + l] + dinq[(2 * 2 + c) * L4 + l] +
-                        dinq[(3 * 2 + c) * L4 + l];
-        p.din_part_out[(((long)b * gridDim.y + j) * 2 + c) * L + l] = s;
+        const float s2 = dinq[(0 * 2 + c) * L4 + l] + dinq[(1 * 2 + c) * L4 + l] + dinq[(2 * 2 + c) * L4 + l] +
+                         dinq[(3 * 2 + c) * L4 + l];
+        p.din_part_out[(((long)b * gridDim.y + j) * 2 + c) * L + l] = s2;
     }
 }
 
@@ -672,7 +676,7 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         k.dpmT = a->dpmT; k.dq = Z + (long)(t + 1) * B * ldz + 4 * A; k.lddq = ldz;
         k.dv_part = a->dv_part; k.dU_part = a->dU_part; k.din_part_out = a->din_part;
         hipLaunchKernelGGL(attn_bwd_dw_kernel, dim3(B, t2_cdiv(L, 32)), dim3(256), sm_dw, st, k);
-        hipLaunchKernelGGL(attn_bwd_ds_kernel, dim3(B, NA), dim3(256), sm_ds, st, k);
+        hipLaunchKernelGGL(attn_bwd_ds_kernel, dim3(B, NA), dim3(ENT), sm_ds, st, k);
         // (4) attention-LSTM cell backward: dh = dh_ext + [dgates_{t+1} | dq_t] . [W_hh ; Wq]
         T2LstmBwdStep c;
         memset(&c, 0, sizeof(c));

@@ -45,7 +45,10 @@ static inline bool t2_aligned16(const void* p) { return (((uintptr_t)p) & 15) ==
 // ------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float t2_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// sigmoid / tanh on the hardware exp + rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each).  Absolute error ~1e-7, far
+// inside the fp32 parity budget, and ~6x fewer instructions than the branchy libm tanhf.
+__device__ __forceinline__ float t2_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float t2_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
 
 __device__ __forceinline__ float t2_wave_sum(float v) {
 #pragma unroll

@@ -140,7 +140,7 @@ __global__ void bn_apply_kernel(BnK p) {
             const float xv = p.x[((long)b * p.Lp_x + l) * p.C + c];
             v = (xv - p.mean[c]) * p.invstd[c] * p.gamma[c] + p.beta[c];
             if (p.act == 1) v = fmaxf(v, 0.f);
-            else if (p.act == 2) v = tanhf(v);
+            else if (p.act == 2) v = t2_tanh(v);
             if (p.drop) v *= p.drop[((long)b * p.L + l) * p.C + c];
             if (p.res) v += p.res[((long)b * p.Lp_res + p.pad_res + l) * p.C + c];
             if (p.len && l >= p.len[b]) v = p.fill;
@@ -157,7 +157,7 @@ __device__ __forceinline__ float bn_dz(const BnK& p, int b, int l, int c, float&
     if (p.drop) g *= p.drop[((long)b * p.L + l) * p.C + c];
     const float pre = xhat * p.gamma[c] + p.beta[c];
     if (p.act == 1) g = pre > 0.f ? g : 0.f;
-    else if (p.act == 2) { const float t = tanhf(pre); g *= (1.f - t * t); }
+    else if (p.act == 2) { const float t = t2_tanh(pre); g *= (1.f - t * t); }
     return g;
 }
 
@@ -356,7 +356,7 @@ __global__ void condition_fwd_kernel(const float* enc, const float* spk_table, c
         float v;
         if (e < E) {
             v = enc[row * E + e];
-            if (spk_table) v = tanhf(v + spk_table[(long)spk[b] * E + e]);
+            if (spk_table) v = t2_tanh(v + spk_table[(long)spk[b] * E + e]);
         } else {
             v = desc[(long)b * (Ef - E) + (e - E)];
         }
@@ -388,7 +388,7 @@ __global__ void condition_bwd_kernel(const float* dmem, const float* memory, con
 __global__ void tanh_bias_kernel(float* x, const float* bias, long rows, int C) {
     const long n = rows * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        x[i] = tanhf(x[i] + (bias ? bias[i % C] : 0.f));
+        x[i] = t2_tanh(x[i] + (bias ? bias[i % C] : 0.f));
 }
 __global__ void tanh_bwd_kernel(const float* g, const float* y, float* out, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)

@@ -51,27 +51,6 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmK2 pp) {
     f32x4 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // Epilogue operands (hoisted: issued now, consumed after the GEMM, so they never add a memory round trip)
-    const int eb = tid >> 2, euu = tid & 3, eu = u0 + euu;
-    const long ebc = eb < p.B ? eb : p.B - 1;
-    float e_pre[4] = {0.f, 0.f, 0.f, 0.f}, e_b1[4] = {0.f, 0.f, 0.f, 0.f}, e_b2[4] = {0.f, 0.f, 0.f, 0.f};
-    float e_cp = 0.f, e_drop = 1.f;
-    int e_len = 0x7fffffff;
-    if (p.pre) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) e_pre[g] = p.pre[ebc * p.ldpre + g * H + eu];
-    }
-    if (p.bias1) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) e_b1[g] = p.bias1[g * H + eu];
-    }
-    if (p.bias2) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) e_b2[g] = p.bias2[g * H + eu];
-    }
-    if (p.c_prev) e_cp = p.c_prev[ebc * p.ldc_prev + eu];
-    if (p.drop) e_drop = p.drop[ebc * p.lddrop + eu];
-    if (p.len) e_len = p.len[ebc];
 
     // Flattened 16-deep chunk list over the input segments; wave w owns chunks w, w+4, ...
     const int cb1 = p.nseg > 0 ? (p.seg[0].K >> 4) : 0;
@@ -157,10 +136,10 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmK2 pp) {
                 gsum[g] = s;
             }
             const bool active = (p.len == nullptr) || (p.t < p.len[b]);
-            float gi = t2_sigmoid(gsum[0]), gf = t2_sigmoid(gsum[1]), gg = tanhf(gsum[2]), go = t2_sigmoid(gsum[3]);
+            float gi = t2_sigmoid(gsum[0]), gf = t2_sigmoid(gsum[1]), gg = t2_tanh(gsum[2]), go = t2_sigmoid(gsum[3]);
             const float cp = p.c_prev ? p.c_prev[(long)b * p.ldc_prev + u] : 0.f;
             float cn = gf * cp + gi * gg;
-            float hn = go * tanhf(cn);
+            float hn = go * t2_tanh(cn);
             if (p.drop) hn *= p.drop[(long)b * p.lddrop + u];
             if (!active) { hn = 0.f; cn = 0.f; gi = gf = gg = go = 0.f; }
             p.h_out[(long)b * p.ldh + u] = hn;
@@ -180,7 +159,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmK2 pp) {
 // all-zero padding chunks of the weight stream with (clamped, finite) activations, so no guard, select or wait sits
 // between a load and the next load: two groups (2 x 12 x 1 KB per wave) are in flight while one is in the MFMAs.
 // ---------------------------------------------------------------------------------------------------------
-template <int MT>
+template <int MT, int U>
 __global__ __launch_bounds__(256, 1) void lstm_step_fwd_fast_kernel(LstmK2 pp) {
     const LstmK& p = pp.s[blockIdx.y];
     __shared__ float red[4 * MT * 256];
@@ -189,7 +168,7 @@ __global__ __launch_bounds__(256, 1) void lstm_step_fwd_fast_kernel(LstmK2 pp) {
     const int r = lane & 15, q = lane >> 4;
     const int u0 = blockIdx.x * 4;
     const int H = p.H;
-    const int NT = p.seg[0].K >> 4, NTpad = (NT + 15) & ~15, G = NTpad >> 4;
+    const int NT = p.seg[0].K >> 4, NTpad = (NT + 15) & ~15, G = NTpad / (4 * U);   // host guarantees NTpad % (4U) == 0
     const float* wb = p.wpacked + (long)blockIdx.x * NTpad * 256 + lane * 4;
     const float* xb[MT];
 #pragma unroll
@@ -221,11 +200,10 @@ __global__ __launch_bounds__(256, 1) void lstm_step_fwd_fast_kernel(LstmK2 pp) {
     if (p.c_prev) e_cp = p.c_prev[ebc * p.ldc_prev + eu];
     if (p.drop) e_drop = p.drop[ebc * p.lddrop + eu];
     if (p.len) e_len = p.len[ebc];
-    constexpr int U = 4;
     auto load_group = [&](int g, f32x4 (&bw)[U], f32x4 (&ax)[U][MT]) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const int c = 16 * g + 4 * j + w;
+            const int c = 4 * U * g + 4 * j + w;
             const int cx = c < NT ? c : NT - 1;     // padding chunks: any finite activations x the zero weight chunk
             bw[j] = *reinterpret_cast<const f32x4*>(wb + (long)c * 256);
 #pragma unroll
@@ -287,9 +265,9 @@ __global__ __launch_bounds__(256, 1) void lstm_step_fwd_fast_kernel(LstmK2 pp) {
                 gsum[g] = s + e_pre[g] + e_b1[g] + e_b2[g];
             }
             const bool active = p.t < e_len;
-            float gi = t2_sigmoid(gsum[0]), gf = t2_sigmoid(gsum[1]), gg = tanhf(gsum[2]), go = t2_sigmoid(gsum[3]);
+            float gi = t2_sigmoid(gsum[0]), gf = t2_sigmoid(gsum[1]), gg = t2_tanh(gsum[2]), go = t2_sigmoid(gsum[3]);
             float cn = gf * e_cp + gi * gg;
-            float hn = go * tanhf(cn) * e_drop;
+            float hn = go * t2_tanh(cn) * e_drop;
             if (!active) { hn = 0.f; cn = 0.f; gi = gf = gg = go = 0.f; }
             p.h_out[(long)b * p.ldh + u] = hn;
             if (p.h_out2) p.h_out2[(long)b * p.ldh2 + u] = hn;
@@ -347,9 +325,14 @@ int launch_fwd(const T2LstmStep* steps, int n, hipStream_t st) {
         bool fast = true;
         for (int i = 0; i < n; ++i) fast = fast && steps[i].wpacked && steps[i].nseg == 1;
         if (fast) {
-            if (bn <= 16) hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<1>), grid, block, 0, st, kk);
-            else if (bn <= 32) hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<2>), grid, block, 0, st, kk);
-            else hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<4>), grid, block, 0, st, kk);
+            // 8 chunks per group (24 x 1 KB loads per wave per group, two groups in flight) when the padded chunk count allows
+            const int ntpad = ((steps[0].seg[0].K >> 4) + 15) & ~15;
+            const bool u8 = (ntpad % 32 == 0) && (n == 1 || ((((steps[1].seg[0].K >> 4) + 15) & ~15) % 32 == 0));
+            if (bn <= 16) { if (u8) hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<1, 8>), grid, block, 0, st, kk);
+                            else hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<1, 4>), grid, block, 0, st, kk); }
+            else if (bn <= 32) { if (u8) hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<2, 8>), grid, block, 0, st, kk);
+                                 else hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<2, 4>), grid, block, 0, st, kk); }
+            else hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<4, 4>), grid, block, 0, st, kk);
         } else {
             if (bn <= 16) hipLaunchKernelGGL((lstm_step_fwd_kernel<1>), grid, block, 0, st, kk);
             else if (bn <= 32) hipLaunchKernelGGL((lstm_step_fwd_kernel<2>), grid, block, 0, st, kk);
@@ -402,7 +385,7 @@ __device__ __forceinline__ void bwd_epilogue(const BwdK& p, const float* red, in
                 const float* gs = p.gates + (long)b * p.ldgs + u;
                 const float gi = gs[0], gf = gs[H], gg = gs[2 * H], go = gs[3 * H];
                 const float cp = p.c_prev ? p.c_prev[(long)b * p.ldcp + u] : 0.f;
-                const float tc = tanhf(p.c_cur[(long)b * p.ldcc + u]);
+                const float tc = t2_tanh(p.c_cur[(long)b * p.ldcc + u]);
                 float dcv = p.dc[(long)b * p.lddc + u] + dh * go * (1.f - tc * tc);
                 float d_o = dh * tc * go * (1.f - go);
                 float d_i = dcv * gg * gi * (1.f - gi);
@@ -449,7 +432,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(BwdK2 pp) {
                     const float* ap = (s2 ? p.dg2 + arow * p.lddg2 : p.dg_next + arow * p.lddg) + 16 * lc + 4 * q;
                     a[j] = *reinterpret_cast<const f32x4*>(ap);
                     if (p.wtpacked) {   // packed stream is laid out over BOTH segments even when dg_next is absent
-                        const int pk1 = p.N4 >> 4, pkn = (pk1 + (p.N2 >> 4) + 15) & ~15;
+                        const int pk1 = p.N4 >> 4, pkn = (pk1 + (p.N2 >> 4) + 31) & ~31;
                         b[j] = *reinterpret_cast<const f32x4*>(p.wtpacked + (((long)blockIdx.x * pkn + (s2 ? pk1 + lc : lc)) * 64 + lane) * 4);
                     } else {
                         const long ldw = s2 ? p.ldw2 : p.ldw;
@@ -531,7 +514,7 @@ __device__ __forceinline__ void bwd_epi_apply(const BwdK& p, const BwdEpi& e, co
             const int H = p.H;
             const bool active = p.t < e.len;
             const float dh = dx * e.drop;
-            const float tc = tanhf(e.cc);
+            const float tc = t2_tanh(e.cc);
             const float dcv = e.dc + dh * e.go * (1.f - tc * tc);
             float d_o = dh * tc * e.go * (1.f - e.go);
             float d_i = dcv * e.gg * e.gi * (1.f - e.gi);
@@ -557,16 +540,16 @@ __global__ __launch_bounds__(256, 1) void lstm_step_bwd_fast_kernel(BwdK2 pp) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
     const int u0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
-    const int NCH = (p.N4 + p.N2) >> 4, NCHpad = (NCH + 15) & ~15, G = NCHpad >> 4;
+    const int NCH = (p.N4 + p.N2) >> 4, NCHpad = (NCH + 31) & ~31, G = NCHpad >> 5;
     const float* wb = p.wtpacked + (long)blockIdx.x * NCHpad * 256 + lane * 4;
     const float* ab = p.dg_next + (long)((b0 + r) < p.B ? (b0 + r) : 0) * p.lddg + 4 * q;
     const BwdEpi epi = bwd_epi_load(p, tid, u0, b0);   // hoisted: in flight during the GEMM
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    constexpr int U = 4;
+    constexpr int U = 8;
     auto load_group = [&](int g, f32x4 (&a)[U], f32x4 (&b)[U]) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const int c = 16 * g + 4 * j + w;
+            const int c = 32 * g + 4 * j + w;
             const int cx = c < NCH ? c : NCH - 1;   // padding chunks: finite gradients x the zero weight chunk
             b[j] = *reinterpret_cast<const f32x4*>(wb + (long)c * 256);
             a[j] = *reinterpret_cast<const f32x4*>(ab + 16 * cx);
@@ -677,7 +660,7 @@ __global__ void lstm_pack_fwd_kernel(PackSegs s, int H, int NT, float* out) {
 // out[((ut*NCH + c)*64 + lane)*4 + s] = Wx[(16*lc + 4q + s)*ldwx + 16*ut + j],  lane = q*16 + j  (0 past ncols)
 __global__ void lstm_pack_bwd_kernel(const float* W, long ldw, int N4, const float* W2, long ldw2, int N2, int ncols,
                                      float* out) {
-    const int nch1 = N4 >> 4, nch = nch1 + (W2 ? (N2 >> 4) : 0), nchpad = (nch + 15) & ~15;
+    const int nch1 = N4 >> 4, nch = nch1 + (W2 ? (N2 >> 4) : 0), nchpad = (nch + 31) & ~31;
     const int tiles = (ncols + 15) / 16;
     const long total = (long)tiles * nchpad * 64;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -771,7 +754,7 @@ extern "C" int t2_lstm_pack_fwd(const T2Seg* segs, int nseg, int H, float* out, 
 extern "C" int t2_lstm_pack_bwd(const float* W, int64_t ldw, int N4, const float* W2, int64_t ldw2, int N2, int ncols,
                                 float* out, void* stream) {
     T2_REQUIRE(W && out && N4 % 16 == 0 && (!W2 || N2 % 16 == 0) && ncols >= 1, "t2_lstm_pack_bwd: bad arguments");
-    const long total = (long)t2_cdiv(ncols, 16) * ((((N4 >> 4) + (W2 ? (N2 >> 4) : 0)) + 15) & ~15) * 64;
+    const long total = (long)t2_cdiv(ncols, 16) * ((((N4 >> 4) + (W2 ? (N2 >> 4) : 0)) + 31) & ~31) * 64;
     hipLaunchKernelGGL(lstm_pack_bwd_kernel, dim3(t2_cdiv(total, 256) > 2048 ? 2048 : t2_cdiv(total, 256)), dim3(256), 0,
                        (hipStream_t)stream, W, (long)ldw, N4, W2, (long)ldw2, N2, ncols, out);
     T2_CHECK_LAUNCH();

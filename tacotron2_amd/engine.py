@@ -129,7 +129,7 @@ class Engine:
 
     def pack_bwd(self, name, W, ldw, N4, ncols, W2=None, ldw2=0, N2=0):
         tiles = (ncols + 15) // 16
-        nchpad = ((N4 + N2) // 16 + 15) // 16 * 16
+        nchpad = ((N4 + N2) // 16 + 31) // 32 * 32
         out = self.buf("pack." + name, tiles * nchpad * 256)
         call("t2_lstm_pack_bwd", W, ldw, N4, W2, ldw2, N2, ncols, out, _stream())
         return out
