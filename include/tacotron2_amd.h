@@ -243,9 +243,12 @@ int t2_bn_bwd(const T2Bn* s, void* stream);
 int t2_colsum(const float* x, int64_t ld, int64_t R, int C, float* out, void* stream);          /* out[c] += sum_r x[r][c] */
 int t2_mel_to_tm(const float* mel, float* out, int B, int T, int M, void* stream);              /* (B,T,M) -> [T+1][B][M], slot 0 = 0 */
 int t2_swap01(const float* in, float* out, int D0, int D1, int C, int accumulate, void* stream); /* (D0,D1,C) -> (D1,D0,C) */
-int t2_finalize_fwd(const float* proj, const int32_t* len, float* mels, float* gates, float* post_in, int B, int T, int M,
-                    void* stream);
+int t2_finalize_fwd(const float* proj, int64_t ld_proj, const int32_t* len, float* mels, float* gates, float* post_in, int B,
+                    int T, int M, void* stream);
 int t2_finalize_bwd(const float* dpost_in, float* dproj, int B, int T, int M, void* stream);
+/* upstream gradients of (mels, mels_post, gates) (any may be NULL) -> d_post_out (B,T,M) and dproj [T][B][M+1], masked */
+int t2_outgrad_pack(const float* d_mels, const float* d_post, const float* d_gates, const int32_t* len, float* d_post_out,
+                    float* dproj, int B, int T, int M, void* stream);
 int t2_loss_fwd_bwd(const float* mels, const float* post, const float* gates, const float* mel_tgt, const float* gate_tgt,
                     const int32_t* len, int B, int T, int M, double* loss3 /* gate, mel, post */, float* d_post, float* dproj,
                     float grad_scale, void* stream);
@@ -256,6 +259,32 @@ int t2_condition_bwd(const float* dmem, const float* memory, const int32_t* spk,
                      int B, int L, int E, int Ef, void* stream);
 int t2_tanh_bias(float* x, const float* bias, int64_t rows, int C, void* stream);
 int t2_tanh_bwd(const float* g, const float* y, float* out, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Autoregressive decoding: forward(teacher_forcing=False, max_len_override=N) of model/tacotron2.py:262-325.
+ *   t2_linear_rows  out[b][n] = act(x[b][:] . w[n][:] + bias[n]) * mask[b][n]   (nn.Linear on <= batch rows; K % 16 == 0)
+ *   t2_decoder_infer runs frames [t0, t1) with no host synchronisation: state[0] = all-done flag, state[1] = number of
+ *   emitted frames, done [B] int32, lengths [B] int64 (counts every frame whose stop logit is >= 0, Appendix C.4).
+ * Buffers: xatt [2][B][A+Ef+P] rows [att_h | ctx | prenet_out]; xdec [2][B][A+Ef+D] rows [att_h | ctx | dec_h];
+ * att_c [2][B][A], dec_c [2][B][D], cum [2][B][L] (ping-pong, slot 0 zero-filled by the caller); xproj [B][D+Ef];
+ * proj [Tcap][B][ld_proj] (cols 0..M-1 mel, col M stop logit; ld_proj % 4 == 0); align [B][Tcap][L];
+ * prenet_mask [Tcap][2][B][P] or NULL; wp_att / wp_dec = t2_lstm_pack_fwd streams in the row order above. */
+int t2_linear_rows(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* mask,
+                   int64_t ldmask, int relu, float* out, int64_t ldo, int B, int N, int K, void* stream);
+typedef struct {
+    int B, L, A, D, Ef, Ad, P, M, Kl, Tcap;
+    const float* W_pre1; const float* W_pre2;
+    const float* wp_att; const float* b_att_ih; const float* b_att_hh;
+    const float* wp_dec; const float* b_dec_ih; const float* b_dec_hh;
+    const float* Wq; const float* U; const float* v;
+    const float* W_proj; const float* b_proj;
+    const float* pmT; const float* memory; const int32_t* len;
+    const float* prenet_mask; const float* zero_frame;
+    float* xatt; float* xdec; float* att_c; float* dec_c; float* cum; float* xproj; float* p1; float* e_part;
+    float* proj; int64_t ld_proj; float* align;
+    int32_t* done; int64_t* lengths; int32_t* state;
+} T2Infer;
+int t2_decoder_infer(const T2Infer* a, int t0, int t1, void* stream);
 
 /* dropout scale masks (Philox4x32-10, counter = element index) and the optimizer of model/tts_model.py:78-91 +
  * Lightning gradient_clip_val=1.0 (run/train.py:240) on one flat fp32 parameter buffer. */

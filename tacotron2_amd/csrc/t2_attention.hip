@@ -38,7 +38,6 @@ struct AttnK {
 // Load discipline for these one-workgroup-per-CU kernels: every global load of a phase is ISSUED (unconditionally, from a
 // clamped in-range address) before anything waits on one; out-of-range lanes are zeroed by a select afterwards.  A
 // `load -> wait -> use` loop with a run-time trip count costs one full memory round trip (~1 us) per iteration.
-constexpr int MAXI = 3;   // work items (4 positions each) per thread per round: one round covers L <= 192
 
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
@@ -501,7 +500,7 @@ __global__ __launch_bounds__(ENT, 2) void attn_bwd_ds_kernel(AttnBwdK p) {
     float* des = Us + 16 * 64;     // [L4]
     const int items = 16 * NG;
     // ---- issue: tanh stash of the first round, de, location inputs, filter rows ----
-    float thv[EMAXI][4], vv[EMAXI];
+    float thv[EMAXI][4], dpv[EMAXI][4], vv[EMAXI];
 #pragma unroll
     for (int it = 0; it < EMAXI; ++it) {
         const int item = imin(tid + ENT * it, items - 1);
@@ -509,9 +508,15 @@ __global__ __launch_bounds__(ENT, 2) void attn_bwd_ds_kernel(AttnBwdK p) {
         const int a = j * 16 + al;
         vv[it] = p.v[a];
         const float* tr = p.th + ((long)b * p.Ad + a) * L;
+        const float* dr = p.dpmT + ((long)b * p.Ad + a) * L;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) thv[it][i] = tr[imin(4 * lg + i, L - 1)];
+        for (int i = 0; i < 4; ++i) { thv[it][i] = tr[imin(4 * lg + i, L - 1)]; dpv[it][i] = dr[imin(4 * lg + i, L - 1)]; }
     }
+    // old values of the per-sample accumulators this thread updates (read-modify-write without a dependent round trip)
+    const int c_al = tid >> 5, c_c = (tid >> 4) & 1, c_k0 = 2 * (tid & 15);
+    float* dU_dst = p.dU_part + (((long)b * p.Ad + j * 16 + c_al) * 2 + c_c) * KL + imin(c_k0, KL - 2);
+    const float dU_old0 = dU_dst[0], dU_old1 = dU_dst[1];
+    const float dv_old = p.dv_part[(long)b * p.Ad + j * 16 + c_al];
     float dev[2];   // de for up to 1024 positions
 #pragma unroll
     for (int i = 0; i < 2; ++i) dev[i] = p.de[(long)b * L + imin(tid + ENT * i, L - 1)];
@@ -537,7 +542,10 @@ __global__ __launch_bounds__(ENT, 2) void attn_bwd_ds_kernel(AttnBwdK p) {
             if (base > 0) {
                 vv[it] = p.v[a];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) thv[it][i] = (4 * lg + i < L) ? p.th[rowoff + 4 * lg + i] : 0.f;
+                for (int i = 0; i < 4; ++i) {
+                    thv[it][i] = (4 * lg + i < L) ? p.th[rowoff + 4 * lg + i] : 0.f;
+                    dpv[it][i] = (4 * lg + i < L) ? p.dpmT[rowoff + 4 * lg + i] : 0.f;
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -547,7 +555,7 @@ __global__ __launch_bounds__(ENT, 2) void attn_bwd_ds_kernel(AttnBwdK p) {
                     const float th = thv[it][i];
                     d = des[l] * vv[it] * (1.f - th * th);
                     tv = des[l] * th;
-                    p.dpmT[rowoff + l] += d;
+                    p.dpmT[rowoff + l] = dpv[it][i] + d;
                 }
                 dsp[al * Lp + KPAD + l] = d;
                 tvs[al * L4 + l] = tv;
@@ -565,7 +573,7 @@ __global__ __launch_bounds__(ENT, 2) void attn_bwd_ds_kernel(AttnBwdK p) {
         if (sub == 0) {
             const int a = j * 16 + al;
             p.dq[(long)b * p.lddq + a] = sq;
-            p.dv_part[(long)b * p.Ad + a] += sv;
+            p.dv_part[(long)b * p.Ad + a] = dv_old + sv;
         }
     }
 
@@ -586,9 +594,9 @@ __global__ __launch_bounds__(ENT, 2) void attn_bwd_ds_kernel(AttnBwdK p) {
                 out[1] = fmaf(d4[i], wv[i + 1], out[1]);
             }
         }
-        float* dst = p.dU_part + (((long)b * p.Ad + j * 16 + al) * 2 + c) * KL + k0;
-        if (k0 < KL) dst[0] += out[0];
-        if (k0 + 1 < KL) dst[1] += out[1];
+        // (al, c, k0) == (c_al, c_c, c_k0): old values were fetched at kernel entry; k0 = 30 -> only tap 30 exists
+        if (k0 + 1 < KL) { dU_dst[0] = dU_old0 + out[0]; dU_dst[1] = dU_old1 + out[1]; }
+        else dU_dst[1] = dU_old1 + out[0];
     }
     __syncthreads();   // tvs is reused below
 

@@ -262,7 +262,7 @@ __global__ void swap01_kernel(const float* in, float* out, int D0, int D1, int C
 
 // proj [T][B][M+1] (time-major, col M = stop logit) -> mels (B,T,M) masked 0, gates (B,T,1) masked -1000,
 // postnet input (B,T+4,M) padded layout holding the UNMASKED mels (model/tacotron2.py:327-345)
-__global__ void finalize_fwd_kernel(const float* proj, const int32_t* len, float* mels, float* gates, float* post_in,
+__global__ void finalize_fwd_kernel(const float* proj, long ldp, const int32_t* len, float* mels, float* gates, float* post_in,
                                     int B, int T, int M) {
     const int Tp = T + 4, M1 = M + 1;
     const long n = (long)B * Tp * M1;
@@ -272,7 +272,7 @@ __global__ void finalize_fwd_kernel(const float* proj, const int32_t* len, float
         const int tp = (int)(row % Tp), b = (int)(row / Tp);
         const int t = tp - 2;
         const bool in = t >= 0 && t < T;
-        const float v = in ? proj[((long)t * B + b) * M1 + m] : 0.f;
+        const float v = in ? proj[((long)t * B + b) * ldp + m] : 0.f;
         if (m < M) {
             if (post_in) post_in[((long)b * Tp + tp) * M + m] = v;
             if (in) mels[((long)b * T + t) * M + m] = (t >= len[b]) ? 0.f : v;
@@ -323,6 +323,28 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* mels, const floa
     if (threadIdx.x < 3) {
         const double s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
         atomicAdd(&loss3[threadIdx.x], s / (threadIdx.x == 0 ? (double)ng : (double)nm));
+    }
+}
+
+// Arbitrary upstream gradients (autograd path) -> the two tensors backward_tf consumes.  Masked positions are constants
+// (masked_fill, model/tacotron2.py:343-345) so their gradient is dropped.
+__global__ void outgrad_pack_kernel(const float* d_mels, const float* d_post, const float* d_gates, const int32_t* len,
+                                    float* d_post_out, float* dproj, int B, int T, int M) {
+    const long n = (long)B * T * (M + 1);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i % (M + 1));
+        const long row = i / (M + 1);
+        const int t = (int)(row % T), b = (int)(row / T);
+        const bool masked = t >= len[b];
+        if (m < M) {
+            const long j = row * M + m;
+            const float g1 = (masked || !d_mels) ? 0.f : d_mels[j];
+            const float g2 = (masked || !d_post) ? 0.f : d_post[j];
+            d_post_out[j] = g2;
+            dproj[((long)t * B + b) * (M + 1) + m] = g1 + g2;
+        } else {
+            dproj[((long)t * B + b) * (M + 1) + M] = (masked || !d_gates) ? 0.f : d_gates[row];
+        }
     }
 }
 
@@ -517,10 +539,10 @@ extern "C" int t2_swap01(const float* in, float* out, int D0, int D1, int C, int
     hipLaunchKernelGGL(swap01_kernel, dim3(ew_grid((long)D0 * D1 * C)), dim3(256), 0, ST, in, out, D0, D1, C, accumulate);
     T2_CHECK_LAUNCH(); return T2_OK;
 }
-extern "C" int t2_finalize_fwd(const float* proj, const int32_t* len, float* mels, float* gates, float* post_in, int B, int T,
-                               int M, void* stream) {
+extern "C" int t2_finalize_fwd(const float* proj, int64_t ld_proj, const int32_t* len, float* mels, float* gates, float* post_in,
+                               int B, int T, int M, void* stream) {
     T2_REQUIRE(proj && len && mels && gates, "t2_finalize_fwd: null");
-    hipLaunchKernelGGL(finalize_fwd_kernel, dim3(ew_grid((long)B * (T + 4) * (M + 1))), dim3(256), 0, ST, proj, len, mels, gates,
+    hipLaunchKernelGGL(finalize_fwd_kernel, dim3(ew_grid((long)B * (T + 4) * (M + 1))), dim3(256), 0, ST, proj, (long)ld_proj, len, mels, gates,
                        post_in, B, T, M);
     T2_CHECK_LAUNCH(); return T2_OK;
 }
@@ -531,6 +553,13 @@ extern "C" int t2_loss_fwd_bwd(const float* mels, const float* post, const float
     (void)hipMemsetAsync(loss3, 0, 3 * sizeof(double), ST);
     hipLaunchKernelGGL(loss_kernel, dim3(ew_grid((long)B * T * (M + 1))), dim3(256), 0, ST, mels, post, gates, mel_tgt, gate_tgt,
                        len, B, T, M, loss3, d_post, dproj, grad_scale);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
+extern "C" int t2_outgrad_pack(const float* d_mels, const float* d_post, const float* d_gates, const int32_t* len,
+                               float* d_post_out, float* dproj, int B, int T, int M, void* stream) {
+    T2_REQUIRE(len && d_post_out && dproj, "t2_outgrad_pack: null");
+    hipLaunchKernelGGL(outgrad_pack_kernel, dim3(ew_grid((long)B * T * (M + 1))), dim3(256), 0, ST, d_mels, d_post, d_gates, len,
+                       d_post_out, dproj, B, T, M);
     T2_CHECK_LAUNCH(); return T2_OK;
 }
 extern "C" int t2_finalize_bwd(const float* dpost_in, float* dproj, int B, int T, int M, void* stream) {

@@ -327,7 +327,7 @@ class Engine:
         mels = torch.empty(B, T, M, dtype=torch.float32, device=self.dev)
         gates = torch.empty(B, T, 1, dtype=torch.float32, device=self.dev)
         post_in = self.buf("post.x0", B, T + 4, M)
-        call("t2_finalize_fwd", proj, mlen32, mels, gates, post_in, B, T, M, st)
+        call("t2_finalize_fwd", proj, M + 1, mlen32, mels, gates, post_in, B, T, M, st)
 
         # postnet (model/postnet.py) + residual + output masks (model/tacotron2.py:331-345)
         Pn = d["postnet_dim"]
@@ -601,3 +601,112 @@ class Engine:
         call("t2_adam_step", ps.flat, ps.grad, ps.exp_avg, ps.exp_avg_sq, ps.numel, sumsq, float(max_norm), float(lr),
              float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step), float(grad_scale), _stream())
         return sumsq
+
+    # =============================================================================================
+    # autoregressive inference: forward(teacher_forcing=False, max_len_override=N)  (model/tacotron2.py:262-325)
+    # =============================================================================================
+    def infer(self, chars_idx, chars_len, max_len, speaker_id=None, description_embeddings=None, training=False,
+              prenet_masks=None, seed=0, check_every=32):
+        """Returns (mels, mels_post, gates, alignments) exactly as the reference's non-teacher-forced forward.
+        prenet_masks: optional [n][2][B][P] scale masks (parity tests); otherwise Philox masks (AlwaysDropout)."""
+        d, P, ps = self.d, self.ps.P, self.ps
+        B, L = chars_idx.shape
+        assert B <= 64, "engine.infer handles up to 64 utterances per call (callers split larger batches)"
+        M, E, Pd, A, D, Ad = d["num_mels"], d["encoded_dim"], d["prenet_dim"], d["att_rnn_dim"], d["rnn_hidden_dim"], d["att_dim"]
+        Ef = E + (128 if d.get("description_embeddings") else 0)
+        F = d.get("loc_filters", 32)
+        st = _stream()
+        ctx: dict = {}
+        len32 = chars_len.to(torch.int32)
+        enc = self.encoder_fwd(chars_idx, len32, training, {}, ctx)
+        memory = self.buf("memory", B, L, Ef)
+        desc = None
+        if d.get("description_embeddings"):
+            desc = self.buf("desc", B, 128)
+            Dd = d["description_embeddings_dim"]
+            gemm(description_embeddings, P["description_embeddings_linear.0.weight"], desc, B, 128, Dd, Dd, Dd, 128)
+            call("t2_tanh_bias", desc, P["description_embeddings_linear.0.bias"], B, 128, st)
+        spk32 = speaker_id.to(torch.int32) if d.get("speaker_tokens") else None
+        call("t2_condition_fwd", enc, P["speaker_embedding.weight"] if d.get("speaker_tokens") else None, spk32, desc,
+             memory, B, L, E, Ef, st)
+        pmT = self.buf("pmT", B, Ad, L)
+        gemm(P["att_encoder.weight"], memory, pmT, Ad, L, Ef, Ef, Ef, L, batch=B, sA=0, sB=L * Ef, sC=Ad * L)
+        U = self.buf("U", Ad, 2, KL)
+        call("t2_attn_fold_location", P["decoder.attention.location_dense.weight"],
+             P["decoder.attention.location_conv.weight"], U, Ad, F, KL, st)
+
+        Tcap = int(max_len)
+        lda, ldd, ldp = A + Ef + Pd, A + Ef + D, D + Ef
+        ldo = (M + 1 + 3) // 4 * 4
+        Wih_a, Wih_d = P["decoder.att_rnn.weight_ih"], P["decoder.lstm.weight_ih"]
+        wp_att = self.pack_fwd("inf.att", [(P["decoder.att_rnn.weight_hh"], A, A), (_ptr(Wih_a, Pd), Pd + Ef, Ef),
+                                           (Wih_a, Pd + Ef, Pd)], A)
+        wp_dec = self.pack_fwd("inf.dec", [(Wih_d, A + Ef, A), (_ptr(Wih_d, A), A + Ef, Ef),
+                                           (P["decoder.lstm.weight_hh"], D, D)], D)
+        xatt = self.buf("inf.xatt", 2, B, lda, zero=True)
+        xdec = self.buf("inf.xdec", 2, B, ldd, zero=True)
+        att_c = self.buf("inf.att_c", 2, B, A, zero=True)
+        dec_c = self.buf("inf.dec_c", 2, B, D, zero=True)
+        cum = self.buf("inf.cum", 2, B, L, zero=True)
+        xproj = self.buf("inf.xproj", B, ldp)
+        p1 = self.buf("inf.p1", B, Pd)
+        e_part = self.buf("e_part", B, Ad // 16, L)
+        proj = self.buf("inf.proj", Tcap, B, ldo)
+        align = torch.zeros(B, Tcap, L, dtype=torch.float32, device=self.dev)
+        zero_frame = self.buf("inf.zero", max(M, 64), zero=True)
+        done = self.buf("inf.done", B, dtype=torch.int32, zero=True)
+        lengths = self.buf("inf.lengths", B, dtype=torch.int64, zero=True)
+        state = self.buf("inf.state", 2, dtype=torch.int32, zero=True)
+        p = float(d["dropout"])
+        wproj = ps.cat_view("decoder.mel_out.weight", M + 1, ldp)
+        bproj = ps.cat_view("decoder.mel_out.bias", M + 1, 0)
+        t0 = 0
+        while t0 < Tcap:
+            t1 = min(Tcap, t0 + check_every)
+            if prenet_masks is not None:
+                pm = prenet_masks
+                pm_ptr = pm.data_ptr()
+                assert pm.shape[0] >= t1 or pm.shape[0] >= 1
+            elif p > 0.0:
+                pm = self.buf("inf.pmask", Tcap, 2, B, Pd)
+                n = (t1 - t0) * 2 * B * Pd
+                call("t2_philox_mask", _ptr(pm, t0 * 2 * B * Pd), n, p, seed, 1000 + t0, st)
+                pm_ptr = pm.data_ptr()
+            else:
+                pm, pm_ptr = None, None
+            if prenet_masks is not None:
+                t1 = min(t1, int(prenet_masks.shape[0]))   # only as many frames as masks were supplied
+            a = make("T2Infer", B=B, L=L, A=A, D=D, Ef=Ef, Ad=Ad, P=Pd, M=M, Kl=KL, Tcap=Tcap,
+                     W_pre1=P["prenet.0.weight"], W_pre2=P["prenet.3.weight"], wp_att=wp_att,
+                     b_att_ih=P["decoder.att_rnn.bias_ih"], b_att_hh=P["decoder.att_rnn.bias_hh"], wp_dec=wp_dec,
+                     b_dec_ih=P["decoder.lstm.bias_ih"], b_dec_hh=P["decoder.lstm.bias_hh"],
+                     Wq=P["decoder.attention.query_layer.weight"], U=U, v=P["decoder.attention.v.weight"],
+                     W_proj=wproj, b_proj=bproj, pmT=pmT, memory=memory, len=len32, prenet_mask=pm_ptr,
+                     zero_frame=zero_frame, xatt=xatt, xdec=xdec, att_c=att_c, dec_c=dec_c, cum=cum, xproj=xproj, p1=p1,
+                     e_part=e_part, proj=proj, ld_proj=ldo, align=align, done=done, lengths=lengths, state=state)
+            call("t2_decoder_infer", a, t0, t1, st)
+            t0 = t1
+            stt = state.cpu()            # the only host synchronisation: once per `check_every` frames
+            if int(stt[0]) or (prenet_masks is not None and t0 >= int(prenet_masks.shape[0])):
+                break
+        n = int(state.cpu()[1])
+        n = max(n, 1)
+        # outputs: mask by the counted lengths, postnet on the unmasked mels (model/tacotron2.py:327-345)
+        mlen32 = lengths.to(torch.int32)
+        mels = torch.empty(B, n, M, dtype=torch.float32, device=self.dev)
+        gates = torch.empty(B, n, 1, dtype=torch.float32, device=self.dev)
+        post_in = self.buf("post.x0", B, n + 4, M)
+        call("t2_finalize_fwd", proj, ldo, mlen32, mels, gates, post_in, B, n, M, st)
+        Pn = d["postnet_dim"]
+        chans = [M, Pn, Pn, Pn, Pn, M]
+        x = post_in
+        post = torch.empty(B, n, M, dtype=torch.float32, device=self.dev)
+        pctx: dict = {}
+        for li in range(5):
+            last = li == 4
+            x = self.conv_bn_fwd(f"post.conv{li}", x, P[f"postnet.postnet.{4 * li}.weight"], None,
+                                 f"postnet.postnet.{4 * li + 1}", B, n, chans[li], chans[li + 1], 0 if last else 2, None,
+                                 training, pctx, y=post if last else None, Lp_y=n if last else None,
+                                 pad_y=0 if last else 2, res=post_in if last else None, Lp_res=n + 4, pad_res=2,
+                                 length=mlen32 if last else None, fill=0.0)
+        return mels, post, gates, align[:, :n].contiguous(), lengths.clone()

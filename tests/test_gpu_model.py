@@ -220,3 +220,100 @@ def test_train_step_midsize_matches_oracle():
         assert worst < 2e-6, f"parameter drift after step {step}: {worst}"
         # keep both sides on the same trajectory for the next step (ill-conditioned elements excluded above)
         ps.load_state_dict({k: v.detach() for k, v in Pc.items()})
+
+
+# ------------------------------------------------------------------------------------------------------
+# autoregressive inference
+# ------------------------------------------------------------------------------------------------------
+def test_inference_matches_reference_golden():
+    """forward(teacher_forcing=False): device-side stop logic, the non-sticky length count and early break must match
+    the reference frame for frame (prenet dropout masks replayed from the fixture)."""
+    dev = _dev()
+    z = load_golden("infer")
+    d = R.default_dims(**SMALL, dropout=0.5)
+    eng, ps = build_engine(d, params_from(z), dev)
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    pm = t("m.prenet_drop").contiguous()            # [n][2][B][P]
+    mels, post, gates, al, lengths = eng.infer(t("chars_idx"), t("chars_len"), int(z["max_len"]), prenet_masks=pm,
+                                               check_every=4)
+    torch.cuda.synchronize()
+    assert mels.shape == z["o_mels"].shape, (mels.shape, z["o_mels"].shape)
+    assert l1(mels, z["o_mels"]) < MEL_L1_TOL and l1(post, z["o_post"]) < MEL_L1_TOL
+    assert mx(al, z["o_align"]) < 2e-5
+    assert ((gates.cpu() == -1000.0).numpy() == (z["o_gates"] == -1000.0)).all()
+
+
+def test_inference_midsize_matches_oracle():
+    dev = _dev()
+    d = R.default_dims(num_chars=39, encoded_dim=128, prenet_dim=64, att_rnn_dim=256, att_dim=64, rnn_hidden_dim=256,
+                       postnet_dim=128, num_mels=80, dropout=0.5, speaker_tokens=True, num_speakers=4)
+    P = R.init_params(d, seed=9)
+    P["decoder.gate.bias"] = P["decoder.gate.bias"] + 0.3      # make the stop logit cross zero at different frames
+    P["decoder.gate.weight"] = P["decoder.gate.weight"] * 6.0
+    g = torch.Generator().manual_seed(4)
+    B, L, N = 6, 29, 24
+    lens = torch.tensor([29, 21, 17, 25, 9, 13])
+    ci = torch.zeros(B, L, dtype=torch.int64)
+    for b in range(B):
+        ci[b, :lens[b]] = torch.randint(1, 40, (int(lens[b]),), generator=g)
+    spk = torch.randint(0, 4, (B,), generator=g, dtype=torch.int32)
+    pm = (torch.rand(N + 1, 2, B, 64, generator=g) >= 0.5).float() * 2
+    masks = dict(prenet_drop=[[pm[i, 0], pm[i, 1]] for i in range(N + 1)])
+    with torch.no_grad():
+        ref = R.tacotron2_fwd(P, d, ci, lens, False, speaker_id=spk, max_len_override=N, training=False, masks=masks)
+    eng, ps = build_engine(d, P, dev)
+    mels, post, gates, al, lengths = eng.infer(ci.to(dev), lens.to(dev), N, speaker_id=spk.to(dev),
+                                               prenet_masks=pm.to(dev).contiguous(), check_every=5)
+    torch.cuda.synchronize()
+    assert mels.shape == ref[0].shape, (mels.shape, ref[0].shape)
+    assert l1(mels, ref[0]) < MEL_L1_TOL and l1(post, ref[1]) < MEL_L1_TOL
+    assert mx(al, ref[3]) < 5e-5
+    assert ((gates.cpu() == -1000.0) == (ref[2] == -1000.0)).all()
+
+
+# ------------------------------------------------------------------------------------------------------
+# drop-in nn.Module surface on the GPU
+# ------------------------------------------------------------------------------------------------------
+def test_module_forward_backward_autograd_matches_reference_golden():
+    """model.tacotron2.Tacotron2-style use: forward(), torch losses, loss.backward(), p.grad for every parameter."""
+    import torch.nn.functional as F
+    from tacotron2_amd.model import Tacotron2
+    dev = _dev()
+    z = load_golden("tf_train")
+    m = Tacotron2(dropout=0.5, device=dev, **SMALL)
+    m.load_state_dict(params_from(z))
+    m.train()
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    masks = masks_to_device(tf_masks_from(z), dev)
+    mels, post, gates, al = m(t("chars_idx"), t("chars_len"), True, t("mel"), t("mel_len"), dropout_masks=masks)
+    loss = F.binary_cross_entropy_with_logits(gates, t("gate")) + F.mse_loss(mels, t("mel")) + F.mse_loss(post, t("mel"))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - z["o_loss"][0]) < 1e-5 * max(1.0, abs(z["o_loss"][0]))
+    bad = []
+    for name, p in m.named_parameters():
+        r = torch.from_numpy(z["g." + name]).double()
+        err = float((p.grad.double().cpu() - r).abs().max()) / max(float(r.abs().max()), 1e-3)
+        if not err < 3e-4:
+            bad.append((name, err))
+    assert not bad, bad[:8]
+
+
+def test_module_inference_and_eval_mode():
+    from tacotron2_amd.model import TTSModel
+    dev = _dev()
+    z = load_golden("infer")
+    tm = TTSModel(lr=1e-3, weight_decay=1e-6, num_chars=39, char_embedding_dim=32, num_mels=16, prenet_dim=16, att_rnn_dim=32,
+                  att_dim=16, rnn_hidden_dim=32, postnet_dim=32, dropout=0.5, device=dev)
+    tm.tacotron2.load_state_dict(params_from(z))
+    tm.eval()
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    pm = t("m.prenet_drop").contiguous()
+    mels, post, gates, al = tm.tacotron2(t("chars_idx"), t("chars_len"), False, max_len_override=int(z["max_len"]),
+                                         dropout_masks={"prenet_drop": pm})
+    assert mels.shape == z["o_mels"].shape and l1(post, z["o_post"]) < MEL_L1_TOL
+    # Philox prenet masks (AlwaysDropout): eval-mode outputs differ between calls, shapes are sane
+    o1 = tm(t("chars_idx"), t("chars_len"), teacher_forcing=False, max_len_override=12)
+    o2 = tm(t("chars_idx"), t("chars_len"), teacher_forcing=False, max_len_override=12)
+    assert o1[0].shape[0] == 3 and o1[0].shape[1] <= 12 and o1[3].shape[2] == z["chars_idx"].shape[1]
+    assert float((o1[0][:, :2] - o2[0][:, :2]).abs().max()) > 0
