@@ -286,6 +286,15 @@ typedef struct {
 } T2Infer;
 int t2_decoder_infer(const T2Infer* a, int t0, int t1, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Log-mel front-end (datasets/tts_dataset.py:166-168,204; definition restated from datasets/prosody_dataset.py:39-50,67):
+ * wav [n] fp32 -> out [frames = 1 + n/hop][n_mels] natural-log mel.  basis [2*(n_fft/2+1)][n_fft] = window-folded
+ * [cos ; -sin] DFT rows, fb [n_mels][ldm] mel filterbank rows zero-padded to ldm = round_up(n_fft/2+1, 4) (both built by the
+ * host once, tacotron2_amd/datasets/logmel.py).  Workspaces: padded [n + n_fft], spec [frames][2*(n_fft/2+1)], mag [frames][ldm]. */
+int t2_logmel_frames(int64_t n_samples, int hop);
+int t2_logmel_fwd(const float* wav, int64_t n, const float* basis, const float* fb, float* padded, float* spec, float* mag,
+                  float* out, int n_fft, int hop, int n_mels, void* stream);
+
 /* dropout scale masks (Philox4x32-10, counter = element index) and the optimizer of model/tts_model.py:78-91 +
  * Lightning gradient_clip_val=1.0 (run/train.py:240) on one flat fp32 parameter buffer. */
 int t2_philox_mask(float* out, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream);

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""CLI with the reference's surface for the hot path (main.py:15-107,150-226 of mattm458/tacotron2):
+
+    python main.py --config C --device N train --speech-dir S [--results-dir R] [--resume-ckpt K] [--finetune --finetune-steps n]
+    python main.py --config C --device N say --checkpoint K --text "..." [--out out.npy] [--random-seed s] [--speaker-id i]
+
+Other reference sub-commands (test, test_correlation, train_mel_export, preprocess, server) are evaluation / demo tooling
+outside the hot-path scope.  Multi-GPU training: `python -m torch.distributed.run --nproc-per-node N
+main.py --config C train ...` (one process per GPU, RCCL gradient all-reduce)."""
+import click
+
+from tacotron2_amd.run.common import load_config
+
+
+@click.group()
+@click.pass_context
+@click.option("--config", type=str, required=False, default=None, help="A Tacotron hyperparameter config file")
+@click.option("--device", type=int, required=False, default=0, help="The GPU to use for training or inference. Default 0.")
+def main(ctx, config, device):
+    ctx.ensure_object(dict)
+    ctx.obj["config"] = load_config(config) if config is not None else None
+    ctx.obj["device"] = device
+
+
+@main.command()
+@click.pass_context
+@click.option("--speech-dir", required=True, type=str, help="A directory containing audio files from the dataset.")
+@click.option("--results-dir", required=False, type=str, help="The directory to save results.")
+@click.option("--resume-ckpt", required=False, type=str, help="Resume training from the given checkpoint.")
+@click.option("--prosody-model-checkpoint", required=False, type=str, help="(accepted for CLI compatibility; unused)")
+@click.option("--finetune", is_flag=True, default=False, help="Fine-tune a model. If specified, --resume-ckpt is required.")
+@click.option("--finetune-steps", required=False, type=int, help="Steps to fine-tune. Required if --finetune is given.")
+@click.option("--max-steps", required=False, type=int, default=None, help="Override training.args.max_steps (smoke runs).")
+@click.option("--synthetic", is_flag=True, default=False, help="Train on synthetic LJSpeech-shaped batches (no dataset needed).")
+def train(ctx, speech_dir, results_dir=None, resume_ckpt=None, prosody_model_checkpoint=None, finetune=False,
+          finetune_steps=None, max_steps=None, synthetic=False):
+    if ctx.obj["config"] is None:
+        raise Exception("Configuration required for training!")
+    if finetune and finetune_steps is None:
+        raise Exception("If finetuning, --finetune-steps is required!")
+    from tacotron2_amd.run.train import do_train
+    c = ctx.obj["config"]
+    do_train(dataset_config=c["dataset"], training_config=c["training"], model_config=c["model"],
+             extensions_config=c["extensions"], device=ctx.obj["device"], speech_dir=speech_dir, results_dir=results_dir,
+             resume_ckpt=resume_ckpt, finetune=finetune, finetune_steps=finetune_steps, max_steps_override=max_steps,
+             synthetic=synthetic)
+
+
+@main.command()
+@click.pass_context
+@click.option("--checkpoint", required=True, type=str, help="A trained Tacotron model checkpoint")
+@click.option("--text", required=True, type=str, help="Text to speak")
+@click.option("--out", required=False, type=str, default="out.npy", help="Output file (log-mel .npy). Default: out.npy")
+@click.option("--hifi-gan-checkpoint", required=False, type=str, default=None, help="(vocoding is out of scope)")
+@click.option("--random-seed", required=False, type=int, default=None, help="A random seed to use in generation.")
+@click.option("--speaker-id", required=False, type=int, default=None, help="Speaker ID for a multi-speaker model")
+@click.option("--controls", required=False, type=str, default=None, help="(controls extension is out of scope)")
+@click.option("--description", required=False, type=str, default=None, help="Description text (needs BERT weights; unavailable offline)")
+def say(ctx, checkpoint, text, out, speaker_id, hifi_gan_checkpoint, random_seed, controls, description):
+    if ctx.obj["config"] is None:
+        raise Exception("Configuration required for speech!")
+    from tacotron2_amd.run.say import do_say
+    c = ctx.obj["config"]
+    do_say(dataset_config=c["dataset"], training_config=c["training"], model_config=c["model"],
+           extensions_config=c["extensions"], device=ctx.obj["device"], checkpoint=checkpoint, text=text, output=out,
+           speaker_id=speaker_id, hifi_gan_checkpoint=hifi_gan_checkpoint, random_seed=random_seed, controls=controls,
+           description=description)
+
+
+if __name__ == "__main__":
+    main(obj={})

@@ -213,7 +213,9 @@ def encoder_fwd(P, chars_idx: Tensor, chars_len: Tensor, training: bool,
     conv_out = x
     B, L, E = x.shape
     H = E // 2
-    Lmax = int(chars_len.max())
+    # pad_packed_sequence returns max(len) columns; batches are padded to their own longest item so this equals L
+    # (Appendix C.7).  Data-parallel shards padded to the GLOBAL L keep L columns (zeros past each length).
+    Lmax = L
     out = torch.zeros(B, Lmax, E, dtype=x.dtype)
     lens = chars_len.to(torch.int64)
     for d_, sfx in enumerate(("", "_reverse")):

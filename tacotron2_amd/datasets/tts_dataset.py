@@ -1,0 +1,134 @@
+"""TTSDataset / collate with the reference's item and batch layout (datasets/tts_dataset.py:184-302,
+datasets/tts_dataloader.py:8-35): three dicts (data, metadata, extra); chars (B,L) int64 pad 0, mel (B,T,M) pad 0,
+gate (B,T,1) = ones with the last valid frame 0, lengths stacked to (B,).  The log-mel runs on the DEVICE
+(tacotron2_amd.datasets.logmel).  PCM WAV decoding uses the stdlib `wave` module (torchaudio/librosa are absent)."""
+from __future__ import annotations
+
+import os
+import wave
+from collections import defaultdict
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .logmel import TacotronMelSpectrogram
+from .text import ALLOWED_CHARS, TextEncoder
+
+
+def load_wav(path: str):
+    with wave.open(path, "rb") as w:
+        sr, n, width, ch = w.getframerate(), w.getnframes(), w.getsampwidth(), w.getnchannels()
+        raw = w.readframes(n)
+    if width == 2:
+        x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+    elif width == 4:
+        x = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
+    elif width == 1:
+        x = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+    else:
+        raise ValueError(f"unsupported sample width {width}")
+    if ch > 1:
+        x = x.reshape(-1, ch)[:, 0]
+    return x, sr
+
+
+def trim_silence(x: np.ndarray, top_db: float = 60, frame_length: int = 2048, hop_length: int = 512) -> np.ndarray:
+    """librosa.effects.trim semantics: keep from the first to the last frame whose RMS is within top_db of the peak."""
+    if len(x) < frame_length:
+        return x
+    pad = frame_length // 2
+    xp = np.pad(x, (pad, pad), mode="constant")
+    nfr = 1 + (len(xp) - frame_length) // hop_length
+    idx = np.arange(frame_length)[None, :] + hop_length * np.arange(nfr)[:, None]
+    rms = np.sqrt(np.mean(xp[idx] ** 2, axis=1))
+    db = 20 * np.log10(np.maximum(rms, 1e-10)) - 20 * np.log10(max(rms.max(), 1e-10))
+    nz = np.nonzero(db > -top_db)[0]
+    if len(nz) == 0:
+        return x[:0]
+    return x[nz[0] * hop_length:min(len(x), (nz[-1] + 1) * hop_length)]
+
+
+class TTSDataset(torch.utils.data.Dataset):
+    def __init__(self, filenames: List[str], texts: List[str], base_dir: str, speaker_ids: Optional[List[int]] = None,
+                 features=None, allowed_chars: str = ALLOWED_CHARS, end_token: Optional[str] = "^", silence: int = 0,
+                 trim: bool = True, trim_top_db: int = 60, trim_frame_length: int = 2048, expand_abbreviations=False,
+                 include_text=False, include_filename=False, num_mels: int = 80, cache=False, cache_dir=None,
+                 description_embeddings: Optional[List[Optional[str]]] = None, description_embeddings_dim: int = 768,
+                 sample_rate: int = 22050, device="cuda:0", **_ignored):
+        assert (cache and cache_dir is not None) or not cache, "If caching spectrograms, a cache directory is required"
+        if cache and not os.path.exists(cache_dir):
+            os.makedirs(cache_dir, exist_ok=True)
+        self.filenames, self.base_dir = filenames, base_dir
+        self.enc = TextEncoder(allowed_chars, end_token, expand_abbreviations)
+        self.ids = [torch.tensor(self.enc.encode(t), dtype=torch.int64) for t in texts]
+        self.texts = [self.enc.clean(t) for t in texts]
+        self.speaker_ids, self.features = speaker_ids, features
+        self.silence, self.trim, self.trim_top_db, self.trim_frame_length = silence, trim, trim_top_db, trim_frame_length
+        self.cache, self.cache_dir = cache, cache_dir
+        self.description_embeddings, self.description_embeddings_dim = description_embeddings, description_embeddings_dim
+        self.include_text, self.include_filename = include_text, include_filename
+        self.melspectrogram = TacotronMelSpectrogram(n_mels=num_mels, sample_rate=sample_rate, device=device)
+
+    def __len__(self):
+        return len(self.filenames)
+
+    def __getitem__(self, i: int):
+        fn = self.filenames[i]
+        mel = None
+        cache_path = None
+        if self.cache:
+            cache_path = os.path.join(self.cache_dir, f"{fn.replace('/', '_')}.pt")
+            if os.path.exists(cache_path):
+                mel = torch.load(cache_path, weights_only=True)
+        if mel is None:
+            wav, _ = load_wav(os.path.join(self.base_dir, fn))
+            if self.trim:
+                wav = trim_silence(wav, self.trim_top_db, self.trim_frame_length)
+            wav = np.pad(wav, (0, self.silence))
+            mel = self.melspectrogram(torch.from_numpy(np.ascontiguousarray(wav)), id=str(i)).cpu()
+            if cache_path is not None:
+                torch.save(mel, cache_path)
+        gate = torch.ones(len(mel), 1)
+        gate[-1] = 0.0
+        data = {"chars_idx": self.ids[i], "mel_spectrogram": mel, "gate": gate}
+        meta = {"chars_idx_len": torch.tensor([len(self.ids[i])], dtype=torch.int64),
+                "mel_spectrogram_len": torch.IntTensor([len(mel)]), "gate_len": torch.IntTensor([len(gate)])}
+        extra: Dict[str, Any] = {}
+        if self.include_text:
+            extra["text"] = self.texts[i]
+        if self.include_filename:
+            extra["filename"] = fn
+        if self.speaker_ids is not None:
+            meta["speaker_id"] = torch.IntTensor([self.speaker_ids[i]])
+        if self.description_embeddings is not None:
+            p = self.description_embeddings[i]
+            if p is not None:
+                meta["description_embeddings"] = torch.load(os.path.join(self.base_dir, p), map_location="cpu",
+                                                            weights_only=True).unsqueeze(0)
+            else:
+                meta["description_embeddings"] = torch.zeros(1, self.description_embeddings_dim)
+        if self.features is not None:
+            meta["features"] = torch.Tensor([self.features[i]])
+        return data, meta, extra
+
+
+def collate(items):
+    """datasets/tts_dataloader.py:8-35."""
+    data, meta, extra = defaultdict(list), defaultdict(list), defaultdict(list)
+    for d, m, e in items:
+        for k, v in d.items():
+            data[k].append(v)
+        for k, v in m.items():
+            meta[k].append(v)
+        for k, v in e.items():
+            extra[k].append(v)
+    out_d = {k: torch.nn.utils.rnn.pad_sequence(v, batch_first=True) for k, v in data.items()}
+    out_m = {k: torch.stack(v).squeeze(1) for k, v in meta.items()}
+    return out_d, out_m, dict(extra)
+
+
+def TTSDataLoader(dataset, batch_size=1, num_workers=0, shuffle=None, drop_last=True, **_ignored):
+    """The log-mel runs on the GPU inside __getitem__, so items are produced in-process (num_workers = 0)."""
+    return torch.utils.data.DataLoader(dataset, batch_size=batch_size, collate_fn=collate if batch_size > 1 else None,
+                                       num_workers=0, shuffle=shuffle, drop_last=drop_last)

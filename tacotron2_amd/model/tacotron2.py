@@ -51,7 +51,7 @@ class _TacotronFn(torch.autograd.Function):
         outs, ectx = eng.forward_tf(batch["chars_idx"], batch["chars_len"], batch["mel"], batch["mel_len"],
                                     speaker_id=batch.get("speaker_id"),
                                     description_embeddings=batch.get("description_embeddings"),
-                                    training=model.training, masks=masks, save_for_backward=torch.is_grad_enabled())
+                                    training=model.training, masks=masks, save_for_backward=batch["need_grad"])
         ctx.model, ctx.ectx = model, ectx
         ctx.mark_non_differentiable(outs[3])
         return outs
@@ -170,7 +170,8 @@ class Tacotron2(nn.Module):
             batch = dict(chars_idx=chars_idx.contiguous(), chars_len=chars_idx_len, mel=mel, mel_len=mel_spectrogram_len,
                          speaker_id=speaker_id,
                          description_embeddings=description_embeddings.contiguous().float()
-                         if description_embeddings is not None else None, masks=dropout_masks)
+                         if description_embeddings is not None else None, masks=dropout_masks,
+                         need_grad=torch.is_grad_enabled())
             params = [p for p in self.parameters()]
             return _TacotronFn.apply(self, batch, *params)
         outs = []

@@ -1,0 +1,50 @@
+"""do_say (run/say.py:25-179): text -> ids -> checkpoint -> forward(teacher_forcing=False, max_len_override=5000) ON THE GPU
+(the reference runs this on CPU at batch 1; here any number of texts is decoded as one batch, up to 64 per group) ->
+log-mel written as .npy.  Vocoding (Griffin-Lim / HiFi-GAN) is outside the hot-path scope."""
+from __future__ import annotations
+
+from typing import List, Optional, Union
+
+import numpy as np
+import torch
+
+from ..datasets.text import TextEncoder
+from ..model.tts_model import TTSModel
+from .common import model_kwargs
+
+
+def do_say(dataset_config: dict, training_config: dict, model_config: dict, extensions_config: dict, device: int,
+           checkpoint: str, text: Union[str, List[str]], output: str, hifi_gan_checkpoint: Optional[str] = None,
+           random_seed: Optional[int] = None, speaker_id: Optional[int] = None, controls: Optional[str] = None,
+           description: Optional[str] = None, max_len: int = 5000):
+    if hifi_gan_checkpoint is not None:
+        raise NotImplementedError("HiFi-GAN vocoding is out of scope for the hot-path build (SURVEY.md section 8f)")
+    dev = torch.device("cuda", device)
+    torch.cuda.set_device(dev)
+    pre = dataset_config["preprocessing"]
+    enc = TextEncoder(pre["allowed_chars"], pre.get("end_token"), expand_abbrev=False)   # run/say.py: no abbreviations
+    texts = [text] if isinstance(text, str) else list(text)
+    ids = [torch.tensor(enc.encode(t), dtype=torch.int64) for t in texts]
+    chars = torch.nn.utils.rnn.pad_sequence(ids, batch_first=True).to(dev)
+    lens = torch.tensor([len(i) for i in ids], dtype=torch.int64, device=dev)
+    cfg = dict(dataset=dataset_config, training=training_config, model=model_config, extensions=extensions_config)
+    model = TTSModel.load_from_checkpoint(checkpoint, device=dev, **model_kwargs(cfg))
+    model.eval()
+    if random_seed is not None:
+        model.tacotron2._seed = int(random_seed)
+    kw = {}
+    if model.speaker_tokens:
+        kw["speaker_id"] = torch.full((len(texts),), int(speaker_id or 0), dtype=torch.int32, device=dev)
+    if model.description_embeddings:
+        dim = model.hparams["description_embeddings_dim"]
+        if description is not None:
+            raise NotImplementedError("BERT description encoding needs the remote google-bert weights (unavailable offline); "
+                                      "pass precomputed embeddings through the Python API instead")
+        kw["description_embeddings"] = torch.zeros(len(texts), dim, device=dev)
+    with torch.no_grad():
+        _, post, gates, _ = model(chars_idx=chars, chars_idx_len=lens, teacher_forcing=False, max_len_override=max_len, **kw)
+    post = post.cpu().numpy()
+    valid = (gates.cpu().numpy()[:, :, 0] != -1000.0).sum(1)
+    mels = [post[b, :max(int(valid[b]) - 1, 1)] for b in range(len(texts))]     # callers drop the stop frame (run/say.py:155)
+    np.save(output, mels[0] if isinstance(text, str) else np.array(mels, dtype=object), allow_pickle=not isinstance(text, str))
+    return mels

@@ -210,3 +210,21 @@ def test_adam_clip_step_matches_oracle(dev):
         torch.cuda.synchronize()
         assert abs(float(ss.sqrt()) - tot) < 1e-6 * tot
         assert float((pd_.cpu() - p).abs().max()) < 2e-6
+
+
+def test_logmel_matches_float64_restatement(dev):
+    """Device log-mel (DFT as an fp32-MFMA GEMM over overlapping windows) vs the float64 numpy restatement.  PARITY
+    UNPINNED against the reference (speech_utils is not available): this pins the build's own definition."""
+    import numpy as np
+    from oracle.logmel_ref import logmel
+    from tacotron2_amd.datasets.logmel import TacotronMelSpectrogram
+    rng = np.random.default_rng(3)
+    n = 22050 + 777
+    t = np.arange(n) / 22050
+    wav = (0.3 * np.sin(2 * np.pi * 220 * t) + 0.2 * np.sin(2 * np.pi * 3100 * t) * np.exp(-3 * t) + 0.01 * rng.normal(size=n))
+    wav[5000:5600] = 0.0                                   # digital silence -> exercises the 1e-5 clamp
+    ref = logmel(wav)
+    fe = TacotronMelSpectrogram(device=dev)
+    got = fe(torch.from_numpy(wav.astype(np.float32)), id="0").double().cpu().numpy()
+    assert got.shape == ref.shape == (1 + n // 256, 80)
+    assert np.abs(got - ref).max() < 2e-3 and np.abs(got - ref).mean() < 1e-4

@@ -1,0 +1,91 @@
+"""CPU-only host logic: text -> ids, collate layout, config aliasing, synthetic batches, LR schedule."""
+import json
+
+import numpy as np
+import torch
+
+from tacotron2_amd.datasets.text import TextEncoder, expand_abbreviations
+from tacotron2_amd.run.common import load_config, model_kwargs
+from tacotron2_amd.synthetic import ljspeech_batch
+
+ALLOWED = "!'(),.:;? \\-abcdefghijklmnopqrstuvwxyz"
+
+
+def test_text_to_ids_matches_reference_table():
+    enc = TextEncoder(ALLOWED, "^")
+    assert enc.num_chars == 39
+    assert enc.table[" "] == 1 and enc.table["^"] == 13 and enc.table["a"] == 14 and enc.table["z"] == 39 and enc.table["\\"] == 12
+    want = [21, 18, 25, 25, 28, 6, 1, 26, 31, 8, 1, 32, 26, 22, 33, 21, 7, 23, 28, 27, 18, 32, 2, 13]
+    assert enc.encode("Hello, Mr. Smith-Jones!") == want
+    assert enc.clean("Café 42 — déjà vu") == "cafe   deja vu^"
+    assert expand_abbreviations("mrs. smith and dr. who at ft. knox") == "misess smith and doctor who at fort knox"
+    assert TextEncoder(ALLOWED, "^", expand_abbrev=True).clean("Mr. X") == "mister x^"
+
+
+def test_collate_layout():
+    from tacotron2_amd.datasets.tts_dataset import collate
+    items = []
+    for L, T in ((5, 7), (3, 4)):
+        gate = torch.ones(T, 1); gate[-1] = 0
+        items.append(({"chars_idx": torch.arange(1, L + 1), "mel_spectrogram": torch.randn(T, 80), "gate": gate},
+                      {"chars_idx_len": torch.tensor([L]), "mel_spectrogram_len": torch.IntTensor([T]),
+                       "speaker_id": torch.IntTensor([2])}, {"text": "x"}))
+    d, m, e = collate(items)
+    assert d["chars_idx"].shape == (2, 5) and d["chars_idx"][1, 3:].sum() == 0
+    assert d["mel_spectrogram"].shape == (2, 7, 80) and float(d["mel_spectrogram"][1, 4:].abs().sum()) == 0.0
+    assert d["gate"].shape == (2, 7, 1) and m["chars_idx_len"].tolist() == [5, 3] and m["mel_spectrogram_len"].dtype == torch.int32
+    assert m["speaker_id"].shape == (2,) and e["text"] == ["x", "x"]
+
+
+def test_stale_reference_configs_load(tmp_path):
+    """vanilla-* configs of the reference carry `char_embedding_dim` and lack extensions.descriptions."""
+    cfg = {"dataset": {"train": "t.csv", "val": "v.csv", "preprocessing": {"allowed_chars": ALLOWED, "end_token": "^", "num_mels": 80}},
+           "training": {"lr": 1e-3, "batch_size": 64, "weight_decay": 1e-6, "name": "x", "args": {"max_steps": 100000}},
+           "model": {"scheduler_milestones": [0.5, 0.75],
+                     "args": {"prenet_dim": 256, "att_rnn_dim": 1024, "att_dim": 128, "rnn_hidden_dim": 1024, "postnet_dim": 512,
+                              "dropout": 0.5, "char_embedding_dim": 512, "encoder_kernel_size": 5}},
+           "extensions": {"speaker_tokens": {"active": True, "num_speakers": 4}, "controls": {"active": False}}}
+    p = tmp_path / "c.json"
+    p.write_text(json.dumps(cfg))
+    kw = model_kwargs(load_config(str(p)))
+    assert kw["encoded_dim"] == 512 and "char_embedding_dim" not in kw
+    assert kw["num_chars"] == 39 and kw["speaker_tokens"] and kw["num_speakers"] == 4
+    assert kw["scheduler_milestones"] == [50000, 75000]
+    kw2 = model_kwargs(load_config("config/ljspeech_b32.json"))
+    assert kw2["encoded_dim"] == 512 and kw2["num_speakers"] == 4
+
+
+def test_synthetic_batch_shapes():
+    b = ljspeech_batch(32, seed=1234, num_speakers=4)
+    L, T = b["chars_idx"].shape[1], b["mel_spectrogram"].shape[1]
+    assert 13 <= int(b["chars_idx_len"].min()) and L <= 188 and T <= 872 and b["mel_spectrogram_len"].dtype == torch.int32
+    for i in range(32):
+        l, t = int(b["chars_idx_len"][i]), int(b["mel_spectrogram_len"][i])
+        assert int(b["chars_idx"][i, l - 1]) == 13 and b["chars_idx"][i, l:].sum() == 0
+        assert float(b["gate"][i, t - 1]) == 0.0 and float(b["gate"][i, :t - 1].min()) == 1.0
+    assert float(b["mel_spectrogram"].max()) <= 2.0 and float(b["mel_spectrogram"][b["mel_spectrogram"] != 0].min()) >= np.log(1e-5) - 1e-6
+
+
+def test_multistep_lr_schedule_matches_torch():
+    from tacotron2_amd.trainer import Trainer
+    t = Trainer.__new__(Trainer)
+    t.base_lr, t.milestones = 1e-3, [3, 5]
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=1e-3)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[3, 5], gamma=0.1)
+    for step in range(8):
+        assert abs(t.lr_at(step) - opt.param_groups[0]["lr"]) < 1e-12
+        opt.step(); sch.step()
+
+
+def test_trim_and_wav_roundtrip(tmp_path):
+    import wave
+    from tacotron2_amd.datasets.tts_dataset import load_wav, trim_silence
+    sr = 22050
+    x = np.zeros(sr, np.float32); x[6000:14000] = 0.5 * np.sin(np.arange(8000) / 5.0)
+    with wave.open(str(tmp_path / "a.wav"), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(sr); w.writeframes((x * 32767).astype("<i2").tobytes())
+    y, r = load_wav(str(tmp_path / "a.wav"))
+    assert r == sr and np.abs(y - x).max() < 1e-4
+    tr = trim_silence(y, top_db=40)
+    assert 7000 < len(tr) < 12000
