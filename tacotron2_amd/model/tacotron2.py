@@ -172,7 +172,8 @@ class Tacotron2(nn.Module):
                          description_embeddings=description_embeddings.contiguous().float()
                          if description_embeddings is not None else None, masks=dropout_masks,
                          need_grad=torch.is_grad_enabled())
-            params = [p for p in self.parameters()]
+            named = dict(self.named_parameters())
+            params = [named[n] for n in self._param_names]      # store order = order of the returned gradients
             return _TacotronFn.apply(self, batch, *params)
         outs = []
         with torch.no_grad():
