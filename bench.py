@@ -41,7 +41,12 @@ def cpu_baseline(dims, batch, t_cap, b_cap):
     """Oracle (CPU restatement pinned to the reference, oracle/tacotron2_ref.py) timed on this host's cores on a bounded
     sample of the same workload: the first b_cap utterances, frames capped at t_cap, one fwd+loss+bwd+Adam step."""
     from oracle import tacotron2_ref as R
-    cores = os.cpu_count() or 1
+    # threads actually used: the process's CPU share (the GPU box gives 16 cores per GPU), never the machine total
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
     torch.set_num_threads(cores)
     d = R.default_dims(**dims)
     P = R.init_params(d, seed=0)
@@ -168,7 +173,8 @@ def main():
                    segments_ms={k: round(v, 3) for k, v in seg.items()})
         if world == 1 and not args.no_cpu_baseline:
             dims = {k: v for k, v in VANILLA.items()}
-            out["cpu_baseline"] = cpu_baseline(dims, cpu_batch, t_cap=200, b_cap=32)
+            print("[bench] GPU timing done; timing the CPU oracle baseline (bounded sample)...", file=sys.stderr, flush=True)
+            out["cpu_baseline"] = cpu_baseline(dims, cpu_batch, t_cap=120, b_cap=32)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
