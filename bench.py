@@ -174,7 +174,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             dims = {k: v for k, v in VANILLA.items()}
             print("[bench] GPU timing done; timing the CPU oracle baseline (bounded sample)...", file=sys.stderr, flush=True)
-            out["cpu_baseline"] = cpu_baseline(dims, cpu_batch, t_cap=120, b_cap=32)
+            out["cpu_baseline"] = cpu_baseline(dims, cpu_batch, t_cap=400, b_cap=32)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -173,12 +173,14 @@ typedef struct {
     float* xdec; float* att_c; float* gates; float* align; float* cum; float* th;
     float* xproj_ctx; int64_t ld_xproj;
     float* e_part;
+    int t_begin, t_end;              /* frame range [t_begin, t_end) of this call; 0,0 = all T frames */
 } T2AttnSeq;
 int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream);
 
 /* Back-propagation through the attention chain, frames T-1 .. 0 (autograd of t2_attn_seq_fwd), 4 launches / frame:
- *   dctx_tot[t] = dctx_ext1[t] + dctx_ext2[t] + dgates[t+1] . W_ih_ctx ; attention backward (weights/energies,
- *   then per attention-dim slice) ; attention-LSTM cell backward with dh = dh_ext[t] + dgates[t+1].W_hh + dq[t].Wq.
+ *   one launch for both products of dgates[t+1] (dctx_tot[t] = dctx_ext1[t] + dctx_ext2[t] + dgates[t+1].W_ih_ctx and
+ *   dh_rec = dh_ext[t] + dgates[t+1].W_hh) ; attention backward (weights/energies, then per attention-dim slice) ;
+ *   attention-LSTM cell backward with dh = dh_rec + dq[t].Wq.
  * Upstream gradients are time-major rows (t,b) with their own leading dimensions.  Outputs: dgates = Z [T+1][B][4A+Ad]
  * with Z[s][b] = [dgates_s (4A) | dq_{s-1} (Ad)] (the caller zero-fills slot T's first 4A columns; `dq` is unused),
  * dctx_tot [T][B][Ef] (inputs of the post-loop weight-gradient GEMMs) and the per-sample
@@ -189,7 +191,8 @@ typedef struct {
     const float* W_ih_ctx; int64_t ld_wih;
     const float* W_hh; const float* Wq; const float* U; const float* v;
     const float* wtp_ctx;            /* optional t2_lstm_pack_bwd(W_ih_ctx, ncols = Ef) */
-    const float* wtp_h;              /* optional t2_lstm_pack_bwd(W_hh, 4A, Wq, Ad, ncols = A) */
+    const float* wtp_h;              /* t2_lstm_pack_bwd(W_hh, A, 4A, ncols = A) */
+    const float* wtp_q;              /* t2_lstm_pack_bwd(Wq, A, Ad, ncols = A) */
     const float* memory; const float* xdec; const float* att_c; const float* gates; const float* align;
     const float* cum; const float* th; const float* att_drop;
     const float* dh_ext; int64_t ld_dh;
@@ -197,6 +200,8 @@ typedef struct {
     const float* dctx_ext2; int64_t ld_dc2;
     float* dgates; float* dctx_tot; float* dq; float* dpmT; float* dv_part; float* dU_part;
     float* dc; float* G; float* de; float* din_part;
+    float* dh_rec;                   /* workspace [B][A]: dh_ext[t] + dgates[t+1].W_hh */
+    int t_hi, t_lo;                  /* frames t_hi-1 .. t_lo of this call (descending); 0,0 = T-1 .. 0 */
 } T2AttnSeqBwd;
 int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream);
 

@@ -341,7 +341,9 @@ extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int B = a->B, L = a->L, T = a->T, A = a->A, Ef = a->Ef, Ad = a->Ad;
     const long ldx = A + Ef;
-    for (int t = 0; t < T; ++t) {
+    const int tb = (a->t_begin == 0 && a->t_end == 0) ? 0 : a->t_begin, te = (a->t_begin == 0 && a->t_end == 0) ? T : a->t_end;
+    T2_REQUIRE(tb >= 0 && te <= T && tb <= te, "t2_attn_seq_fwd: bad frame range");
+    for (int t = tb; t < te; ++t) {
         T2LstmStep s;
         memset(&s, 0, sizeof(s));
         s.B = B; s.H = A;
@@ -376,7 +378,7 @@ extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
         q.cum_out = a->cum + (long)(t + 1) * B * L; q.ldco = L;
         q.ctx_out = slot1 + A; q.ldctx = ldx;
         if (a->xproj_ctx) { q.ctx_out2 = a->xproj_ctx + (long)t * B * a->ld_xproj; q.ldctx2 = a->ld_xproj; }
-        if (t == 0) T2_TRY(check_attn(q));
+        if (t == tb) T2_TRY(check_attn(q));
         T2_TRY(launch_attn(q, st));
     }
     return T2_OK;
@@ -654,18 +656,28 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
     // backward step of frame t always reads ONE contiguous row Z[t+1] (no special case for the last frame).
     const long ldz = 4 * A + Ad;
     float* Z = a->dgates;
-    for (int t = T - 1; t >= 0; --t) {
+    T2_REQUIRE(a->wtp_q && a->dh_rec, "t2_attn_seq_bwd: wtp_q / dh_rec required");
+    const int thi = (a->t_hi == 0 && a->t_lo == 0) ? T : a->t_hi, tlo = (a->t_hi == 0 && a->t_lo == 0) ? 0 : a->t_lo;
+    T2_REQUIRE(tlo >= 0 && thi <= T && tlo <= thi, "t2_attn_seq_bwd: bad frame range");
+    for (int t = thi - 1; t >= tlo; --t) {
         const bool last = (t == T - 1);
         const float* zrow = Z + (long)(t + 1) * B * ldz;
-        // (1) total gradient w.r.t. context_t
-        T2LstmBwdStep s;
-        memset(&s, 0, sizeof(s));
+        // (1) ONE launch for both products of dgates_{t+1}: total gradient w.r.t. context_t  and the raw recurrent
+        //     gradient dgates_{t+1}.W_hh of att_h_t (192 workgroups instead of 64 + 128 in two dependent launches)
+        T2LstmBwdStep s2[2];
+        memset(s2, 0, sizeof(s2));
+        T2LstmBwdStep& s = s2[0];
         s.B = B; s.H = A; s.N4 = 4 * A; s.dg_next = zrow; s.lddg = ldz; s.W = a->W_ih_ctx; s.ldw = a->ld_wih;
         s.ncols = Ef; s.epi = 0; s.wtpacked = a->wtp_ctx;
         s.ext1 = a->dctx_ext1 + (long)t * B * a->ld_dc1; s.ldx1 = a->ld_dc1;
         s.ext2 = a->dctx_ext2 + (long)t * B * a->ld_dc2; s.ldx2 = a->ld_dc2;
         s.dx_out = a->dctx_tot + (long)t * B * Ef; s.lddx = Ef;
-        T2_TRY(t2_lstm_step_bwd_launch(&s, 1, st));
+        T2LstmBwdStep& r = s2[1];
+        r.B = B; r.H = A; r.N4 = 4 * A; r.dg_next = zrow; r.lddg = ldz; r.W = a->W_hh; r.ldw = A;
+        r.ncols = A; r.epi = 0; r.wtpacked = a->wtp_h;
+        r.ext1 = a->dh_ext + (long)t * B * a->ld_dh; r.ldx1 = a->ld_dh;
+        r.dx_out = a->dh_rec; r.lddx = A;
+        T2_TRY(t2_lstm_step_bwd_launch(s2, 2, st));
         // (2),(3) attention backward
         AttnBwdK k;
         memset(&k, 0, sizeof(k));
@@ -685,12 +697,12 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         k.dv_part = a->dv_part; k.dU_part = a->dU_part; k.din_part_out = a->din_part;
         hipLaunchKernelGGL(attn_bwd_dw_kernel, dim3(B, t2_cdiv(L, 32)), dim3(256), sm_dw, st, k);
         hipLaunchKernelGGL(attn_bwd_ds_kernel, dim3(B, NA), dim3(ENT), sm_ds, st, k);
-        // (4) attention-LSTM cell backward: dh = dh_ext + [dgates_{t+1} | dq_t] . [W_hh ; Wq]
+        // (4) attention-LSTM cell backward: dh = (dh_ext + dgates_{t+1}.W_hh) + dq_t.Wq  (short K = Ad product + pointwise)
         T2LstmBwdStep c;
         memset(&c, 0, sizeof(c));
-        c.B = B; c.H = A; c.N4 = 4 * A; c.N2 = Ad; c.dg_next = zrow; c.lddg = ldz; c.W = a->W_hh; c.ldw = A;
-        c.ncols = A; c.epi = 1; c.wtpacked = a->wtp_h;
-        c.ext1 = a->dh_ext + (long)t * B * a->ld_dh; c.ldx1 = a->ld_dh;
+        c.B = B; c.H = A; c.N4 = Ad; c.dg_next = Z + (long)(t + 1) * B * ldz + 4 * A; c.lddg = ldz; c.W = a->Wq; c.ldw = A;
+        c.ncols = A; c.epi = 1; c.wtpacked = a->wtp_q;
+        c.ext1 = a->dh_rec; c.ldx1 = A;
         if (a->att_drop) { c.drop = a->att_drop + (long)t * B * A; c.lddrop = A; }
         c.gates = a->gates + (long)t * B * 4 * A; c.ldgs = 4 * A;
         c.c_prev = a->att_c + (long)t * B * A; c.ldcp = A;

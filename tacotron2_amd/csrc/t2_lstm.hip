@@ -540,6 +540,7 @@ __global__ __launch_bounds__(256, 1) void lstm_step_bwd_fast_kernel(BwdK2 pp) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
     const int u0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    if (u0 >= p.ncols) return;   // descriptors of one launch may have different widths (whole workgroup exits)
     const int NCH = (p.N4 + p.N2) >> 4, NCHpad = (NCH + 31) & ~31, G = NCHpad >> 5;
     const float* wb = p.wtpacked + (long)blockIdx.x * NCHpad * 256 + lane * 4;
     const float* ab = p.dg_next + (long)((b0 + r) < p.B ? (b0 + r) : 0) * p.lddg + 4 * q;
@@ -625,11 +626,12 @@ int launch_bwd(const T2LstmBwdStep* steps, int n, hipStream_t st) {
     T2_REQUIRE(n == 1 || n == 2, "lstm bwd step: n must be 1 or 2");
     BwdK2 kk;
     for (int i = 0; i < n; ++i) { T2_TRY(check_bwd(steps[i])); to_bk(steps[i], kk.s[i]); }
-    if (n == 2) T2_REQUIRE(steps[0].B == steps[1].B && steps[0].ncols == steps[1].ncols, "lstm bwd step: shapes differ");
-    if (n == 1) kk.s[1] = kk.s[0];
-    dim3 grid(t2_cdiv(steps[0].ncols, 16), t2_cdiv(steps[0].B, 16), n), block(256);
     bool fast = true;
     for (int i = 0; i < n; ++i) fast = fast && steps[i].wtpacked && steps[i].dg_next && !steps[i].dg2;
+    if (n == 2) T2_REQUIRE(steps[0].B == steps[1].B && (fast || steps[0].ncols == steps[1].ncols), "lstm bwd step: shapes differ");
+    if (n == 1) kk.s[1] = kk.s[0];
+    const int maxcols = (n == 2 && steps[1].ncols > steps[0].ncols) ? steps[1].ncols : steps[0].ncols;
+    dim3 grid(t2_cdiv(maxcols, 16), t2_cdiv(steps[0].B, 16), n), block(256);
     if (fast) hipLaunchKernelGGL(lstm_step_bwd_fast_kernel, grid, block, 0, st, kk);
     else hipLaunchKernelGGL(lstm_step_bwd_kernel, grid, block, 0, st, kk);
     T2_CHECK_LAUNCH();

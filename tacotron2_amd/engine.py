@@ -56,8 +56,15 @@ class Engine:
         self.d = ps.dims
         self.dev = ps.device
         self._ws: Dict[str, torch.Tensor] = {}
+        self._side = None
+        self.chunk = 64               # frames per pipeline chunk (two-stream overlap of the two recurrences)
         self.profile = False          # when True, mark() records HIP events at segment boundaries
         self.marks = []               # [(name, event)] of the current step
+
+    def side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        return self._side
 
     def mark(self, name: str):
         if self.profile:
@@ -293,30 +300,44 @@ class Engine:
                    v=P["decoder.attention.v.weight"], pre=pre_att, pmT=pmT, memory=memory, len=len32,
                    att_drop=masks.get("att_drop"), xdec=xdec, att_c=att_c, gates=gates_att, align=align, cum=cum, th=th,
                    xproj_ctx=_ptr(xproj, B * (D + Ef) + D), ld_xproj=D + Ef, e_part=e_part)
-        call("t2_attn_seq_fwd", seq, st)
-        self.mark("fwd.dec.attn_chain")
-
-        # decoder-LSTM chain: hoisted input projection, then T recurrent steps
+        # decoder-LSTM chain operands (prepared before the pipeline below)
         pre_dec = self.buf("pre_dec", T, B, 4 * D)
-        gemm(_ptr(xdec, B * (A + Ef)), P["decoder.lstm.weight_ih"], pre_dec, R, 4 * D, A + Ef, A + Ef, A + Ef, 4 * D,
-             bias=P["decoder.lstm.bias_ih"], bias2=P["decoder.lstm.bias_hh"])
-        self.mark("fwd.dec.pre_dec_gemm")
         dec_c = self.buf("dec_c", T + 1, B, D)
         dec_c[0].zero_()
         gates_dec = self.buf("gates_dec", T, B, 4 * D) if save_for_backward else None
         dd = masks.get("dec_drop")
         ldp = D + Ef
         wp_dec = self.pack_fwd("dec", [(P["decoder.lstm.weight_hh"], D, D)], D)
-        stp = make("T2LstmStep", B=B, H=D, nseg=1, wpacked=wp_dec, pre=pre_dec, ldpre=4 * D, c_prev=dec_c, ldc_prev=D,
-                   drop=dd, lddrop=D, h_out=_ptr(xproj, B * ldp), ldh=ldp, c_out=_ptr(dec_c, B * D), ldc_out=D,
-                   gates_out=gates_dec, ldg=4 * D)
-        stp.seg[0].x = xproj.data_ptr(); stp.seg[0].ldx = ldp
-        stp.seg[0].w = P["decoder.lstm.weight_hh"].data_ptr(); stp.seg[0].ldw = D; stp.seg[0].K = D
-        inc = make("T2LstmStride", pre=B * 4 * D, c_prev=B * D, drop=B * D, h_out=B * ldp, c_out=B * D,
-                   gates_out=B * 4 * D, dt=0)
-        inc.seg_x[0] = B * ldp
-        call("t2_lstm_seq_fwd", stp, inc, 1, T, st)
-        self.mark("fwd.dec.lstm_chain")
+        # Two-stream pipeline over chunks of frames: the attention chain of chunk c+1 (main stream) overlaps the hoisted
+        # input projection + decoder-LSTM chain of chunk c (side stream); in teacher-forced mode the attention chain never
+        # reads the decoder LSTM (model/decoder.py:70-101), so the only dependency is chunk c -> chunk c.
+        main, side = torch.cuda.current_stream(), self.side_stream()
+        side.wait_stream(main)
+        CH = self.chunk
+        for c0 in range(0, T, CH):
+            c1 = min(T, c0 + CH)
+            seq.t_begin, seq.t_end = c0, c1
+            call("t2_attn_seq_fwd", seq, st)
+            ev = main.record_event()
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                n = c1 - c0
+                gemm(_ptr(xdec, (c0 + 1) * B * (A + Ef)), P["decoder.lstm.weight_ih"], _ptr(pre_dec, c0 * B * 4 * D), n * B,
+                     4 * D, A + Ef, A + Ef, A + Ef, 4 * D, bias=P["decoder.lstm.bias_ih"], bias2=P["decoder.lstm.bias_hh"])
+                stp = make("T2LstmStep", B=B, H=D, nseg=1, wpacked=wp_dec, pre=_ptr(pre_dec, c0 * B * 4 * D), ldpre=4 * D,
+                           c_prev=_ptr(dec_c, c0 * B * D), ldc_prev=D,
+                           drop=_ptr(dd, c0 * B * D) if dd is not None else None, lddrop=D,
+                           h_out=_ptr(xproj, (c0 + 1) * B * ldp), ldh=ldp, c_out=_ptr(dec_c, (c0 + 1) * B * D), ldc_out=D,
+                           gates_out=_ptr(gates_dec, c0 * B * 4 * D) if gates_dec is not None else None, ldg=4 * D)
+                stp.seg[0].x = _ptr(xproj, c0 * B * ldp); stp.seg[0].ldx = ldp
+                stp.seg[0].w = P["decoder.lstm.weight_hh"].data_ptr(); stp.seg[0].ldw = D; stp.seg[0].K = D
+                inc = make("T2LstmStride", pre=B * 4 * D, c_prev=B * D, drop=B * D, h_out=B * ldp, c_out=B * D,
+                           gates_out=B * 4 * D, dt=0)
+                inc.seg_x[0] = B * ldp
+                call("t2_lstm_seq_fwd", stp, inc, 1, n, side.cuda_stream)
+        self.mark("fwd.dec.attn_chain")
+        main.wait_stream(side)
+        self.mark("fwd.dec.lstm_chain_tail")
 
         # mel + stop projection over all frames: [mel_out.weight ; gate.weight] is one (M+1, D+Ef) matrix
         wproj = ps.cat_view("decoder.mel_out.weight", M + 1, D + Ef)
@@ -419,33 +440,17 @@ class Engine:
                     ldp, M + 1, ldp, R)
         call("t2_colsum", dproj, M + 1, R, M + 1, ps.cat_view("decoder.mel_out.bias", M + 1, 0, grad=True), st)
 
-        self.mark("bwd.dec.proj")
-        # ---- decoder-LSTM chain, back-propagation through time ----------------------------------------------
+        # ---- both recurrences, back-propagation through time, as a two-stream pipeline over chunks of frames -----------
+        # side stream: decoder-LSTM BPTT of chunk k (1 launch / frame) + the GEMM that turns its gate gradients into
+        #              d[att_h, ctx] for those frames;   main stream: attention-chain BPTT of chunk k (4 launches / frame).
+        # The attention chain of a frame only needs the decoder chain's gradient of the SAME frame, so chunk k+1 of the
+        # decoder chain overlaps chunk k of the attention chain; the decoder weight-gradient GEMMs overlap the tail.
         dgd = self.buf("dgd", T + 1, B, 4 * D)
         dgd[T].zero_()
         dc_dec = self.buf("dc_dec", B, D, zero=True)
         dd = masks.get("dec_drop")
         wtp_dec = self.pack_bwd("dec.t", P["decoder.lstm.weight_hh"], D, 4 * D, D)
-        s = make("T2LstmBwdStep", B=B, H=D, N4=4 * D, dg_next=_ptr(dgd, T * B * 4 * D), lddg=4 * D,
-                 W=P["decoder.lstm.weight_hh"], ldw=D, wtpacked=wtp_dec, ncols=D, epi=1,
-                 ext1=_ptr(dxproj, (T - 1) * B * ldp), ldx1=ldp,
-                 drop=_ptr(dd, (T - 1) * B * D) if dd is not None else None, lddrop=D,
-                 gates=_ptr(ctx["gates_dec"], (T - 1) * B * 4 * D), ldgs=4 * D,
-                 c_prev=_ptr(ctx["dec_c"], (T - 1) * B * D), ldcp=D, c_cur=_ptr(ctx["dec_c"], T * B * D), ldcc=D,
-                 dc=dc_dec, lddc=D, dg_out=_ptr(dgd, (T - 1) * B * 4 * D), ldgo=4 * D)
-        inc = make("T2LstmBwdStride", dg=-B * 4 * D, ext1=-B * ldp, drop=-B * D, gates=-B * 4 * D, c_prev=-B * D,
-                   c_cur=-B * D, dt=0)
-        call("t2_lstm_seq_bwd", s, inc, 1, T, st)
-        self.mark("bwd.dec.lstm_chain")
-        self._wgrad(dgd, 4 * D, _ptr(xdec, B * ldx), ldx, G["decoder.lstm.weight_ih"], ldx, 4 * D, ldx, R)
-        self._wgrad(dgd, 4 * D, xproj, ldp, G["decoder.lstm.weight_hh"], D, 4 * D, D, R)
-        call("t2_colsum", dgd, 4 * D, R, 4 * D, G["decoder.lstm.bias_ih"], st)
-        call("t2_colsum", dgd, 4 * D, R, 4 * D, G["decoder.lstm.bias_hh"], st)
         dxdec = self.buf("dxdec", T, B, ldx)
-        gemm(dgd, P["decoder.lstm.weight_ih"], dxdec, R, ldx, 4 * D, 4 * D, ldx, ldx, a_k=1, b_k=0)
-
-        self.mark("bwd.dec.lstm_gemms")
-        # ---- attention chain, back-propagation through time ---------------------------------------------------
         ldz = 4 * A + Ad
         Z = self.buf("Zatt", T + 1, B, ldz)       # Z[s][b] = [dgates_s | dq_{s-1}]
         Z[T, :, :4 * A].zero_()
@@ -460,9 +465,11 @@ class Engine:
         de = self.buf("de", B, L)
         din_part = self.buf("din_part", B, Ad // 16, 2, L)
         wtp_ctx = self.pack_bwd("att.ctx.t", _ptr(P["decoder.att_rnn.weight_ih"], Pd), Pd + Ef, 4 * A, Ef)
-        wtp_h = self.pack_bwd("att.h.t", P["decoder.att_rnn.weight_hh"], A, 4 * A, A,
-                              P["decoder.attention.query_layer.weight"], A, Ad)
-        sb = make("T2AttnSeqBwd", B=B, L=L, T=T, A=A, Ad=Ad, Ef=Ef, Kl=KL, wtp_ctx=wtp_ctx, wtp_h=wtp_h,
+        wtp_h = self.pack_bwd("att.h.t", P["decoder.att_rnn.weight_hh"], A, 4 * A, A)
+        wtp_q = self.pack_bwd("att.q.t", P["decoder.attention.query_layer.weight"], A, Ad, A)
+        dh_rec = self.buf("dh_rec", B, A)
+        sb = make("T2AttnSeqBwd", B=B, L=L, T=T, A=A, Ad=Ad, Ef=Ef, Kl=KL, wtp_ctx=wtp_ctx, wtp_h=wtp_h, wtp_q=wtp_q,
+                  dh_rec=dh_rec,
                   W_ih_ctx=_ptr(P["decoder.att_rnn.weight_ih"], Pd), ld_wih=Pd + Ef, W_hh=P["decoder.att_rnn.weight_hh"],
                   Wq=P["decoder.attention.query_layer.weight"], U=ctx["U"], v=P["decoder.attention.v.weight"],
                   memory=ctx["memory"], xdec=xdec, att_c=ctx["att_c"], gates=ctx["gates_att"], align=ctx["align"],
@@ -470,8 +477,36 @@ class Engine:
                   dh_ext=dxdec, ld_dh=ldx, dctx_ext1=_ptr(dxdec, A), ld_dc1=ldx, dctx_ext2=_ptr(dxproj, D), ld_dc2=ldp,
                   dgates=Z, dctx_tot=dctx_tot, dq=None, dpmT=dpmT, dv_part=dv_part, dU_part=dU_part,
                   dc=dc_att, G=Gc, de=de, din_part=din_part)
-        call("t2_attn_seq_bwd", sb, st)
-        self.mark("bwd.dec.attn_chain")
+        self.mark("bwd.dec.proj")
+        main, side = torch.cuda.current_stream(), self.side_stream()
+        side.wait_stream(main)
+        CH = self.chunk
+        for hi in range(T, 0, -CH):
+            lo = max(0, hi - CH)
+            n = hi - lo
+            with torch.cuda.stream(side):
+                s = make("T2LstmBwdStep", B=B, H=D, N4=4 * D, dg_next=_ptr(dgd, hi * B * 4 * D), lddg=4 * D,
+                         W=P["decoder.lstm.weight_hh"], ldw=D, wtpacked=wtp_dec, ncols=D, epi=1,
+                         ext1=_ptr(dxproj, (hi - 1) * B * ldp), ldx1=ldp,
+                         drop=_ptr(dd, (hi - 1) * B * D) if dd is not None else None, lddrop=D,
+                         gates=_ptr(ctx["gates_dec"], (hi - 1) * B * 4 * D), ldgs=4 * D,
+                         c_prev=_ptr(ctx["dec_c"], (hi - 1) * B * D), ldcp=D, c_cur=_ptr(ctx["dec_c"], hi * B * D), ldcc=D,
+                         dc=dc_dec, lddc=D, dg_out=_ptr(dgd, (hi - 1) * B * 4 * D), ldgo=4 * D)
+                inc = make("T2LstmBwdStride", dg=-B * 4 * D, ext1=-B * ldp, drop=-B * D, gates=-B * 4 * D, c_prev=-B * D,
+                           c_cur=-B * D, dt=0)
+                call("t2_lstm_seq_bwd", s, inc, 1, n, side.cuda_stream)
+                gemm(_ptr(dgd, lo * B * 4 * D), P["decoder.lstm.weight_ih"], _ptr(dxdec, lo * B * ldx), n * B, ldx, 4 * D,
+                     4 * D, ldx, ldx, a_k=1, b_k=0)
+                ev = side.record_event()
+            main.wait_event(ev)
+            sb.t_hi, sb.t_lo = hi, lo
+            call("t2_attn_seq_bwd", sb, st)
+        with torch.cuda.stream(side):   # decoder-LSTM weight gradients overlap the attention chain's tail
+            self._wgrad(dgd, 4 * D, _ptr(xdec, B * ldx), ldx, G["decoder.lstm.weight_ih"], ldx, 4 * D, ldx, R)
+            self._wgrad(dgd, 4 * D, xproj, ldp, G["decoder.lstm.weight_hh"], D, 4 * D, D, R)
+            call("t2_colsum", dgd, 4 * D, R, 4 * D, G["decoder.lstm.bias_ih"], side.cuda_stream)
+            call("t2_colsum", dgd, 4 * D, R, 4 * D, G["decoder.lstm.bias_hh"], side.cuda_stream)
+        self.mark("bwd.dec.chains")
 
         # weight gradients of the attention chain (large GEMMs over all frames)
         gWih = G["decoder.att_rnn.weight_ih"]
@@ -576,6 +611,7 @@ class Engine:
                                   G[f"encoder.convolutions.{i}.weight"], G[f"encoder.convolutions.{i}.bias"],
                                   f"encoder.convolutions.{i + 1}", B, L, E, E, 1, training)
         call("t2_embedding_bwd", ctx["chars_idx"], dx, G["encoder.embedding.weight"], B, L, E, Lp, 0, st)
+        torch.cuda.current_stream().wait_stream(self.side_stream())
         self.mark("bwd.encoder_convs")
 
     # =============================================================================================
