@@ -317,3 +317,77 @@ def test_module_inference_and_eval_mode():
     o2 = tm(t("chars_idx"), t("chars_len"), teacher_forcing=False, max_len_override=12)
     assert o1[0].shape[0] == 3 and o1[0].shape[1] <= 12 and o1[3].shape[2] == z["chars_idx"].shape[1]
     assert float((o1[0][:, :2] - o2[0][:, :2]).abs().max()) > 0
+
+
+# ------------------------------------------------------------------------------------------------------
+# edge shapes and full-size properties
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,L,T,lens,tls", [(1, 1, 1, [1], [1]), (2, 7, 3, [7, 2], [3, 1]), (33, 21, 9, None, None)])
+def test_edge_shapes_match_oracle(B, L, T, lens, tls):
+    """single utterance / single character / single frame; ragged lengths down to 1; B = 33 (three 16-row MFMA tiles)."""
+    dev = _dev()
+    d = R.default_dims(num_chars=39, encoded_dim=64, prenet_dim=32, att_rnn_dim=64, att_dim=32, rnn_hidden_dim=64,
+                       postnet_dim=64, num_mels=80, dropout=0.5)
+    P = R.init_params(d, seed=B)
+    ci, cl, mel, tl, gate, masks = random_case(d, B, L, T, 300 + B, dev)
+    if lens is not None:
+        cl = torch.tensor(lens); tl = torch.tensor(tls, dtype=torch.int32)
+        for b in range(B):
+            ci[b, lens[b]:] = 0; mel[b, tls[b]:] = 0
+    with torch.no_grad():
+        ref = R.tacotron2_fwd(P, d, ci, cl, True, mel, tl, training=True, masks=masks)
+    eng, ps = build_engine(d, P, dev)
+    (mels, post, gates, al), ctx = eng.forward_tf(ci.to(dev), cl.to(dev), mel.to(dev), tl.to(dev), training=True,
+                                                  masks=masks_to_device(masks, dev))
+    ps.grad.zero_()
+    loss3 = eng.loss_and_grads((mels, post, gates, al), ctx, mel.to(dev), gate.to(dev))
+    torch.cuda.synchronize()
+    assert l1(mels, ref[0]) < MEL_L1_TOL and l1(post, ref[1]) < MEL_L1_TOL and mx(al, ref[3]) < 2e-5
+    assert torch.isfinite(ps.grad).all() and torch.isfinite(loss3).all()
+
+
+def test_unsupported_shapes_fail_loudly():
+    from tacotron2_amd._lib import T2Error
+    dev = _dev()
+    d = R.default_dims(num_chars=39, encoded_dim=64, prenet_dim=32, att_rnn_dim=64, att_dim=32, rnn_hidden_dim=64,
+                       postnet_dim=64, num_mels=80, dropout=0.0)
+    eng, ps = build_engine(d, R.init_params(d, seed=1), dev)
+    B, L, T = 2, 800, 3       # text longer than the attention kernels' LDS budget (L <= 768)
+    ci = torch.ones(B, L, dtype=torch.int64, device=dev); cl = torch.full((B,), L, device=dev)
+    mel = torch.zeros(B, T, 80, device=dev); tl = torch.full((B,), T, dtype=torch.int32, device=dev)
+    with pytest.raises(T2Error):
+        eng.forward_tf(ci, cl, mel, tl, training=False, save_for_backward=False)
+    torch.cuda.synchronize()
+
+
+def test_full_size_training_step_properties():
+    """BASELINE configs[1] size (vanilla dims, B = 32, LJSpeech-shaped L/T): properties that do not need the oracle -
+    attention rows are distributions supported on the text, masked tails are exactly 0 / -1000, BN running statistics
+    move, the loss is finite and decreases over a few optimisation steps on a fixed batch."""
+    from tacotron2_amd.init import init_parameters
+    from tacotron2_amd.params import ParamStore
+    from tacotron2_amd.synthetic import ljspeech_batch
+    from tacotron2_amd.trainer import Trainer
+    dev = _dev()
+    dims = dict(num_chars=39, encoded_dim=512, encoder_kernel_size=5, num_mels=80, prenet_dim=256, att_rnn_dim=1024,
+                att_dim=128, rnn_hidden_dim=1024, postnet_dim=512, dropout=0.5, speaker_tokens=True, num_speakers=4,
+                description_embeddings=False, description_embeddings_dim=0)
+    ps = ParamStore(dims, dev); init_parameters(ps, 0)
+    tr = Trainer(ps, lr=1e-3, weight_decay=1e-6)
+    batch = {k: v.to(dev) for k, v in ljspeech_batch(32, seed=1234, num_speakers=4).items()}
+    losses = []
+    for step in range(4):
+        loss3, (mels, post, gates, al) = tr.train_step(batch)
+        losses.append(float(loss3.sum()))
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses)) and losses[-1] < 0.6 * losses[0], losses
+    cl, ml = batch["chars_idx_len"], batch["mel_spectrogram_len"]
+    rows = al.sum(-1)
+    assert float((rows - 1).abs().max()) < 1e-4
+    for b in (0, 7, 31):
+        assert float(al[b, :, int(cl[b]):].abs().max()) == 0.0
+        if int(ml[b]) < mels.shape[1]:
+            assert float(mels[b, int(ml[b]):].abs().max()) == 0.0 and float(post[b, int(ml[b]):].abs().max()) == 0.0
+            assert bool((gates[b, int(ml[b]):] == -1000.0).all())
+    assert float((ps.Bf["postnet.postnet.1.running_mean"]).abs().max()) > 0
+    assert ps.num_batches_tracked["encoder.convolutions.1.num_batches_tracked"] == 4
