@@ -99,8 +99,8 @@ def test_forward_train_matches_reference_golden(name, extra):
 
 def random_case(d, B, L, T, seed, dev):
     g = torch.Generator().manual_seed(seed)
-    lens = torch.randint(max(3, L // 2), L + 1, (B,), generator=g); lens[0] = L
-    tl = torch.randint(max(3, T // 2), T + 1, (B,), generator=g); tl[-1] = T
+    lens = torch.randint(min(max(3, L // 2), L), L + 1, (B,), generator=g); lens[0] = L
+    tl = torch.randint(min(max(3, T // 2), T), T + 1, (B,), generator=g); tl[-1] = T
     ci = torch.zeros(B, L, dtype=torch.int64); mel = torch.zeros(B, T, d["num_mels"]); gate = torch.zeros(B, T, 1)
     for b in range(B):
         ci[b, :lens[b]] = torch.randint(1, d["num_chars"] + 1, (int(lens[b]),), generator=g)
