@@ -51,11 +51,11 @@ __device__ __forceinline__ void stage_inp_U(float* inp, float* Us, const float* 
     const float* wsrc = w_prev ? w_prev + (long)b * ldw : dummy;
     const float* csrc = cum_prev ? cum_prev + (long)b * ldcum : dummy;
     const bool wz = w_prev == nullptr, cz = cum_prev == nullptr;
-    float uv[PER];
+    float uv[PER];   // Us[al][c][32]: taps 0..30 of channel c, tap 31 = 0 (rows padded for aligned 16-byte reads)
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const int idx = tid + NTH * i, al = idx >> 6, kk = idx & 63;
-        uv[i] = U[(long)(j * 16 + al) * 2 * KL + imin(kk, 2 * KL - 1)];
+        const int idx = tid + NTH * i, al = idx >> 6, c = (idx >> 5) & 1, k = idx & 31;
+        uv[i] = U[(long)(j * 16 + al) * 2 * KL + c * KL + imin(k, KL - 1)];
     }
     for (int base = 0; base < 2 * Lp; base += 1024) {
         float iv[PER];
@@ -77,35 +77,48 @@ __device__ __forceinline__ void stage_inp_U(float* inp, float* Us, const float* 
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int idx = tid + NTH * i;
-        Us[idx] = (idx & 63) < 2 * KL ? uv[i] : 0.f;
+        Us[idx] = (idx & 31) < KL ? uv[i] : 0.f;
     }
 }
 
 constexpr int ENT = 512;   // threads of the energy / ds kernels: two waves per SIMD double the VALU issue rate
-constexpr int EMAXI = 2;   // work items per thread per round: one round covers L <= 256
+constexpr int EMAXI = 2;   // 4-position work items per thread per round (32 threads per attention dim): one round covers L <= 256
+
+// Thread mapping of both kernels: attention dim al = tid >> 5 (16 dims x 32 threads), position groups lg = sub + 32*it.
+// All items of a thread share its dim, so the 62 filter taps are read from LDS ONCE into registers (16 aligned 16-byte
+// reads) instead of 62 scalar reads per item; the kernels are LDS-instruction bound otherwise.
+__device__ __forceinline__ void load_taps(const float* Us, int al, float (&uk)[2][32]) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const f32x4* up = reinterpret_cast<const f32x4*>(Us + al * 64 + c * 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 t = up[i];
+            uk[c][4 * i] = t[0]; uk[c][4 * i + 1] = t[1]; uk[c][4 * i + 2] = t[2]; uk[c][4 * i + 3] = t[3];
+        }
+    }
+}
 
 __global__ __launch_bounds__(ENT, 2) void attn_energy_kernel(AttnK p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x, j = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
+    const int al = tid >> 5, sub = tid & 31, a = j * 16 + al;
     const int L = p.L, NG = (L + 3) >> 2, Lp = 4 * NG + 36;
-    float* inp = sm;             // [2][Lp]   zero-haloed (w_prev, cum_prev)
-    float* Us = inp + 2 * Lp;    // [16][64]  folded location filter rows of this slice
+    float* inp = sm;             // [2][Lp]   zero-haloed (w_prev, cum_prev), index l + 15
+    float* Us = inp + 2 * Lp;    // [16][2][32] folded location filter rows of this slice
     float* qs = Us + 16 * 64;    // [16]
     float* ec = qs + 16;         // [16][4*NG] per-dim energy contributions
-    const int items = 16 * NG;
+    const long rowoff = ((long)b * p.Ad + a) * L;
 
     // ---- issue: first round of processed-memory values + v ----
-    float pmv[EMAXI][4], vv[EMAXI];
+    float pmv[EMAXI][4];
+    const float va = p.v[a];
 #pragma unroll
     for (int it = 0; it < EMAXI; ++it) {
-        const int item = imin(tid + ENT * it, items - 1);
-        const int al = item / NG, lg = item - al * NG;
-        const int a = j * 16 + al;
-        vv[it] = p.v[a];
-        const float* pr = p.pmT + ((long)b * p.Ad + a) * L;
+        const int lg = imin(sub + 32 * it, NG - 1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pmv[it][i] = pr[imin(4 * lg + i, L - 1)];
+        for (int i = 0; i < 4; ++i) pmv[it][i] = p.pmT[rowoff + imin(4 * lg + i, L - 1)];
     }
     // ---- issue + accumulate: query projection (2 dims per wave, 16-byte loads) ----
     float qacc[2] = {0.f, 0.f};
@@ -137,53 +150,44 @@ __global__ __launch_bounds__(ENT, 2) void attn_energy_kernel(AttnK p) {
     }
     __syncthreads();
 
-    for (int base = 0; base < items; base += ENT * EMAXI) {
-        if (base > 0) {   // later rounds (L > 256): fetch their processed-memory values now
+    float uk[2][32];
+    load_taps(Us, al, uk);
+    const float qa = qs[al];
+    for (int base = 0; base < NG; base += 32 * EMAXI) {
+        if (base > 0) {   // later rounds (L > 256)
 #pragma unroll
             for (int it = 0; it < EMAXI; ++it) {
-                const int item = imin(base + tid + ENT * it, items - 1);
-                const int al = item / NG, lg = item - al * NG;
-                const int a = j * 16 + al;
-                vv[it] = p.v[a];
-                const float* pr = p.pmT + ((long)b * p.Ad + a) * L;
+                const int lg = imin(base + sub + 32 * it, NG - 1);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) pmv[it][i] = pr[imin(4 * lg + i, L - 1)];
+                for (int i = 0; i < 4; ++i) pmv[it][i] = p.pmT[rowoff + imin(4 * lg + i, L - 1)];
             }
         }
 #pragma unroll
         for (int it = 0; it < EMAXI; ++it) {
-            const int item = base + tid + ENT * it;
-            if (item >= items) continue;
-            const int al = item / NG, lg = item - al * NG;
-            const int a = j * 16 + al;
+            const int lg = base + sub + 32 * it;
+            if (lg >= NG) continue;
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                float win[36], uk[32];
+                float win[36];
                 const f32x4* wp = reinterpret_cast<const f32x4*>(inp + c * Lp + 4 * lg);
 #pragma unroll
                 for (int i = 0; i < 9; ++i) {
                     const f32x4 t = wp[i];
                     win[4 * i] = t[0]; win[4 * i + 1] = t[1]; win[4 * i + 2] = t[2]; win[4 * i + 3] = t[3];
                 }
-                // filter taps of (dim al, channel c): Us row is 64 floats, channel 1 starts at 31 -> read taps singly
-                const float* u = Us + al * 64 + c * KL;
-#pragma unroll
-                for (int k = 0; k < KL; ++k) uk[k] = u[k];
 #pragma unroll
                 for (int k = 0; k < KL; ++k)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(uk[k], win[i + k], acc[i]);
+                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(uk[c][k], win[i + k], acc[i]);
             }
-            const float qa = qs[al];
-            const long rowoff = ((long)b * p.Ad + a) * L;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int l = 4 * lg + i;
                 if (l < L) {
                     const float th = t2_tanh(qa + acc[i] + pmv[it][i]);
                     if (p.th_out) p.th_out[rowoff + l] = th;
-                    ec[al * 4 * NG + l] = vv[it] * th;
+                    ec[al * 4 * NG + l] = va * th;
                 }
             }
         }
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(ENT, 2) void attn_energy_kernel(AttnK p) {
     for (int l = tid; l < L; l += ENT) {
         float s = 0.f;
 #pragma unroll
-        for (int al = 0; al < 16; ++al) s += ec[al * 4 * NG + l];
+        for (int al2 = 0; al2 < 16; ++al2) s += ec[al2 * 4 * NG + l];
         p.e_part[((long)b * gridDim.y + j) * L + l] = s;
     }
 }
@@ -494,31 +498,36 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dw_kernel(AttnBwdK p) {
 __global__ __launch_bounds__(ENT, 2) void attn_bwd_ds_kernel(AttnBwdK p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
+    const int al = tid >> 5, sub = tid & 31, a = j * 16 + al;
     const int L = p.L, NG = (L + 3) >> 2, Lp = 4 * NG + 36, L4 = 4 * NG;
-    float* inp = sm;               // [2][Lp]  haloed (w_{t-1}, cum_{t-1})
-    float* dsp = inp + 2 * Lp;     // [16][Lp] haloed ds (index l + 15)
-    float* tvs = dsp + 16 * Lp;    // [16][L4] de*th, later reused for the d_in partials [4][2][L4]
-    float* Us = tvs + 16 * L4;     // [16][64]
-    float* des = Us + 16 * 64;     // [L4]
-    const int items = 16 * NG;
-    // ---- issue: tanh stash of the first round, de, location inputs, filter rows ----
-    float thv[EMAXI][4], dpv[EMAXI][4], vv[EMAXI];
+    constexpr int DH = 16;         // halo of the ds rows (16, not 15: keeps every 4-position read 16-byte aligned)
+    float* inp = sm;               // [2][Lp]  haloed (w_{t-1}, cum_{t-1}), index l + 15
+    float* dsp = inp + 2 * Lp;     // [16][Lp] haloed ds, index l + 16
+    float* Us = dsp + 16 * Lp;     // [16][2][32]
+    float* tvs = Us + 16 * 64;     // [16][L4] de*th      } after phase C these three (32*L4 floats) hold the
+    float* des = tvs + 16 * L4;    // [L4]                } per-dim d_in partials dinq[16][2][L4]
+                                   // [15*L4] extension   }
+    const long rowoff = ((long)b * p.Ad + a) * L;
+    // ---- issue: tanh stash + old dpmT of the first round, de, location inputs, filter rows, old accumulator values ----
+    float thv[EMAXI][4], dpv[EMAXI][4];
+    const float va = p.v[a];
 #pragma unroll
     for (int it = 0; it < EMAXI; ++it) {
-        const int item = imin(tid + ENT * it, items - 1);
-        const int al = item / NG, lg = item - al * NG;
-        const int a = j * 16 + al;
-        vv[it] = p.v[a];
-        const float* tr = p.th + ((long)b * p.Ad + a) * L;
-        const float* dr = p.dpmT + ((long)b * p.Ad + a) * L;
+        const int lg = imin(sub + 32 * it, NG - 1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { thv[it][i] = tr[imin(4 * lg + i, L - 1)]; dpv[it][i] = dr[imin(4 * lg + i, L - 1)]; }
+        for (int i = 0; i < 4; ++i) {
+            const int l = imin(4 * lg + i, L - 1);
+            thv[it][i] = p.th[rowoff + l];
+            dpv[it][i] = p.dpmT[rowoff + l];
+        }
     }
-    // old values of the per-sample accumulators this thread updates (read-modify-write without a dependent round trip)
-    const int c_al = tid >> 5, c_c = (tid >> 4) & 1, c_k0 = 2 * (tid & 15);
-    float* dU_dst = p.dU_part + (((long)b * p.Ad + j * 16 + c_al) * 2 + c_c) * KL + imin(c_k0, KL - 2);
-    const float dU_old0 = dU_dst[0], dU_old1 = dU_dst[1];
-    const float dv_old = p.dv_part[(long)b * p.Ad + j * 16 + c_al];
+    // phase C ownership: (dim al, channel c_c, tap group c_kg of 8 taps, position quarter c_lq)
+    const int c_c = sub >> 4, c_kg = (sub >> 2) & 3, c_lq = sub & 3, c_k0 = 8 * c_kg;
+    float* dU_dst = p.dU_part + (((long)b * p.Ad + a) * 2 + c_c) * KL + c_k0;
+    float dU_old[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) dU_old[kk] = dU_dst[imin(kk, KL - 1 - c_k0)];
+    const float dv_old = p.dv_part[(long)b * p.Ad + a];
     float dev[2];   // de for up to 1024 positions
 #pragma unroll
     for (int i = 0; i < 2; ++i) dev[i] = p.de[(long)b * L + imin(tid + ENT * i, L - 1)];
@@ -532,108 +541,121 @@ __global__ __launch_bounds__(ENT, 2) void attn_bwd_ds_kernel(AttnBwdK p) {
     for (int l = tid + 1024; l < L4; l += ENT) des[l] = l < L ? p.de[(long)b * L + l] : 0.f;
     __syncthreads();
 
-    // phase A: ds, dpmT accumulation
-    for (int base = 0; base < items; base += ENT * EMAXI) {
+    // phase A: ds, dpmT accumulation (32 threads per dim)
+    for (int base = 0; base < NG; base += 32 * EMAXI) {
 #pragma unroll
         for (int it = 0; it < EMAXI; ++it) {
-            const int item = base + tid + ENT * it;
-            if (item >= items) continue;
-            const int al = item / NG, lg = item - al * NG;
-            const int a = j * 16 + al;
-            const long rowoff = ((long)b * p.Ad + a) * L;
+            const int lg = base + sub + 32 * it;
+            if (lg >= NG) continue;
             if (base > 0) {
-                vv[it] = p.v[a];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    thv[it][i] = (4 * lg + i < L) ? p.th[rowoff + 4 * lg + i] : 0.f;
-                    dpv[it][i] = (4 * lg + i < L) ? p.dpmT[rowoff + 4 * lg + i] : 0.f;
+                    const int l = imin(4 * lg + i, L - 1);
+                    thv[it][i] = p.th[rowoff + l];
+                    dpv[it][i] = p.dpmT[rowoff + l];
                 }
             }
+            f32x4 d4 = {0.f, 0.f, 0.f, 0.f}, t4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 de4 = *reinterpret_cast<const f32x4*>(des + 4 * lg);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int l = 4 * lg + i;
-                float d = 0.f, tv = 0.f;
                 if (l < L) {
                     const float th = thv[it][i];
-                    d = des[l] * vv[it] * (1.f - th * th);
-                    tv = des[l] * th;
-                    p.dpmT[rowoff + l] = dpv[it][i] + d;
+                    d4[i] = de4[i] * va * (1.f - th * th);
+                    t4[i] = de4[i] * th;
+                    p.dpmT[rowoff + l] = dpv[it][i] + d4[i];
                 }
-                dsp[al * Lp + KPAD + l] = d;
-                tvs[al * L4 + l] = tv;
             }
+            *reinterpret_cast<f32x4*>(dsp + al * Lp + DH + 4 * lg) = d4;
+            *reinterpret_cast<f32x4*>(tvs + al * L4 + 4 * lg) = t4;
         }
     }
     __syncthreads();
 
-    {   // phase B: dq[a], dv[a]: 32 lanes per attention dim
-        const int al = tid >> 5, sub = tid & 31;
+    {   // phase B: dq[a], dv[a]: 32 lanes per attention dim, 16-byte reads
         float sq = 0.f, sv = 0.f;
-        for (int l = sub; l < L; l += 32) { sq += dsp[al * Lp + KPAD + l]; sv += tvs[al * L4 + l]; }
+        for (int lg = sub; lg < NG; lg += 32) {
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dsp + al * Lp + DH + 4 * lg);
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(tvs + al * L4 + 4 * lg);
+            sq += (d4[0] + d4[1]) + (d4[2] + d4[3]);
+            sv += (t4[0] + t4[1]) + (t4[2] + t4[3]);
+        }
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) { sq += __shfl_xor(sq, o, 64); sv += __shfl_xor(sv, o, 64); }
         if (sub == 0) {
-            const int a = j * 16 + al;
             p.dq[(long)b * p.lddq + a] = sq;
             p.dv_part[(long)b * p.Ad + a] = dv_old + sv;
         }
     }
 
-    {   // phase C: dU partial; thread = (dim al, channel c, tap pair kg): taps k0 = 2*kg, 2*kg + 1
-        const int al = tid >> 5, c = (tid >> 4) & 1, kg = tid & 15, k0 = 2 * kg;
-        float out[2] = {0.f, 0.f};
-        const float* dsr = dsp + al * Lp + KPAD;
-        const float* inr = inp + c * Lp + k0;
-        for (int l = 0; l < L4; l += 4) {
-            float d4[4], wv[5];
+    {   // phase C: dU[a][c][k0..k0+7] += sum_l ds[l] * in[c][l + k - 15]; 8 taps x 4 positions per register tile,
+        // a quarter of the position groups per thread, quarters combined by two shuffles
+        float out[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float* dsr = dsp + al * Lp + DH;
+        const float* inr = inp + c_c * Lp + c_k0;          // padded index of in[c][l + k - 15] is l + k
+        for (int lg = c_lq; lg < NG; lg += 4) {
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dsr + 4 * lg);
+            float wv[12];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) d4[i] = dsr[l + i];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) wv[i] = inr[l + i];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                out[0] = fmaf(d4[i], wv[i], out[0]);
-                out[1] = fmaf(d4[i], wv[i + 1], out[1]);
+            for (int i = 0; i < 3; ++i) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(inr + 4 * lg + 4 * i);
+                wv[4 * i] = t[0]; wv[4 * i + 1] = t[1]; wv[4 * i + 2] = t[2]; wv[4 * i + 3] = t[3];
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) out[kk] = fmaf(d4[i], wv[i + kk], out[kk]);
         }
-        // (al, c, k0) == (c_al, c_c, c_k0): old values were fetched at kernel entry; k0 = 30 -> only tap 30 exists
-        if (k0 + 1 < KL) { dU_dst[0] = dU_old0 + out[0]; dU_dst[1] = dU_old1 + out[1]; }
-        else dU_dst[1] = dU_old1 + out[0];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            out[kk] += __shfl_xor(out[kk], 1, 64);
+            out[kk] += __shfl_xor(out[kk], 2, 64);
+        }
+        if (c_lq == 0) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+                if (c_k0 + kk < KL) dU_dst[kk] = dU_old[kk] + out[kk];
+        }
     }
-    __syncthreads();   // tvs is reused below
+    __syncthreads();   // tvs (and the tail of dsp's region is NOT touched) is reused below
 
-    // phase D: d_in partials; item = ((aq*2 + c)*NG + lg), 4 dims per item
-    float* dinq = tvs;   // [4][2][L4]
-    const int items_d = 8 * NG;
-    for (int item = tid; item < items_d; item += ENT) {
-        const int lg = item % NG, ac = item / NG, c = ac & 1, aq = ac >> 1;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int ai = 0; ai < 4; ++ai) {
-            const int al = aq * 4 + ai;
+    // phase D: d_in partial of THIS dim: dinq[al][c][l'] = sum_k ds[l' + 15 - k] * U[al][c][k]; items (c, lg) per dim
+    float* dinq = tvs;   // [16][2][L4] over tvs + des + extension
+    {
+        float uk[2][32];
+        load_taps(Us, al, uk);
+        for (int item = sub; item < 2 * NG; item += 32) {
+            const int c = item >= NG ? 1 : 0, lg = item - c * NG;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
             float win[36];
-            const f32x4* wp = reinterpret_cast<const f32x4*>(dsp + al * Lp + 4 * lg);
+            const f32x4* wp = reinterpret_cast<const f32x4*>(dsp + al * Lp + 4 * lg);   // padded index of ds[m] is m + 16
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
                 const f32x4 t = wp[i];
                 win[4 * i] = t[0]; win[4 * i + 1] = t[1]; win[4 * i + 2] = t[2]; win[4 * i + 3] = t[3];
             }
-            const float* u = Us + al * 64 + c * KL;
+            // ds[l' + 15 - k] with l' = 4lg + i  ->  win[i + 31 - k]
+            if (c == 0) {
 #pragma unroll
-            for (int k = 0; k < KL; ++k) {
-                const float uk = u[k];
+                for (int k = 0; k < KL; ++k)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = fmaf(uk, win[i + 30 - k], acc[i]);
+                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(uk[0][k], win[i + 31 - k], acc[i]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < KL; ++k)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(uk[1][k], win[i + 31 - k], acc[i]);
             }
+            *reinterpret_cast<f32x4*>(dinq + (al * 2 + c) * L4 + 4 * lg) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dinq[(aq * 2 + c) * L4 + 4 * lg + i] = acc[i];
     }
     __syncthreads();
     for (int idx = tid; idx < 2 * L; idx += ENT) {
         const int c = idx >= L ? 1 : 0, l = idx - c * L;
-        const float s2 = dinq[(0 * 2 + c) * L4 + l] + dinq[(1 * 2 + c) * L4 + l] + dinq[(2 * 2 + c) * L4 + l] +
-                         dinq[(3 * 2 + c) * L4 + l];
+        float s2 = 0.f;
+#pragma unroll
+        for (int al2 = 0; al2 < 16; ++al2) s2 += dinq[(al2 * 2 + c) * L4 + l];
         p.din_part_out[(((long)b * gridDim.y + j) * 2 + c) * L + l] = s2;
     }
 }
@@ -643,13 +665,13 @@ __global__ __launch_bounds__(ENT, 2) void attn_bwd_ds_kernel(AttnBwdK p) {
 extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
     T2_REQUIRE(a != nullptr, "t2_attn_seq_bwd: null");
     T2_REQUIRE(a->Kl == KL && a->Ad % 16 == 0 && a->Ef % 32 == 0, "t2_attn_seq_bwd: unsupported dims");
-    T2_REQUIRE(a->L >= 1 && a->L <= 384, "t2_attn_seq_bwd: need 1 <= L <= 384");
+    T2_REQUIRE(a->L >= 1 && a->L <= 256, "t2_attn_seq_bwd: need 1 <= L <= 256 (LDS budget of the backward attention kernel)");
     hipStream_t st = (hipStream_t)stream;
     const int B = a->B, L = a->L, T = a->T, A = a->A, Ef = a->Ef, Ad = a->Ad, NA = Ad / 16;
     const long ldx = A + Ef;
     const int NG = (L + 3) >> 2, Lp = 4 * NG + 36, L4 = 4 * NG;
     const size_t sm_dw = (size_t)(Ef + ((L + 3) & ~3) + 8) * sizeof(float);
-    const size_t sm_ds = (size_t)(2 * Lp + 16 * Lp + 16 * L4 + 16 * 64 + L4) * sizeof(float);
+    const size_t sm_ds = (size_t)(18 * Lp + 16 * 64 + 32 * L4) * sizeof(float);
     T2_REQUIRE(sm_ds <= 64 * 1024, "t2_attn_seq_bwd: LDS budget exceeded");
     T2_REQUIRE(a->wtp_ctx && a->wtp_h, "t2_attn_seq_bwd: packed weight streams (t2_lstm_pack_bwd) are required");
     // Z[s][b] = [ dgates_s (4A) | dq_{s-1} (Ad) ], s = 0..T; slot T's dgates part is zero-filled by the caller, so the
