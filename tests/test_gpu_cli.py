@@ -74,3 +74,17 @@ def test_cli_train_on_wav_manifest_resume(tmp_path):
     out = _run(["--config", str(cfg), "train", "--speech-dir", str(speech), "--results-dir", str(res), "--max-steps", "4",
                 "--resume-ckpt", str(res / "final.ckpt")])
     assert "step 3/4" in out or "step 4/4" in out
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
+    """The data-parallel code path end to end on the GPU (shard padding, flat-gradient all-reduce, 1/world scale) with two
+    ranks sharing cuda:0 over gloo (RCCL needs one GPU per rank; the 8-GPU run is the driver's)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29611", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "4", "--backend", "gloo", "--share-gpu"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["value"] > 0 and d["scaling"] == "weak"
+    assert all(np.isfinite(d["loss"]))
