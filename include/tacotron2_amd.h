@@ -106,7 +106,6 @@ int t2_lstm_seq_fwd(const T2LstmStep* base, const T2LstmStride* inc, int n, int 
 /* One step of back-propagation through time for an LSTM cell (autograd of the cells above):
  *   dx[b][u] = sum_n dg_next[b][n] * W[n*ldw + u]          (n over N4 = 4H' rows of the producing cell)
  *   epi = 0: dx_out = dx + ext1 + ext2                      (gradient w.r.t. a non-recurrent input slice)
- *   epi = 2: dx_out += dx with fp32 atomics (K-split partials into a zero-filled destination; no ext terms)
  *   epi = 1: dh = (dx + ext1 + ext2) * drop; pointwise cell backward with the stashed activations of
  *            step t -> dg_out[b][4H] (pre-activation gate grads), dc[b][H] updated in place.
  * dg_next may be NULL (last frame: no recurrent contribution). */
@@ -116,7 +115,6 @@ typedef struct {
     const float* W; int64_t ldw;
     const float* dg2; int64_t lddg2; const float* W2; int64_t ldw2; int N2;  /* optional second K segment (+= dg2 . W2) */
     const float* wtpacked;           /* optional lane-contiguous transposed copy of W (and W2) (t2_lstm_pack_bwd) */
-    int ksplit;                      /* > 1: K split over ksplit workgroups, epi must be 2 (dx_out += partial, fp32 atomics) */
     int ncols; int epi;
     const float* ext1; int64_t ldx1; const float* ext2; int64_t ldx2;
     float* dx_out; int64_t lddx;
@@ -180,10 +178,9 @@ typedef struct {
 int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream);
 
 /* Back-propagation through the attention chain, frames T-1 .. 0 (autograd of t2_attn_seq_fwd), 4 launches / frame:
- *   one launch for both products of dgates[t+1] (dctx_rec[t] = dgates[t+1].W_ih_ctx, dh_rec[t] = dgates[t+1].W_hh; K split
- *   over 4 / 2 workgroups with fp32 atomics so the launch fills the chip) ; attention backward (weights/energies - which
- *   forms dctx_tot[t] = dctx_ext1[t] + dctx_ext2[t] + dctx_rec[t] -, then per attention-dim slice) ; attention-LSTM cell
- *   backward with dh = dh_ext[t] + dh_rec[t] + dq[t].Wq.
+ *   one launch for both products of dgates[t+1] (dctx_tot[t] = dctx_ext1[t] + dctx_ext2[t] + dgates[t+1].W_ih_ctx and
+ *   dh_rec = dh_ext[t] + dgates[t+1].W_hh) ; attention backward (weights/energies, then per attention-dim slice) ;
+ *   attention-LSTM cell backward with dh = dh_rec + dq[t].Wq.
  * Upstream gradients are time-major rows (t,b) with their own leading dimensions.  Outputs: dgates = Z [T+1][B][4A+Ad]
  * with Z[s][b] = [dgates_s (4A) | dq_{s-1} (Ad)] (the caller zero-fills slot T's first 4A columns; `dq` is unused),
  * dctx_tot [T][B][Ef] (inputs of the post-loop weight-gradient GEMMs) and the per-sample
@@ -203,8 +200,7 @@ typedef struct {
     const float* dctx_ext2; int64_t ld_dc2;
     float* dgates; float* dctx_tot; float* dq; float* dpmT; float* dv_part; float* dU_part;
     float* dc; float* G; float* de; float* din_part;
-    float* dh_rec;                   /* [T][B][A], zero-filled by the caller: dgates[t+1].W_hh (K-split atomic partials) */
-    float* dctx_rec;                 /* [T][B][Ef], zero-filled by the caller: dgates[t+1].W_ih_ctx (K-split atomic partials) */
+    float* dh_rec;                   /* workspace [B][A]: dh_ext[t] + dgates[t+1].W_hh */
     int t_hi, t_lo;                  /* frames t_hi-1 .. t_lo of this call (descending); 0,0 = T-1 .. 0 */
 } T2AttnSeqBwd;
 int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream);

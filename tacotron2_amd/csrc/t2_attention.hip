@@ -404,9 +404,7 @@ extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
 //     d_in partial [c][l'] = sum_{a in slice,k} ds[l'+15-k][a] * U[a][c][k]  (summed over slices by the next frame)
 struct AttnBwdK {
     int B, L, Ad, Ef;
-    const float* dctx; long lddctx;                       // recurrent part (K-split atomic partials)
-    const float* dext1; long ldde1; const float* dext2; long ldde2;   // + upstream parts
-    float* dctx_full;                                    // [b][Ef] total, written by the blockIdx.y == 0 workgroups
+    const float* dctx; long lddctx;
     const float* ctx; long ldctx;
     const float* w; long ldw;
     const float* memory;
@@ -436,24 +434,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dw_kernel(AttnBwdK p) {
     // ---- issue: dctx / ctx (<= 4 per thread per pass) ----
     float part = 0.f;
     for (int e0 = 0; e0 < Ef; e0 += 1024) {
-        float dv[4], cv[4], x1[4], x2[4];
+        float dv[4], cv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int e = imin(e0 + tid + 256 * i, Ef - 1);
             dv[i] = p.dctx[(long)b * p.lddctx + e];
-            x1[i] = p.dext1 ? p.dext1[(long)b * p.ldde1 + e] : 0.f;
-            x2[i] = p.dext2 ? p.dext2[(long)b * p.ldde2 + e] : 0.f;
             cv[i] = p.ctx[(long)b * p.ldctx + e];
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int e = e0 + tid + 256 * i;
-            if (e < Ef) {
-                const float tot = dv[i] + x1[i] + x2[i];
-                dctx_s[e] = tot;
-                part = fmaf(tot, cv[i], part);
-                if (blockIdx.y == 0 && p.dctx_full) p.dctx_full[(long)b * Ef + e] = tot;
-            }
+            if (e < Ef) { dctx_s[e] = dv[i]; part = fmaf(dv[i], cv[i], part); }
         }
     }
     // ---- location-path gradient of every position (needed for sigma), partials of frame t+1 ----
@@ -687,7 +678,7 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
     // backward step of frame t always reads ONE contiguous row Z[t+1] (no special case for the last frame).
     const long ldz = 4 * A + Ad;
     float* Z = a->dgates;
-    T2_REQUIRE(a->wtp_q && a->dh_rec && a->dctx_rec, "t2_attn_seq_bwd: wtp_q / dh_rec / dctx_rec required");
+    T2_REQUIRE(a->wtp_q && a->dh_rec, "t2_attn_seq_bwd: wtp_q / dh_rec required");
     const int thi = (a->t_hi == 0 && a->t_lo == 0) ? T : a->t_hi, tlo = (a->t_hi == 0 && a->t_lo == 0) ? 0 : a->t_lo;
     T2_REQUIRE(tlo >= 0 && thi <= T && tlo <= thi, "t2_attn_seq_bwd: bad frame range");
     for (int t = thi - 1; t >= tlo; --t) {
@@ -697,25 +688,23 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         //     gradient dgates_{t+1}.W_hh of att_h_t (192 workgroups instead of 64 + 128 in two dependent launches)
         T2LstmBwdStep s2[2];
         memset(s2, 0, sizeof(s2));
-        if (!last) {   // dgates_T = 0: nothing to add for the last frame (the slots stay zero)
-            T2LstmBwdStep& s = s2[0];
-            s.B = B; s.H = A; s.N4 = 4 * A; s.dg_next = zrow; s.lddg = ldz; s.W = a->W_ih_ctx; s.ldw = a->ld_wih;
-            s.ncols = Ef; s.epi = 2; s.ksplit = 4; s.wtpacked = a->wtp_ctx;
-            s.dx_out = a->dctx_rec + (long)t * B * Ef; s.lddx = Ef;
-            T2LstmBwdStep& r = s2[1];
-            r.B = B; r.H = A; r.N4 = 4 * A; r.dg_next = zrow; r.lddg = ldz; r.W = a->W_hh; r.ldw = A;
-            r.ncols = A; r.epi = 2; r.ksplit = 2; r.wtpacked = a->wtp_h;
-            r.dx_out = a->dh_rec + (long)t * B * A; r.lddx = A;
-            T2_TRY(t2_lstm_step_bwd_launch(s2, 2, st));
-        }
+        T2LstmBwdStep& s = s2[0];
+        s.B = B; s.H = A; s.N4 = 4 * A; s.dg_next = zrow; s.lddg = ldz; s.W = a->W_ih_ctx; s.ldw = a->ld_wih;
+        s.ncols = Ef; s.epi = 0; s.wtpacked = a->wtp_ctx;
+        s.ext1 = a->dctx_ext1 + (long)t * B * a->ld_dc1; s.ldx1 = a->ld_dc1;
+        s.ext2 = a->dctx_ext2 + (long)t * B * a->ld_dc2; s.ldx2 = a->ld_dc2;
+        s.dx_out = a->dctx_tot + (long)t * B * Ef; s.lddx = Ef;
+        T2LstmBwdStep& r = s2[1];
+        r.B = B; r.H = A; r.N4 = 4 * A; r.dg_next = zrow; r.lddg = ldz; r.W = a->W_hh; r.ldw = A;
+        r.ncols = A; r.epi = 0; r.wtpacked = a->wtp_h;
+        r.ext1 = a->dh_ext + (long)t * B * a->ld_dh; r.ldx1 = a->ld_dh;
+        r.dx_out = a->dh_rec; r.lddx = A;
+        T2_TRY(t2_lstm_step_bwd_launch(s2, 2, st));
         // (2),(3) attention backward
         AttnBwdK k;
         memset(&k, 0, sizeof(k));
         k.B = B; k.L = L; k.Ad = Ad; k.Ef = Ef;
-        k.dctx = a->dctx_rec + (long)t * B * Ef; k.lddctx = Ef;
-        k.dext1 = a->dctx_ext1 + (long)t * B * a->ld_dc1; k.ldde1 = a->ld_dc1;
-        k.dext2 = a->dctx_ext2 + (long)t * B * a->ld_dc2; k.ldde2 = a->ld_dc2;
-        k.dctx_full = a->dctx_tot + (long)t * B * Ef;
+        k.dctx = a->dctx_tot + (long)t * B * Ef; k.lddctx = Ef;
         k.ctx = a->xdec + (long)(t + 1) * B * ldx + A; k.ldctx = ldx;
         k.w = a->align + (long)t * L; k.ldw = (long)T * L;
         k.memory = a->memory;
@@ -735,8 +724,7 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         memset(&c, 0, sizeof(c));
         c.B = B; c.H = A; c.N4 = Ad; c.dg_next = Z + (long)(t + 1) * B * ldz + 4 * A; c.lddg = ldz; c.W = a->Wq; c.ldw = A;
         c.ncols = A; c.epi = 1; c.wtpacked = a->wtp_q;
-        c.ext1 = a->dh_rec + (long)t * B * A; c.ldx1 = A;
-        c.ext2 = a->dh_ext + (long)t * B * a->ld_dh; c.ldx2 = a->ld_dh;
+        c.ext1 = a->dh_rec; c.ldx1 = A;
         if (a->att_drop) { c.drop = a->att_drop + (long)t * B * A; c.lddrop = A; }
         c.gates = a->gates + (long)t * B * 4 * A; c.ldgs = 4 * A;
         c.c_prev = a->att_c + (long)t * B * A; c.ldcp = A;

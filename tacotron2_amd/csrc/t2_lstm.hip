@@ -352,7 +352,6 @@ struct BwdK {
     const float* W; long ldw;           // element (n,u) at W[n*ldw + u]
     const float* dg2; long lddg2; const float* W2; long ldw2; int N2;   // optional second K segment
     const float* wtpacked;              // optional: [ncols/16][NCH][64 lanes][4] lane-contiguous transposed weights
-    int ksplit;                         // fast path: K split over `ksplit` workgroups, partials added with fp32 atomics (epi 2)
     int ncols;                          // number of output columns u (H for the recurrent path)
     int epi;                            // 0: plain store of dx (+ext), 1: LSTM pointwise backward
     const float* ext1; long ldx1; const float* ext2; long ldx2;
@@ -511,8 +510,6 @@ __device__ __forceinline__ void bwd_epi_apply(const BwdK& p, const BwdEpi& e, co
                          red[(3 * 16 + bl) * 16 + ul] + e.ext;
         if (p.epi == 0) {
             p.dx_out[(long)b * p.lddx + u] = dx;
-        } else if (p.epi == 2) {
-            atomicAdd(&p.dx_out[(long)b * p.lddx + u], dx);     // K-slice partial into a zero-filled slot
         } else {
             const int H = p.H;
             const bool active = p.t < e.len;
@@ -542,13 +539,9 @@ __global__ __launch_bounds__(256, 1) void lstm_step_bwd_fast_kernel(BwdK2 pp) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
-    const int nbt = (p.B + 15) >> 4;                       // batch tiles; blockIdx.y = k-slice * nbt + batch tile
-    const int kz = blockIdx.y / nbt;
-    const int u0 = blockIdx.x * 16, b0 = (blockIdx.y - kz * nbt) * 16;
-    if (u0 >= p.ncols || kz >= p.ksplit) return;   // descriptors of one launch may differ in width / split (whole workgroup exits)
-    const int NCH = (p.N4 + p.N2) >> 4, NCHpad = (NCH + 31) & ~31, Gall = NCHpad >> 5;
-    const int gper = (Gall + p.ksplit - 1) / p.ksplit, g_lo = kz * gper;
-    const int G = (g_lo + gper) < Gall ? (g_lo + gper) : Gall;    // this workgroup's group range [g_lo, G)
+    const int u0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    if (u0 >= p.ncols) return;   // descriptors of one launch may have different widths (whole workgroup exits)
+    const int NCH = (p.N4 + p.N2) >> 4, NCHpad = (NCH + 31) & ~31, G = NCHpad >> 5;
     const float* wb = p.wtpacked + (long)blockIdx.x * NCHpad * 256 + lane * 4;
     const float* ab = p.dg_next + (long)((b0 + r) < p.B ? (b0 + r) : 0) * p.lddg + 4 * q;
     const BwdEpi epi = bwd_epi_load(p, tid, u0, b0);   // hoisted: in flight during the GEMM
@@ -574,8 +567,8 @@ __global__ __launch_bounds__(256, 1) void lstm_step_bwd_fast_kernel(BwdK2 pp) {
     };
     {
         f32x4 aA[U], bA[U], aB[U], bB[U];
-        int g = g_lo;
-        if (g < G) load_group(g, aA, bA);
+        load_group(0, aA, bA);
+        int g = 0;
         for (; g + 2 < G; g += 2) {
             load_group(g + 1, aB, bB);
             __builtin_amdgcn_sched_barrier(0);
@@ -591,7 +584,7 @@ __global__ __launch_bounds__(256, 1) void lstm_step_bwd_fast_kernel(BwdK2 pp) {
             __builtin_amdgcn_sched_barrier(0);
             mma_group(aA, bA);
             mma_group(aB, bB);
-        } else if (g < G) {
+        } else {
             mma_group(aA, bA);
         }
     }
@@ -605,7 +598,7 @@ void to_bk(const T2LstmBwdStep& s, BwdK& k) {
     k.B = s.B; k.H = s.H; k.N4 = s.N4;
     k.dg_next = s.dg_next; k.lddg = s.lddg; k.W = s.W; k.ldw = s.ldw; k.ncols = s.ncols; k.epi = s.epi;
     k.dg2 = s.dg2; k.lddg2 = s.lddg2; k.W2 = s.W2; k.ldw2 = s.ldw2; k.N2 = s.N2; k.dg_out2 = s.dg_out2; k.ldgo2 = s.ldgo2;
-    k.wtpacked = s.wtpacked; k.ksplit = s.ksplit > 1 ? s.ksplit : 1;
+    k.wtpacked = s.wtpacked;
     k.ext1 = s.ext1; k.ldx1 = s.ldx1; k.ext2 = s.ext2; k.ldx2 = s.ldx2;
     k.dx_out = s.dx_out; k.lddx = s.lddx; k.drop = s.drop; k.lddrop = s.lddrop;
     k.gates = s.gates; k.ldgs = s.ldgs; k.c_prev = s.c_prev; k.ldcp = s.ldcp; k.c_cur = s.c_cur; k.ldcc = s.ldcc;
@@ -621,8 +614,6 @@ int check_bwd(const T2LstmBwdStep& s) {
     if (s.dg2) {
         T2_REQUIRE(s.N2 % 16 == 0 && s.lddg2 % 4 == 0 && t2_aligned16(s.dg2) && (s.W2 || s.wtpacked), "lstm bwd step: dg2 alignment");
     }
-    T2_REQUIRE(s.ksplit <= 1 || (s.epi == 2 && s.wtpacked && s.dg_next && !s.dg2), "lstm bwd step: ksplit needs the fast path and epi = 2");
-    T2_REQUIRE(s.epi != 2 || (!s.ext1 && !s.ext2), "lstm bwd step: epi = 2 (atomic partials) cannot add ext terms");
     if (s.epi == 1) {
         T2_REQUIRE(s.gates && s.c_cur && s.dc && s.dg_out && s.ncols == s.H, "lstm bwd step: epilogue operands");
     } else {
@@ -640,9 +631,7 @@ int launch_bwd(const T2LstmBwdStep* steps, int n, hipStream_t st) {
     if (n == 2) T2_REQUIRE(steps[0].B == steps[1].B && (fast || steps[0].ncols == steps[1].ncols), "lstm bwd step: shapes differ");
     if (n == 1) kk.s[1] = kk.s[0];
     const int maxcols = (n == 2 && steps[1].ncols > steps[0].ncols) ? steps[1].ncols : steps[0].ncols;
-    int maxks = steps[0].ksplit > 1 ? steps[0].ksplit : 1;
-    if (n == 2 && steps[1].ksplit > maxks) maxks = steps[1].ksplit;
-    dim3 grid(t2_cdiv(maxcols, 16), t2_cdiv(steps[0].B, 16) * maxks, n), block(256);
+    dim3 grid(t2_cdiv(maxcols, 16), t2_cdiv(steps[0].B, 16), n), block(256);
     if (fast) hipLaunchKernelGGL(lstm_step_bwd_fast_kernel, grid, block, 0, st, kk);
     else hipLaunchKernelGGL(lstm_step_bwd_kernel, grid, block, 0, st, kk);
     T2_CHECK_LAUNCH();

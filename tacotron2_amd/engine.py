@@ -467,10 +467,9 @@ class Engine:
         wtp_ctx = self.pack_bwd("att.ctx.t", _ptr(P["decoder.att_rnn.weight_ih"], Pd), Pd + Ef, 4 * A, Ef)
         wtp_h = self.pack_bwd("att.h.t", P["decoder.att_rnn.weight_hh"], A, 4 * A, A)
         wtp_q = self.pack_bwd("att.q.t", P["decoder.attention.query_layer.weight"], A, Ad, A)
-        dh_rec = self.buf("dh_rec", T, B, A, zero=True)          # K-split atomic partials land in zero-filled per-frame slots
-        dctx_rec = self.buf("dctx_rec", T, B, Ef, zero=True)
+        dh_rec = self.buf("dh_rec", B, A)
         sb = make("T2AttnSeqBwd", B=B, L=L, T=T, A=A, Ad=Ad, Ef=Ef, Kl=KL, wtp_ctx=wtp_ctx, wtp_h=wtp_h, wtp_q=wtp_q,
-                  dh_rec=dh_rec, dctx_rec=dctx_rec,
+                  dh_rec=dh_rec,
                   W_ih_ctx=_ptr(P["decoder.att_rnn.weight_ih"], Pd), ld_wih=Pd + Ef, W_hh=P["decoder.att_rnn.weight_hh"],
                   Wq=P["decoder.attention.query_layer.weight"], U=ctx["U"], v=P["decoder.attention.v.weight"],
                   memory=ctx["memory"], xdec=xdec, att_c=ctx["att_c"], gates=ctx["gates_att"], align=ctx["align"],
