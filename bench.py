@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the secondary autoregressive decode-rate measurement")
     ap.add_argument("--fixed-shape", action="store_true", help="every utterance L=160, T=860 (roofline accounting variant)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0 (needs --backend gloo)")
@@ -152,6 +153,23 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
 
+    # secondary metric of BASELINE.json ("decode steps/sec"): batched autoregressive inference, 64 utterances (configs[4]),
+    # fixed 256 frames with the stop checks live (random weights never emit a stop), rank 0 only, outside the timed region
+    decode = None
+    if rank == 0 and not args.no_decode:
+        ib = ljspeech_batch(64, seed=4321, num_speakers=4)
+        eng = tr.engine
+        ci, cl, spk = ib["chars_idx"].to(dev), ib["chars_idx_len"].to(dev), ib["speaker_id"].to(dev)
+        eng.infer(ci, cl, 32, speaker_id=spk, training=False, seed=1)           # warm-up
+        torch.cuda.synchronize()
+        n_dec = 256
+        t1 = time.perf_counter()
+        eng.infer(ci, cl, n_dec, speaker_id=spk, training=False, seed=2, check_every=64)
+        torch.cuda.synchronize()
+        ddt = time.perf_counter() - t1
+        decode = dict(decode_steps_per_s=n_dec / ddt, utterance_frames_per_s=64 * n_dec / ddt, batch=64, frames=n_dec,
+                      L=int(ci.shape[1]), note="includes encoder, conditioning and postnet of the call")
+
     if rank == 0:
         Ef = 512
         ms_step = dt / args.steps * 1e3
@@ -175,7 +193,15 @@ def main():
                                  achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                                  traffic=None, algorithmic_bytes_per_step=decoder_step_bytes(B, L, Ef),
                                  us_per_decoder_step=dec_fwd_ms * 1e3 / T if T else None),
-                   segments_ms={k: round(v, 3) for k, v in seg.items()})
+                   segments_ms={k: round(v, 3) for k, v in seg.items()}, decode=decode)
+        # HBM-side bytes of the same kernels from rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE, profiles/):
+        # recorded offline because counters cannot be collected inside this process
+        tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tj):
+            with open(tj) as f:
+                tinfo = json.load(f)
+            if tinfo.get("L") == L and tinfo.get("B") == B:
+                out["roofline"]["traffic"] = tinfo["bytes_per_decoder_step_fwd"] * T
         if world == 1 and not args.no_cpu_baseline:
             dims = {k: v for k, v in VANILLA.items()}
             print("[bench] GPU timing done; timing the CPU oracle baseline (bounded sample)...", file=sys.stderr, flush=True)

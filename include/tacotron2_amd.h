@@ -33,6 +33,8 @@ extern "C" {
 const char* t2_last_error(void);
 int t2_version(void);
 int t2_sizeof(const char* struct_name); /* sizeof of an ABI struct by name, -1 if unknown */
+/* diagnostic: enable/disable in-kernel clock stamps of the LSTM step kernel, read back 8 words (memtime, memrealtime) x 4 */
+int t2_debug_clock(int enable, uint64_t* out8);
 
 /* ------------------------------------------------------------------------------------------------
  * Generic fp32 MFMA GEMM:  C[M,N] (op)= alpha * A[M,K] x B[K,N]  (+ bias[n] + bias2[n]) (relu) (* mask[m,n])

@@ -15,6 +15,11 @@
 //   producing dgates_t - the A operand of the next launch and the row block of the wgrad GEMMs.
 #include "t2_common.hpp"
 
+// Diagnostic only (t2_debug_clock): when enabled, workgroup 0 of the forward fast kernel stamps the shader clock
+// (s_memtime) and the 100 MHz reference (s_memrealtime) at entry and exit; nothing else reads these words.
+__device__ unsigned long long g_t2_clk[8];
+__device__ int g_t2_clk_enable;
+
 namespace {
 
 struct Seg { const float* x; long ldx; const float* w; long ldw; int K; };
@@ -168,6 +173,8 @@ __global__ __launch_bounds__(256, 1) void lstm_step_fwd_fast_kernel(LstmK2 pp) {
     const int r = lane & 15, q = lane >> 4;
     const int u0 = blockIdx.x * 4;
     const int H = p.H;
+    const bool stamp = blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && g_t2_clk_enable;
+    if (stamp) { g_t2_clk[0] = __builtin_amdgcn_s_memtime(); g_t2_clk[1] = __builtin_amdgcn_s_memrealtime(); }
     const int NT = p.seg[0].K >> 4, NTpad = (NT + 15) & ~15, G = NTpad / (4 * U);   // host guarantees NTpad % (4U) == 0
     const float* wb = p.wpacked + (long)blockIdx.x * NTpad * 256 + lane * 4;
     const float* xb[MT];
@@ -247,11 +254,13 @@ __global__ __launch_bounds__(256, 1) void lstm_step_fwd_fast_kernel(LstmK2 pp) {
             mma_group(bwA, axA);
         }
     }
+    if (stamp) { g_t2_clk[2] = __builtin_amdgcn_s_memtime(); g_t2_clk[3] = __builtin_amdgcn_s_memrealtime(); }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int g = 0; g < 4; ++g) red[((w * MT + m) * 16 + (q * 4 + g)) * 16 + r] = acc[m][g];
     __syncthreads();
+    if (stamp) { g_t2_clk[4] = __builtin_amdgcn_s_memtime(); g_t2_clk[5] = __builtin_amdgcn_s_memrealtime(); }
     if (tid < MT * 64) {
         const int b = eb, uu = euu;
         if (b < p.B) {
@@ -278,6 +287,7 @@ __global__ __launch_bounds__(256, 1) void lstm_step_fwd_fast_kernel(LstmK2 pp) {
             }
         }
     }
+    if (stamp) { g_t2_clk[6] = __builtin_amdgcn_s_memtime(); g_t2_clk[7] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 int check_step(const T2LstmStep& s) {
@@ -760,5 +770,12 @@ extern "C" int t2_lstm_pack_bwd(const float* W, int64_t ldw, int N4, const float
     hipLaunchKernelGGL(lstm_pack_bwd_kernel, dim3(t2_cdiv(total, 256) > 2048 ? 2048 : t2_cdiv(total, 256)), dim3(256), 0,
                        (hipStream_t)stream, W, (long)ldw, N4, W2, (long)ldw2, N2, ncols, out);
     T2_CHECK_LAUNCH();
+    return T2_OK;
+}
+
+// Diagnostic: enable/disable the clock stamps of the forward fast kernel and read the last 8 stamped words.
+extern "C" int t2_debug_clock(int enable, uint64_t* out8) {
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_t2_clk_enable), &enable, sizeof(int)) != hipSuccess) return T2_ERR_LAUNCH;
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_t2_clk), 8 * sizeof(unsigned long long)) != hipSuccess) return T2_ERR_LAUNCH;
     return T2_OK;
 }

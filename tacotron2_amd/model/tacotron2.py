@@ -25,11 +25,16 @@ class _Node(nn.Module):
 
 
 def _attach(root: nn.Module, dotted: str, value, buffer: bool = False):
+    import weakref
+    from .submodules import CLASSES
     parts = dotted.split(".")
     mod = root
-    for part in parts[:-1]:
+    for i, part in enumerate(parts[:-1]):
         if part not in mod._modules:
-            mod.add_module(part, _Node())
+            cls = CLASSES.get(".".join(parts[:i + 1]), _Node)
+            child = cls()
+            child.__dict__["_t2_root"] = weakref.ref(root)      # not a registered sub-module: no reference cycle in state
+            mod.add_module(part, child)
         mod = mod._modules[part]
     if buffer:
         mod.register_buffer(parts[-1], value)

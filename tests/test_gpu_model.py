@@ -391,3 +391,40 @@ def test_full_size_training_step_properties():
             assert bool((gates[b, int(ml[b]):] == -1000.0).all())
     assert float((ps.Bf["postnet.postnet.1.running_mean"]).abs().max()) > 0
     assert ps.num_batches_tracked["encoder.convolutions.1.num_batches_tracked"] == 4
+
+
+def test_submodule_forward_signatures_match_oracle():
+    """Encoder / Attention / Decoder / Postnet called directly with the reference's signatures (eval mode)."""
+    from tacotron2_amd.model import Tacotron2
+    dev = _dev()
+    d = R.default_dims(**SMALL, dropout=0.0)
+    P = R.init_params(d, seed=8)
+    m = Tacotron2(dropout=0.0, device=dev, **SMALL)
+    m.load_state_dict(P)
+    m.eval()
+    g = torch.Generator().manual_seed(1)
+    B, L, T = 3, 13, 11
+    lens = torch.tensor([13, 9, 4])
+    ci = torch.zeros(B, L, dtype=torch.int64)
+    for b in range(B):
+        ci[b, :lens[b]] = torch.randint(1, 40, (int(lens[b]),), generator=g)
+    enc = m.encoder(ci.to(dev), lens.to(dev))
+    ref_enc = R.encoder_fwd(P, ci, lens, False)
+    assert mx(enc, ref_enc) < 1e-5
+    mem, pm = R.condition(P, d, ref_enc)
+    mask = torch.arange(L)[None] >= lens[:, None]
+    att_h = torch.randn(B, 32, generator=g); w = torch.softmax(torch.randn(B, L, generator=g), 1); cum = 2 * w
+    c_ref, w_ref = R.attention_fwd(P, att_h, mem, pm, torch.stack([w, cum], 1), mask)
+    c_got, w_got = m.decoder.attention(att_h.to(dev), mem.to(dev), pm.to(dev), torch.stack([w, cum], 1).to(dev), mask.to(dev))
+    assert mx(c_got, c_ref) < 1e-5 and mx(w_got, w_ref) < 1e-5
+    z = lambda *s: torch.randn(*s, generator=g) * 0.3
+    pre, ah, ac, ctx0, dh, dc = z(B, 16), z(B, 32), z(B, 32), z(B, 32), z(B, 32), z(B, 32)
+    ref = R.decoder_step(P, pre, ah, ac, ctx0, w, cum.clone(), dh, dc, mem, pm, mask, None, None)
+    cum_dev = cum.clone().to(dev)
+    got = m.decoder(pre.to(dev), (ah.to(dev), ac.to(dev)), ctx0.to(dev), w.to(dev), cum_dev, (dh.to(dev), dc.to(dev)),
+                    mem.to(dev), pm.to(dev), mask.to(dev))
+    assert mx(got[0], ref[0]) < 2e-5 and mx(got[1], ref[1]) < 2e-5 and mx(got[2][0], ref[2]) < 1e-5
+    assert mx(got[4], ref[5]) < 1e-5 and mx(cum_dev, ref[6]) < 1e-5 and mx(got[6][1], ref[8]) < 1e-5
+    X = torch.randn(B, 16, T, generator=g)
+    post = m.postnet(X.to(dev))
+    assert mx(post, R.postnet_fwd(P, X.transpose(1, 2), False).transpose(1, 2)) < 2e-5
