@@ -84,6 +84,13 @@ typedef struct {
     float* c_out; int64_t ldc_out;
     float* gates_out; int64_t ldg;   /* optional stash of activated gates [b][4H] for backward */
     const int32_t* len; int t;       /* optional activity predicate */
+    /* x16-tiled operands (packed path only).  A (B x K) matrix in x16 layout is stored [K/16][Bp][16] with
+     * Bp = round_up(B,16): one 16-row x 16-column MFMA operand tile is ONE contiguous 1 KB block, so a wave-load reads
+     * 8 full cache lines instead of 16 half lines (measured 3.4 us per step at K = 1536, tools/ubench_cell.hip).
+     * xt: tiled copy of the single input segment (replaces seg[0].x; rows >= B must be finite);
+     * ht_out: tiled copy of h written at columns [ht_col0, ht_col0 + H) of a tiled matrix with the same Bp. */
+    const float* xt;
+    float* ht_out; int ht_col0;
 } T2LstmStep;
 /* n = 1 or 2 independent cells in one launch (the two directions of the encoder BiLSTM). */
 int t2_lstm_step_fwd(const T2LstmStep* steps, int n, void* stream);
@@ -102,6 +109,7 @@ int t2_lstm_pack_bwd(const float* W, int64_t ldw, int N4, const float* W2, int64
  * decoder-LSTMCell recurrence of model/decoder.py:94-101 over all frames (model/tacotron2.py:276-317). */
 typedef struct {
     int64_t seg_x[3]; int64_t pre, c_prev, drop, h_out, h_out2, c_out, gates_out; int dt;
+    int64_t xt, ht_out;
 } T2LstmStride;
 int t2_lstm_seq_fwd(const T2LstmStep* base, const T2LstmStride* inc, int n, int S, void* stream);
 
@@ -127,9 +135,13 @@ typedef struct {
     float* dg_out; int64_t ldgo;
     float* dg_out2; int64_t ldgo2;          /* optional second copy of dg_out with its own row stride */
     const int32_t* len; int t;
+    /* x16-tiled operands (packed path only, layout as in T2LstmStep): dgt_next = tiled copy of dg_next ([N4/16][Bp][16]),
+     * read instead of dg_next (which must still be non-NULL); dgt_out = tiled copy of dg_out ([4H/16][Bp][16]). */
+    const float* dgt_next;
+    float* dgt_out;
 } T2LstmBwdStep;
 int t2_lstm_step_bwd(const T2LstmBwdStep* steps, int n, void* stream);
-typedef struct { int64_t dg, dg2, ext1, ext2, drop, gates, c_prev, c_cur; int dt; } T2LstmBwdStride;
+typedef struct { int64_t dg, dg2, ext1, ext2, drop, gates, c_prev, c_cur; int dt; int64_t dgt; } T2LstmBwdStride;
 /* S steps; every pointer advances by its stride each step.  The caller lays the dgates stash out with one extra
  * zero-filled slot so that base[i].dg_next (the slot 'after' the first processed step) is valid and zero. */
 int t2_lstm_seq_bwd(const T2LstmBwdStep* base, const T2LstmBwdStride* inc, int n, int S, void* stream);
@@ -152,6 +164,7 @@ typedef struct {
     float* e_part; float* th_out;
     float* w_out; int64_t ldwo; float* cum_out; int64_t ldco;
     float* ctx_out; int64_t ldctx; float* ctx_out2; int64_t ldctx2;
+    float* ctxt_out; int ctxt_col0;          /* optional x16-tiled copy of the context (see T2LstmStep) */
 } T2AttnStep;
 int t2_attn_fold_location(const float* Wd, const float* Wc, float* U, int Ad, int F, int Kl, void* stream);
 int t2_attn_step_fwd(const T2AttnStep* s, void* stream);
@@ -176,6 +189,8 @@ typedef struct {
     float* xproj_ctx; int64_t ld_xproj;
     float* e_part;
     int t_begin, t_end;              /* frame range [t_begin, t_end) of this call; 0,0 = all T frames */
+    float* xdec_t;                   /* optional (with wpacked): x16-tiled copy of xdec, [T+1][(A+Ef)/16][Bp][16], slot 0
+                                        zero-filled by the caller; the attention-LSTM step then reads its input from it */
 } T2AttnSeq;
 int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream);
 
@@ -204,6 +219,8 @@ typedef struct {
     float* dc; float* G; float* de; float* din_part;
     float* dh_rec;                   /* workspace [B][A]: dh_ext[t] + dgates[t+1].W_hh */
     int t_hi, t_lo;                  /* frames t_hi-1 .. t_lo of this call (descending); 0,0 = T-1 .. 0 */
+    float* dgates_t;                 /* optional x16-tiled copy of the dgates part of Z: [T+1][4A/16][Bp][16], slot T
+                                        zero-filled by the caller; read by the per-frame products of dgates[t+1] */
 } T2AttnSeqBwd;
 int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream);
 

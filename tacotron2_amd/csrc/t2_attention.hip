@@ -33,6 +33,7 @@ struct AttnK {
     float* e_part; float* th_out;
     float* w_out; long ldwo; float* cum_out; long ldco;
     float* ctx_out; long ldctx; float* ctx_out2; long ldctx2;
+    float* ctxt_out; int ctxt_col0; long ctxt_cs;
 };
 
 // Load discipline for these one-workgroup-per-CU kernels: every global load of a phase is ISSUED (unconditionally, from a
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(256, 1) void attn_context_kernel(AttnK p) {
         for (int g = 0; g < 8; ++g) s2 += part[g * 32 + tid];
         p.ctx_out[(long)b * p.ldctx + es0 + tid] = s2;
         if (p.ctx_out2) p.ctx_out2[(long)b * p.ldctx2 + es0 + tid] = s2;
+        if (p.ctxt_out) { const int col = p.ctxt_col0 + es0 + tid; p.ctxt_out[(long)(col >> 4) * p.ctxt_cs + b * 16 + (col & 15)] = s2; }
     }
 }
 
@@ -304,6 +306,7 @@ void to_ak(const T2AttnStep& s, AttnK& k) {
     k.pmT = s.pmT; k.memory = s.memory; k.len = s.len; k.e_part = s.e_part; k.th_out = s.th_out;
     k.w_out = s.w_out; k.ldwo = s.ldwo; k.cum_out = s.cum_out; k.ldco = s.ldco;
     k.ctx_out = s.ctx_out; k.ldctx = s.ldctx; k.ctx_out2 = s.ctx_out2; k.ldctx2 = s.ldctx2;
+    k.ctxt_out = s.ctxt_out; k.ctxt_col0 = s.ctxt_col0; k.ctxt_cs = (long)((s.B + 15) / 16 * 16) * 16;
 }
 
 int launch_attn(const T2AttnStep& s, hipStream_t st) {
@@ -347,6 +350,7 @@ extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
     const long ldx = A + Ef;
     const int tb = (a->t_begin == 0 && a->t_end == 0) ? 0 : a->t_begin, te = (a->t_begin == 0 && a->t_end == 0) ? T : a->t_end;
     T2_REQUIRE(tb >= 0 && te <= T && tb <= te, "t2_attn_seq_fwd: bad frame range");
+    T2_REQUIRE(!a->xdec_t || (a->wpacked && (A + Ef) % 16 == 0 && A % 16 == 0), "t2_attn_seq_fwd: xdec_t needs wpacked and A, Ef multiples of 16");
     for (int t = tb; t < te; ++t) {
         T2LstmStep s;
         memset(&s, 0, sizeof(s));
@@ -362,6 +366,8 @@ extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
             s.seg[1].x = slot + A; s.seg[1].ldx = ldx; s.seg[1].w = a->W_ih_ctx; s.seg[1].ldw = a->ld_wih; s.seg[1].K = Ef;
         }
         s.wpacked = a->wpacked;
+        const long xts = (long)((A + Ef) / 16) * ((B + 15) / 16 * 16) * 16;   // one x16-tiled slot
+        if (a->xdec_t) { s.xt = a->xdec_t + (long)t * xts; s.ht_out = a->xdec_t + (long)(t + 1) * xts; s.ht_col0 = 0; }
         s.pre = a->pre + (long)t * B * 4 * A; s.ldpre = 4 * A;
         s.c_prev = a->att_c + (long)t * B * A; s.ldc_prev = A;
         if (a->att_drop) { s.drop = a->att_drop + (long)t * B * A; s.lddrop = A; }
@@ -382,6 +388,7 @@ extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
         q.cum_out = a->cum + (long)(t + 1) * B * L; q.ldco = L;
         q.ctx_out = slot1 + A; q.ldctx = ldx;
         if (a->xproj_ctx) { q.ctx_out2 = a->xproj_ctx + (long)t * B * a->ld_xproj; q.ldctx2 = a->ld_xproj; }
+        if (a->xdec_t) { q.ctxt_out = a->xdec_t + (long)(t + 1) * xts; q.ctxt_col0 = A; }
         if (t == tb) T2_TRY(check_attn(q));
         T2_TRY(launch_attn(q, st));
     }
@@ -679,14 +686,15 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
     const long ldz = 4 * A + Ad;
     float* Z = a->dgates;
     T2_REQUIRE(a->wtp_q && a->dh_rec, "t2_attn_seq_bwd: wtp_q / dh_rec required");
+    T2_REQUIRE(!a->dgates_t || A % 16 == 0, "t2_attn_seq_bwd: dgates_t needs A % 16 == 0");
     const int thi = (a->t_hi == 0 && a->t_lo == 0) ? T : a->t_hi, tlo = (a->t_hi == 0 && a->t_lo == 0) ? 0 : a->t_lo;
     T2_REQUIRE(tlo >= 0 && thi <= T && tlo <= thi, "t2_attn_seq_bwd: bad frame range");
+    T2LstmBwdStep s2[2];
     for (int t = thi - 1; t >= tlo; --t) {
         const bool last = (t == T - 1);
         const float* zrow = Z + (long)(t + 1) * B * ldz;
         // (1) ONE launch for both products of dgates_{t+1}: total gradient w.r.t. context_t  and the raw recurrent
         //     gradient dgates_{t+1}.W_hh of att_h_t (192 workgroups instead of 64 + 128 in two dependent launches)
-        T2LstmBwdStep s2[2];
         memset(s2, 0, sizeof(s2));
         T2LstmBwdStep& s = s2[0];
         s.B = B; s.H = A; s.N4 = 4 * A; s.dg_next = zrow; s.lddg = ldz; s.W = a->W_ih_ctx; s.ldw = a->ld_wih;
@@ -694,11 +702,14 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         s.ext1 = a->dctx_ext1 + (long)t * B * a->ld_dc1; s.ldx1 = a->ld_dc1;
         s.ext2 = a->dctx_ext2 + (long)t * B * a->ld_dc2; s.ldx2 = a->ld_dc2;
         s.dx_out = a->dctx_tot + (long)t * B * Ef; s.lddx = Ef;
+        const long zts = (long)(4 * A / 16) * ((B + 15) / 16 * 16) * 16;   // one x16-tiled dgates slot
+        if (a->dgates_t) s.dgt_next = a->dgates_t + (long)(t + 1) * zts;
         T2LstmBwdStep& r = s2[1];
         r.B = B; r.H = A; r.N4 = 4 * A; r.dg_next = zrow; r.lddg = ldz; r.W = a->W_hh; r.ldw = A;
         r.ncols = A; r.epi = 0; r.wtpacked = a->wtp_h;
         r.ext1 = a->dh_ext + (long)t * B * a->ld_dh; r.ldx1 = a->ld_dh;
         r.dx_out = a->dh_rec; r.lddx = A;
+        if (a->dgates_t) r.dgt_next = a->dgates_t + (long)(t + 1) * zts;
         T2_TRY(t2_lstm_step_bwd_launch(s2, 2, st));
         // (2),(3) attention backward
         AttnBwdK k;
@@ -731,6 +742,7 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         c.c_cur = a->att_c + (long)(t + 1) * B * A; c.ldcc = A;
         c.dc = a->dc; c.lddc = A;
         c.dg_out = Z + (long)t * B * ldz; c.ldgo = ldz;
+        if (a->dgates_t) c.dgt_out = a->dgates_t + (long)t * zts;
         T2_TRY(t2_lstm_step_bwd_launch(&c, 1, st));
     }
     T2_CHECK_LAUNCH();

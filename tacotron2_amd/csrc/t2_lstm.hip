@@ -36,6 +36,8 @@ struct LstmK {
     float* c_out; long ldc_out;
     float* gates_out; long ldg;
     const int32_t* len; int t;
+    const float* xt; long xt_cs;        // x16-tiled input (chunk stride Bp*16 floats) or null
+    float* ht_out; int ht_col0;
 };
 struct LstmK2 { LstmK s[2]; };
 
@@ -177,11 +179,14 @@ __global__ __launch_bounds__(256, 1) void lstm_step_fwd_fast_kernel(LstmK2 pp) {
     if (stamp) { g_t2_clk[0] = __builtin_amdgcn_s_memtime(); g_t2_clk[1] = __builtin_amdgcn_s_memrealtime(); }
     const int NT = p.seg[0].K >> 4, NTpad = (NT + 15) & ~15, G = NTpad / (4 * U);   // host guarantees NTpad % (4U) == 0
     const float* wb = p.wpacked + (long)blockIdx.x * NTpad * 256 + lane * 4;
+    // x16-tiled input: chunk c, tile m is one contiguous 1 KB block (8 full cache lines per wave-load); row-major
+    // input: 16 rows x 64 B per wave-load (16 half lines - 3-4x slower through the vector memory pipe)
     const float* xb[MT];
+    const long xcs = p.xt ? p.xt_cs : 16;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int row = m * 16 + r;
-        xb[m] = p.seg[0].x + (long)(row < p.B ? row : 0) * p.seg[0].ldx + 4 * q;
+        xb[m] = p.xt ? p.xt + (long)row * 16 + 4 * q : p.seg[0].x + (long)(row < p.B ? row : 0) * p.seg[0].ldx + 4 * q;
     }
     f32x4 acc[MT];
 #pragma unroll
@@ -207,51 +212,50 @@ __global__ __launch_bounds__(256, 1) void lstm_step_fwd_fast_kernel(LstmK2 pp) {
     if (p.c_prev) e_cp = p.c_prev[ebc * p.ldc_prev + eu];
     if (p.drop) e_drop = p.drop[ebc * p.lddrop + eu];
     if (p.len) e_len = p.len[ebc];
-    auto load_group = [&](int g, f32x4 (&bw)[U], f32x4 (&ax)[U][MT]) {
+    auto load_chunk = [&](int g, int j, f32x4& bw, f32x4 (&ax)[MT]) {
+        const int c = 4 * U * g + 4 * j + w;
+        const int cx = c < NT ? c : NT - 1;     // padding chunks: any finite activations x the zero weight chunk
+        bw = *reinterpret_cast<const f32x4*>(wb + (long)c * 256);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) ax[m] = *reinterpret_cast<const f32x4*>(xb[m] + xcs * cx);
+    };
+    auto mma_chunk = [&](const f32x4& bw, const f32x4 (&ax)[MT]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[m][s], bw[s], acc[m], 0, 0, 0);
+    };
+    // Software pipeline at chunk granularity: the loads of chunk j of group g+1 are issued right before the MFMAs of
+    // chunk j of group g, so the vector-memory pipe and the MFMA pipe are busy at the same time (a wave that issues a
+    // whole group of loads and then a whole group of MFMAs alternates between the two: 6.2 -> 5.3 us per step at
+    // K = 1536, tools/ubench_cell.hip).  ~U*(1+MT) loads stay in flight; sched_barrier pins the order, the loads are
+    // unconditional so the compiler's counted vmcnt waits stay exact.
+    auto pipe_group = [&](int gl, f32x4 (&bwL)[U], f32x4 (&axL)[U][MT], const f32x4 (&bwM)[U], const f32x4 (&axM)[U][MT]) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const int c = 4 * U * g + 4 * j + w;
-            const int cx = c < NT ? c : NT - 1;     // padding chunks: any finite activations x the zero weight chunk
-            bw[j] = *reinterpret_cast<const f32x4*>(wb + (long)c * 256);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                ax[j][m] = *reinterpret_cast<const f32x4*>(xb[m] + 16 * cx);
-            }
+            load_chunk(gl, j, bwL[j], axL[j]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_chunk(bwM[j], axM[j]);
+            __builtin_amdgcn_sched_barrier(0);
         }
-    };
-    auto mma_group = [&](const f32x4 (&bw)[U], const f32x4 (&ax)[U][MT]) {
-#pragma unroll
-        for (int j = 0; j < U; ++j)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[j][m][s], bw[j][s], acc[m], 0, 0, 0);
     };
     {
         f32x4 bwA[U], bwB[U], axA[U][MT], axB[U][MT];
-        // steady state issues its loads unconditionally (counted vmcnt waits need straight-line load issue)
-        load_group(0, bwA, axA);
+#pragma unroll
+        for (int j = 0; j < U; ++j) load_chunk(0, j, bwA[j], axA[j]);
         int g = 0;
-        // sched_barrier(0): keep each group's 12 loads issued together AHEAD of the previous group's MFMAs (the
-        // scheduler otherwise sinks loads next to their uses and leaves only 2-3 in flight)
         for (; g + 2 < G; g += 2) {
-            load_group(g + 1, bwB, axB);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_group(bwA, axA);
-            __builtin_amdgcn_sched_barrier(0);
-            load_group(g + 2, bwA, axA);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_group(bwB, axB);
-            __builtin_amdgcn_sched_barrier(0);
+            pipe_group(g + 1, bwB, axB, bwA, axA);
+            pipe_group(g + 2, bwA, axA, bwB, axB);
         }
         if (g + 1 < G) {
-            load_group(g + 1, bwB, axB);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_group(bwA, axA);
-            mma_group(bwB, axB);
+            pipe_group(g + 1, bwB, axB, bwA, axA);
+#pragma unroll
+            for (int j = 0; j < U; ++j) mma_chunk(bwB[j], axB[j]);
         } else {
-            mma_group(bwA, axA);
+#pragma unroll
+            for (int j = 0; j < U; ++j) mma_chunk(bwA[j], axA[j]);
         }
     }
     if (stamp) { g_t2_clk[2] = __builtin_amdgcn_s_memtime(); g_t2_clk[3] = __builtin_amdgcn_s_memrealtime(); }
@@ -280,6 +284,7 @@ __global__ __launch_bounds__(256, 1) void lstm_step_fwd_fast_kernel(LstmK2 pp) {
             if (!active) { hn = 0.f; cn = 0.f; gi = gf = gg = go = 0.f; }
             p.h_out[(long)b * p.ldh + u] = hn;
             if (p.h_out2) p.h_out2[(long)b * p.ldh2 + u] = hn;
+            if (p.ht_out) { const int col = p.ht_col0 + u; p.ht_out[(long)(col >> 4) * p.xt_cs + b * 16 + (col & 15)] = hn; }
             if (p.c_out) p.c_out[(long)b * p.ldc_out + u] = cn;
             if (p.gates_out) {
                 float* go_ = p.gates_out + (long)b * p.ldg + u;
@@ -300,6 +305,9 @@ int check_step(const T2LstmStep& s) {
                    "lstm step: segment weights must be 16-byte aligned");
     }
     T2_REQUIRE(s.h_out != nullptr, "lstm step: h_out required");
+    T2_REQUIRE((!s.xt && !s.ht_out) || (s.wpacked && s.nseg == 1), "lstm step: x16-tiled operands need the packed single-segment path");
+    T2_REQUIRE(!s.xt || t2_aligned16(s.xt), "lstm step: xt must be 16-byte aligned");
+    T2_REQUIRE(!s.ht_out || s.ht_col0 >= 0, "lstm step: ht_col0 must be >= 0");
     return T2_OK;
 }
 
@@ -319,6 +327,9 @@ void to_k(const T2LstmStep& s, LstmK& k, int b0, int bn) {
     k.c_out = s.c_out ? s.c_out + (long)b0 * s.ldc_out : nullptr; k.ldc_out = s.ldc_out;
     k.gates_out = s.gates_out ? s.gates_out + (long)b0 * s.ldg : nullptr; k.ldg = s.ldg;
     k.len = s.len ? s.len + b0 : nullptr; k.t = s.t;
+    k.xt_cs = (long)((s.B + 15) / 16 * 16) * 16;
+    k.xt = s.xt ? s.xt + (long)b0 * 16 : nullptr;
+    k.ht_out = s.ht_out ? s.ht_out + (long)b0 * 16 : nullptr; k.ht_col0 = s.ht_col0;
 }
 
 int launch_fwd(const T2LstmStep* steps, int n, hipStream_t st) {
@@ -373,6 +384,7 @@ struct BwdK {
     float* dg_out; long ldgo;
     float* dg_out2; long ldgo2;
     const int32_t* len; int t;
+    const float* dgt; long dgt_cs; float* dgt_out;   // x16-tiled dg_next / dg_out (chunk stride Bp*16 floats)
 };
 struct BwdK2 { BwdK s[2]; };
 
@@ -539,6 +551,11 @@ __device__ __forceinline__ void bwd_epi_apply(const BwdK& p, const BwdEpi& e, co
                 float* dg2o = p.dg_out2 + (long)b * p.ldgo2 + u;
                 dg2o[0] = d_i; dg2o[H] = d_f; dg2o[2 * H] = d_g; dg2o[3 * H] = d_o;
             }
+            if (p.dgt_out) {   // H % 16 == 0 (checked on the host): the four gate columns share (u & 15)
+                float* dt_ = p.dgt_out + (long)(u >> 4) * p.dgt_cs + b * 16 + (u & 15);
+                const long gs = (long)(H >> 4) * p.dgt_cs;
+                dt_[0] = d_i; dt_[gs] = d_f; dt_[2 * gs] = d_g; dt_[3 * gs] = d_o;
+            }
         }
     }
 }
@@ -553,49 +570,51 @@ __global__ __launch_bounds__(256, 1) void lstm_step_bwd_fast_kernel(BwdK2 pp) {
     if (u0 >= p.ncols) return;   // descriptors of one launch may have different widths (whole workgroup exits)
     const int NCH = (p.N4 + p.N2) >> 4, NCHpad = (NCH + 31) & ~31, G = NCHpad >> 5;
     const float* wb = p.wtpacked + (long)blockIdx.x * NCHpad * 256 + lane * 4;
-    const float* ab = p.dg_next + (long)((b0 + r) < p.B ? (b0 + r) : 0) * p.lddg + 4 * q;
+    // x16-tiled gradients: one contiguous 1 KB block per (chunk, row tile) instead of 16 rows x 64 B
+    const float* ab = p.dgt ? p.dgt + (long)(b0 + r) * 16 + 4 * q
+                            : p.dg_next + (long)((b0 + r) < p.B ? (b0 + r) : 0) * p.lddg + 4 * q;
+    const long acs = p.dgt ? p.dgt_cs : 16;
     const BwdEpi epi = bwd_epi_load(p, tid, u0, b0);   // hoisted: in flight during the GEMM
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     constexpr int U = 8;
-    auto load_group = [&](int g, f32x4 (&a)[U], f32x4 (&b)[U]) {
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const int c = 32 * g + 4 * j + w;
-            const int cx = c < NCH ? c : NCH - 1;   // padding chunks: finite gradients x the zero weight chunk
-            b[j] = *reinterpret_cast<const f32x4*>(wb + (long)c * 256);
-            a[j] = *reinterpret_cast<const f32x4*>(ab + 16 * cx);
-        }
+    auto load_chunk = [&](int g, int j, f32x4& a, f32x4& b) {
+        const int c = 32 * g + 4 * j + w;
+        const int cx = c < NCH ? c : NCH - 1;   // padding chunks: finite gradients x the zero weight chunk
+        b = *reinterpret_cast<const f32x4*>(wb + (long)c * 256);
+        a = *reinterpret_cast<const f32x4*>(ab + acs * cx);
     };
-    auto mma_group = [&](const f32x4 (&a)[U], const f32x4 (&b)[U]) {
+    auto mma_chunk = [&](const f32x4& a, const f32x4& b) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc1, 0, 0, 0);
+    };
+    // chunk-granular software pipeline (see the forward kernel)
+    auto pipe_group = [&](int gl, f32x4 (&aL)[U], f32x4 (&bL)[U], const f32x4 (&aM)[U], const f32x4 (&bM)[U]) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][0], b[j][0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][1], b[j][1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][2], b[j][2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][3], b[j][3], acc1, 0, 0, 0);
+            load_chunk(gl, j, aL[j], bL[j]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_chunk(aM[j], bM[j]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     {
         f32x4 aA[U], bA[U], aB[U], bB[U];
-        load_group(0, aA, bA);
+#pragma unroll
+        for (int j = 0; j < U; ++j) load_chunk(0, j, aA[j], bA[j]);
         int g = 0;
         for (; g + 2 < G; g += 2) {
-            load_group(g + 1, aB, bB);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_group(aA, bA);
-            __builtin_amdgcn_sched_barrier(0);
-            load_group(g + 2, aA, bA);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_group(aB, bB);
-            __builtin_amdgcn_sched_barrier(0);
+            pipe_group(g + 1, aB, bB, aA, bA);
+            pipe_group(g + 2, aA, bA, aB, bB);
         }
         if (g + 1 < G) {
-            load_group(g + 1, aB, bB);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_group(aA, bA);
-            mma_group(aB, bB);
+            pipe_group(g + 1, aB, bB, aA, bA);
+#pragma unroll
+            for (int j = 0; j < U; ++j) mma_chunk(aB[j], bB[j]);
         } else {
-            mma_group(aA, bA);
+#pragma unroll
+            for (int j = 0; j < U; ++j) mma_chunk(aA[j], bA[j]);
         }
     }
 #pragma unroll
@@ -613,6 +632,7 @@ void to_bk(const T2LstmBwdStep& s, BwdK& k) {
     k.dx_out = s.dx_out; k.lddx = s.lddx; k.drop = s.drop; k.lddrop = s.lddrop;
     k.gates = s.gates; k.ldgs = s.ldgs; k.c_prev = s.c_prev; k.ldcp = s.ldcp; k.c_cur = s.c_cur; k.ldcc = s.ldcc;
     k.dc = s.dc; k.lddc = s.lddc; k.dg_out = s.dg_out; k.ldgo = s.ldgo; k.len = s.len; k.t = s.t;
+    k.dgt = s.dgt_next; k.dgt_out = s.dgt_out; k.dgt_cs = (long)((s.B + 15) / 16 * 16) * 16;
 }
 
 int check_bwd(const T2LstmBwdStep& s) {
@@ -638,9 +658,14 @@ int launch_bwd(const T2LstmBwdStep* steps, int n, hipStream_t st) {
     for (int i = 0; i < n; ++i) { T2_TRY(check_bwd(steps[i])); to_bk(steps[i], kk.s[i]); }
     bool fast = true;
     for (int i = 0; i < n; ++i) fast = fast && steps[i].wtpacked && steps[i].dg_next && !steps[i].dg2;
-    if (n == 2) T2_REQUIRE(steps[0].B == steps[1].B && (fast || steps[0].ncols == steps[1].ncols), "lstm bwd step: shapes differ");
-    if (n == 1) kk.s[1] = kk.s[0];
-    const int maxcols = (n == 2 && steps[1].ncols > steps[0].ncols) ? steps[1].ncols : steps[0].ncols;
+    for (int i = 1; i < n; ++i)
+        T2_REQUIRE(steps[0].B == steps[i].B && (fast || steps[0].ncols == steps[i].ncols), "lstm bwd step: shapes differ");
+    for (int i = 0; i < n; ++i)
+        T2_REQUIRE((!steps[i].dgt_next && !steps[i].dgt_out) || (fast && steps[i].H % 16 == 0 && t2_aligned16(steps[i].dgt_next)),
+                   "lstm bwd step: x16-tiled operands need the packed path and H % 16 == 0");
+    for (int i = n; i < 2; ++i) kk.s[i] = kk.s[0];
+    int maxcols = steps[0].ncols;
+    for (int i = 1; i < n; ++i) maxcols = steps[i].ncols > maxcols ? steps[i].ncols : maxcols;
     dim3 grid(t2_cdiv(maxcols, 16), t2_cdiv(steps[0].B, 16), n), block(256);
     if (fast) hipLaunchKernelGGL(lstm_step_bwd_fast_kernel, grid, block, 0, st, kk);
     else hipLaunchKernelGGL(lstm_step_bwd_kernel, grid, block, 0, st, kk);
@@ -699,7 +724,24 @@ inline void adv(T*& p, int64_t inc) { if (p) p += inc; }
 
 }  // namespace
 
-// internal entry used by the attention sequence (t2_attention.hip)
+static void t2_lstm_fwd_advance(T2LstmStep& c, const T2LstmStride& inc) {
+    for (int j = 0; j < 3; ++j) adv(c.seg[j].x, inc.seg_x[j]);
+    adv(c.pre, inc.pre); adv(c.c_prev, inc.c_prev); adv(c.drop, inc.drop);
+    adv(c.h_out, inc.h_out); adv(c.h_out2, inc.h_out2); adv(c.c_out, inc.c_out);
+    adv(c.gates_out, inc.gates_out);
+    adv(c.xt, inc.xt); adv(c.ht_out, inc.ht_out);
+    c.t += inc.dt;
+}
+static void t2_lstm_bwd_advance(T2LstmBwdStep& c, const T2LstmBwdStride& inc) {
+    adv(c.dg_next, inc.dg);
+    adv(c.ext1, inc.ext1); adv(c.ext2, inc.ext2); adv(c.drop, inc.drop);
+    adv(c.gates, inc.gates); adv(c.c_prev, inc.c_prev); adv(c.c_cur, inc.c_cur);
+    adv(c.dg_out, inc.dg);
+    adv(c.dg_out2, inc.dg2);
+    adv(c.dgt_next, inc.dgt); adv(c.dgt_out, inc.dgt);
+    c.t += inc.dt;
+}
+// internal entries used by the attention sequence (t2_attention.hip)
 int t2_lstm_step_fwd_launch(const T2LstmStep* steps, int n, hipStream_t st) { return launch_fwd(steps, n, st); }
 int t2_lstm_step_bwd_launch(const T2LstmBwdStep* steps, int n, hipStream_t st) { return launch_bwd(steps, n, st); }
 
@@ -719,13 +761,7 @@ extern "C" int t2_lstm_seq_fwd(const T2LstmStep* base, const T2LstmStride* inc, 
     for (int i = 0; i < n; ++i) cur[i] = base[i];
     for (int s = 0; s < S; ++s) {
         T2_TRY(launch_fwd(cur, n, (hipStream_t)stream));
-        for (int i = 0; i < n; ++i) {
-            for (int j = 0; j < 3; ++j) adv(cur[i].seg[j].x, inc[i].seg_x[j]);
-            adv(cur[i].pre, inc[i].pre); adv(cur[i].c_prev, inc[i].c_prev); adv(cur[i].drop, inc[i].drop);
-            adv(cur[i].h_out, inc[i].h_out); adv(cur[i].h_out2, inc[i].h_out2); adv(cur[i].c_out, inc[i].c_out);
-            adv(cur[i].gates_out, inc[i].gates_out);
-            cur[i].t += inc[i].dt;
-        }
+        for (int i = 0; i < n; ++i) t2_lstm_fwd_advance(cur[i], inc[i]);
     }
     return T2_OK;
 }
@@ -736,14 +772,7 @@ extern "C" int t2_lstm_seq_bwd(const T2LstmBwdStep* base, const T2LstmBwdStride*
     for (int i = 0; i < n; ++i) cur[i] = base[i];
     for (int s = 0; s < S; ++s) {
         T2_TRY(launch_bwd(cur, n, (hipStream_t)stream));
-        for (int i = 0; i < n; ++i) {
-            adv(cur[i].dg_next, inc[i].dg);
-            adv(cur[i].ext1, inc[i].ext1); adv(cur[i].ext2, inc[i].ext2); adv(cur[i].drop, inc[i].drop);
-            adv(cur[i].gates, inc[i].gates); adv(cur[i].c_prev, inc[i].c_prev); adv(cur[i].c_cur, inc[i].c_cur);
-            adv(cur[i].dg_out, inc[i].dg);
-            adv(cur[i].dg_out2, inc[i].dg2);
-            cur[i].t += inc[i].dt;
-        }
+        for (int i = 0; i < n; ++i) t2_lstm_bwd_advance(cur[i], inc[i]);
     }
     return T2_OK;
 }

@@ -287,6 +287,13 @@ class Engine:
         cum[0].zero_()
         xproj = self.buf("xproj", T + 1, B, D + Ef)
         xproj[0].zero_()
+        # x16-tiled copies of the recurrent inputs ([K/16][Bp][16] per slot): the step kernels' activation loads become
+        # contiguous 1 KB blocks (include/tacotron2_amd.h, T2LstmStep.xt)
+        Bp = (B + 15) // 16 * 16
+        xdec_t = self.buf("xdec_t", T + 1, (A + Ef) // 16, Bp, 16, zero=(B != Bp))
+        xdec_t[0].zero_()
+        dech_t = self.buf("dech_t", T + 1, D // 16, Bp, 16, zero=(B != Bp))
+        dech_t[0].zero_()
         gates_att = self.buf("gates_att", T, B, 4 * A) if save_for_backward else None
         th = self.buf("th", T, B, Ad, L) if save_for_backward else None
         align = torch.empty(B, T, L, dtype=torch.float32, device=self.dev)
@@ -299,7 +306,7 @@ class Engine:
                    W_hh=P["decoder.att_rnn.weight_hh"], Wq=P["decoder.attention.query_layer.weight"], U=U,
                    v=P["decoder.attention.v.weight"], pre=pre_att, pmT=pmT, memory=memory, len=len32,
                    att_drop=masks.get("att_drop"), xdec=xdec, att_c=att_c, gates=gates_att, align=align, cum=cum, th=th,
-                   xproj_ctx=_ptr(xproj, B * (D + Ef) + D), ld_xproj=D + Ef, e_part=e_part)
+                   xproj_ctx=_ptr(xproj, B * (D + Ef) + D), ld_xproj=D + Ef, e_part=e_part, xdec_t=xdec_t)
         # decoder-LSTM chain operands (prepared before the pipeline below)
         pre_dec = self.buf("pre_dec", T, B, 4 * D)
         dec_c = self.buf("dec_c", T + 1, B, D)
@@ -308,12 +315,34 @@ class Engine:
         dd = masks.get("dec_drop")
         ldp = D + Ef
         wp_dec = self.pack_fwd("dec", [(P["decoder.lstm.weight_hh"], D, D)], D)
-        # Two-stream pipeline over chunks of frames: the attention chain of chunk c+1 (main stream) overlaps the hoisted
-        # input projection + decoder-LSTM chain of chunk c (side stream); in teacher-forced mode the attention chain never
-        # reads the decoder LSTM (model/decoder.py:70-101), so the only dependency is chunk c -> chunk c.
+        # Two-stream pipeline over chunks of CH frames: the attention chain of chunk c+1 (main stream) runs while the hoisted
+        # input-projection GEMM + decoder-LSTM chain of chunk c sit on the side stream; in teacher-forced mode the attention
+        # chain never reads the decoder LSTM (model/decoder.py:70-101), so the only dependency is chunk c -> chunk c.
+        # Measured (tools/ubench_cell.hip, profiles/): step kernels of the two streams do NOT overlap each other (each
+        # saturates the per-CU miss queue; two cells sharing one launch take exactly the sum), but the large GEMMs of
+        # the side stream do fill the latency gaps of the main stream's chain.
+        CH = self.chunk
+
+        def dec_chunk(c0, c1):
+            stp = make("T2LstmStep", B=B, H=D, nseg=1, wpacked=wp_dec, pre=_ptr(pre_dec, c0 * B * 4 * D), ldpre=4 * D,
+                       c_prev=_ptr(dec_c, c0 * B * D), ldc_prev=D,
+                       drop=_ptr(dd, c0 * B * D) if dd is not None else None, lddrop=D,
+                       h_out=_ptr(xproj, (c0 + 1) * B * ldp), ldh=ldp, c_out=_ptr(dec_c, (c0 + 1) * B * D), ldc_out=D,
+                       gates_out=_ptr(gates_dec, c0 * B * 4 * D) if gates_dec is not None else None, ldg=4 * D,
+                       xt=_ptr(dech_t, c0 * D * Bp), ht_out=_ptr(dech_t, (c0 + 1) * D * Bp), ht_col0=0)
+            stp.seg[0].x = _ptr(xproj, c0 * B * ldp); stp.seg[0].ldx = ldp
+            stp.seg[0].w = P["decoder.lstm.weight_hh"].data_ptr(); stp.seg[0].ldw = D; stp.seg[0].K = D
+            inc = make("T2LstmStride", pre=B * 4 * D, c_prev=B * D, drop=B * D, h_out=B * ldp, c_out=B * D,
+                       gates_out=B * 4 * D, dt=0, xt=D * Bp, ht_out=D * Bp)
+            inc.seg_x[0] = B * ldp
+            return stp, inc
+
+        def pre_dec_gemm(c0, c1):
+            gemm(_ptr(xdec, (c0 + 1) * B * (A + Ef)), P["decoder.lstm.weight_ih"], _ptr(pre_dec, c0 * B * 4 * D), (c1 - c0) * B,
+                 4 * D, A + Ef, A + Ef, A + Ef, 4 * D, bias=P["decoder.lstm.bias_ih"], bias2=P["decoder.lstm.bias_hh"])
+
         main, side = torch.cuda.current_stream(), self.side_stream()
         side.wait_stream(main)
-        CH = self.chunk
         for c0 in range(0, T, CH):
             c1 = min(T, c0 + CH)
             seq.t_begin, seq.t_end = c0, c1
@@ -321,20 +350,9 @@ class Engine:
             ev = main.record_event()
             with torch.cuda.stream(side):
                 side.wait_event(ev)
-                n = c1 - c0
-                gemm(_ptr(xdec, (c0 + 1) * B * (A + Ef)), P["decoder.lstm.weight_ih"], _ptr(pre_dec, c0 * B * 4 * D), n * B,
-                     4 * D, A + Ef, A + Ef, A + Ef, 4 * D, bias=P["decoder.lstm.bias_ih"], bias2=P["decoder.lstm.bias_hh"])
-                stp = make("T2LstmStep", B=B, H=D, nseg=1, wpacked=wp_dec, pre=_ptr(pre_dec, c0 * B * 4 * D), ldpre=4 * D,
-                           c_prev=_ptr(dec_c, c0 * B * D), ldc_prev=D,
-                           drop=_ptr(dd, c0 * B * D) if dd is not None else None, lddrop=D,
-                           h_out=_ptr(xproj, (c0 + 1) * B * ldp), ldh=ldp, c_out=_ptr(dec_c, (c0 + 1) * B * D), ldc_out=D,
-                           gates_out=_ptr(gates_dec, c0 * B * 4 * D) if gates_dec is not None else None, ldg=4 * D)
-                stp.seg[0].x = _ptr(xproj, c0 * B * ldp); stp.seg[0].ldx = ldp
-                stp.seg[0].w = P["decoder.lstm.weight_hh"].data_ptr(); stp.seg[0].ldw = D; stp.seg[0].K = D
-                inc = make("T2LstmStride", pre=B * 4 * D, c_prev=B * D, drop=B * D, h_out=B * ldp, c_out=B * D,
-                           gates_out=B * 4 * D, dt=0)
-                inc.seg_x[0] = B * ldp
-                call("t2_lstm_seq_fwd", stp, inc, 1, n, side.cuda_stream)
+                pre_dec_gemm(c0, c1)
+                stp, inc = dec_chunk(c0, c1)
+                call("t2_lstm_seq_fwd", stp, inc, 1, c1 - c0, side.cuda_stream)
         self.mark("fwd.dec.attn_chain")
         main.wait_stream(side)
         self.mark("fwd.dec.lstm_chain_tail")
@@ -447,6 +465,12 @@ class Engine:
         # decoder chain overlaps chunk k of the attention chain; the decoder weight-gradient GEMMs overlap the tail.
         dgd = self.buf("dgd", T + 1, B, 4 * D)
         dgd[T].zero_()
+        # x16-tiled copies of the gate gradients (A operands of the per-frame backward products; T2LstmBwdStep.dgt_next)
+        Bp = (B + 15) // 16 * 16
+        dgd_t = self.buf("dgd_t", T + 1, 4 * D // 16, Bp, 16)
+        dgd_t[T].zero_()
+        Zt = self.buf("Zatt_t", T + 1, 4 * A // 16, Bp, 16)
+        Zt[T].zero_()
         dc_dec = self.buf("dc_dec", B, D, zero=True)
         dd = masks.get("dec_drop")
         wtp_dec = self.pack_bwd("dec.t", P["decoder.lstm.weight_hh"], D, 4 * D, D)
@@ -476,27 +500,35 @@ class Engine:
                   cum=ctx["cum"], th=ctx["th"], att_drop=masks.get("att_drop"),
                   dh_ext=dxdec, ld_dh=ldx, dctx_ext1=_ptr(dxdec, A), ld_dc1=ldx, dctx_ext2=_ptr(dxproj, D), ld_dc2=ldp,
                   dgates=Z, dctx_tot=dctx_tot, dq=None, dpmT=dpmT, dv_part=dv_part, dU_part=dU_part,
-                  dc=dc_att, G=Gc, de=de, din_part=din_part)
+                  dc=dc_att, G=Gc, de=de, din_part=din_part, dgates_t=Zt)
         self.mark("bwd.dec.proj")
         main, side = torch.cuda.current_stream(), self.side_stream()
         side.wait_stream(main)
         CH = self.chunk
+
+        def dec_bwd_chunk(hi, lo):
+            s = make("T2LstmBwdStep", B=B, H=D, N4=4 * D, dg_next=_ptr(dgd, hi * B * 4 * D), lddg=4 * D,
+                     W=P["decoder.lstm.weight_hh"], ldw=D, wtpacked=wtp_dec, ncols=D, epi=1,
+                     ext1=_ptr(dxproj, (hi - 1) * B * ldp), ldx1=ldp,
+                     drop=_ptr(dd, (hi - 1) * B * D) if dd is not None else None, lddrop=D,
+                     gates=_ptr(ctx["gates_dec"], (hi - 1) * B * 4 * D), ldgs=4 * D,
+                     c_prev=_ptr(ctx["dec_c"], (hi - 1) * B * D), ldcp=D, c_cur=_ptr(ctx["dec_c"], hi * B * D), ldcc=D,
+                     dc=dc_dec, lddc=D, dg_out=_ptr(dgd, (hi - 1) * B * 4 * D), ldgo=4 * D,
+                     dgt_next=_ptr(dgd_t, hi * Bp * 4 * D), dgt_out=_ptr(dgd_t, (hi - 1) * Bp * 4 * D))
+            inc = make("T2LstmBwdStride", dg=-B * 4 * D, ext1=-B * ldp, drop=-B * D, gates=-B * 4 * D, c_prev=-B * D,
+                       c_cur=-B * D, dt=0, dgt=-Bp * 4 * D)
+            return s, inc
+
+        def dxdec_gemm(hi, lo):
+            gemm(_ptr(dgd, lo * B * 4 * D), P["decoder.lstm.weight_ih"], _ptr(dxdec, lo * B * ldx), (hi - lo) * B, ldx, 4 * D,
+                 4 * D, ldx, ldx, a_k=1, b_k=0)
+
         for hi in range(T, 0, -CH):
             lo = max(0, hi - CH)
-            n = hi - lo
             with torch.cuda.stream(side):
-                s = make("T2LstmBwdStep", B=B, H=D, N4=4 * D, dg_next=_ptr(dgd, hi * B * 4 * D), lddg=4 * D,
-                         W=P["decoder.lstm.weight_hh"], ldw=D, wtpacked=wtp_dec, ncols=D, epi=1,
-                         ext1=_ptr(dxproj, (hi - 1) * B * ldp), ldx1=ldp,
-                         drop=_ptr(dd, (hi - 1) * B * D) if dd is not None else None, lddrop=D,
-                         gates=_ptr(ctx["gates_dec"], (hi - 1) * B * 4 * D), ldgs=4 * D,
-                         c_prev=_ptr(ctx["dec_c"], (hi - 1) * B * D), ldcp=D, c_cur=_ptr(ctx["dec_c"], hi * B * D), ldcc=D,
-                         dc=dc_dec, lddc=D, dg_out=_ptr(dgd, (hi - 1) * B * 4 * D), ldgo=4 * D)
-                inc = make("T2LstmBwdStride", dg=-B * 4 * D, ext1=-B * ldp, drop=-B * D, gates=-B * 4 * D, c_prev=-B * D,
-                           c_cur=-B * D, dt=0)
-                call("t2_lstm_seq_bwd", s, inc, 1, n, side.cuda_stream)
-                gemm(_ptr(dgd, lo * B * 4 * D), P["decoder.lstm.weight_ih"], _ptr(dxdec, lo * B * ldx), n * B, ldx, 4 * D,
-                     4 * D, ldx, ldx, a_k=1, b_k=0)
+                s, inc = dec_bwd_chunk(hi, lo)
+                call("t2_lstm_seq_bwd", s, inc, 1, hi - lo, side.cuda_stream)
+                dxdec_gemm(hi, lo)
                 ev = side.record_event()
             main.wait_event(ev)
             sb.t_hi, sb.t_lo = hi, lo
