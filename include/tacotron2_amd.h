@@ -191,6 +191,13 @@ typedef struct {
     int t_begin, t_end;              /* frame range [t_begin, t_end) of this call; 0,0 = all T frames */
     float* xdec_t;                   /* optional (with wpacked): x16-tiled copy of xdec, [T+1][(A+Ef)/16][Bp][16], slot 0
                                         zero-filled by the caller; the attention-LSTM step then reads its input from it */
+    /* Optional co-scheduled recurrence: step i of an independent LSTM sequence (the decoder LSTM of an EARLIER chunk of
+     * frames, whose hoisted input projection is already computed) runs INSIDE the attention-context launch of frame
+     * t_begin+i (heterogeneous launch: extra workgroups next to the context workgroups).  Dependent launches cost ~2.7 us +
+     * a memory round trip each and kernels of two streams do not overlap at this size; a cell step (MFMA + weight
+     * stream) next to the latency-bound context kernel uses otherwise idle pipes.  Needs the packed single-segment path and
+     * co_step->B <= 32 (else, and for steps beyond the frame range, the steps run as plain launches). */
+    const T2LstmStep* co_step; const T2LstmStride* co_inc; int co_steps;
 } T2AttnSeq;
 int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream);
 

@@ -35,9 +35,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s) + ".o")
         objs.append(o)
+        hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".hpp")]
         if not force and os.path.exists(o) and os.path.getmtime(o) > max(
-                os.path.getmtime(s), os.path.getmtime(os.path.join(CSRC, "t2_common.hpp")),
-                os.path.getmtime(os.path.join(HERE, "..", "include", "tacotron2_amd.h"))):
+                [os.path.getmtime(s), os.path.getmtime(os.path.join(HERE, "..", "include", "tacotron2_amd.h"))] +
+                [os.path.getmtime(h) for h in hdrs]):
             continue
         cmd = [hipcc] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", s, "-o", o]
         if verbose:

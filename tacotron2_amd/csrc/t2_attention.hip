@@ -16,9 +16,11 @@
 //     context[b][e] = sum_l w[l] * memory[b][l][e]  (128-byte coalesced rows), slice 0 also writes the new
 //     weights (the alignments row) and cumulative weights.
 #include "t2_common.hpp"
+#include "t2_lstm_step.hpp"
 
 int t2_lstm_step_fwd_launch(const T2LstmStep* steps, int n, hipStream_t st);
 int t2_lstm_step_bwd_launch(const T2LstmBwdStep* steps, int n, hipStream_t st);
+void t2_lstm_fwd_advance(T2LstmStep& c, const T2LstmStride& inc);
 
 namespace {
 
@@ -100,9 +102,8 @@ __device__ __forceinline__ void load_taps(const float* Us, int al, float (&uk)[2
     }
 }
 
-__global__ __launch_bounds__(ENT, 2) void attn_energy_kernel(AttnK p) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int b = blockIdx.x, j = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+__device__ __forceinline__ void attn_energy_body(const AttnK& p, const int b, const int j, float* sm) {
+    const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
     const int al = tid >> 5, sub = tid & 31, a = j * 16 + al;
     const int L = p.L, NG = (L + 3) >> 2, Lp = 4 * NG + 36;
@@ -198,13 +199,18 @@ __global__ __launch_bounds__(ENT, 2) void attn_energy_kernel(AttnK p) {
         float s = 0.f;
 #pragma unroll
         for (int al2 = 0; al2 < 16; ++al2) s += ec[al2 * 4 * NG + l];
-        p.e_part[((long)b * gridDim.y + j) * L + l] = s;
+        p.e_part[((long)b * (p.Ad >> 4) + j) * L + l] = s;
     }
 }
 
-__global__ __launch_bounds__(256, 1) void attn_context_kernel(AttnK p) {
+__global__ __launch_bounds__(ENT, 2) void attn_energy_kernel(AttnK p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int b = blockIdx.x, es0 = blockIdx.y * 32, tid = threadIdx.x;
+    attn_energy_body(p, blockIdx.x, blockIdx.y, sm);
+}
+
+
+__device__ __forceinline__ void attn_context_body(const AttnK& p, const int b, const int es0, float* sm) {
+    const int tid = threadIdx.x;
     const int L = p.L, NA = p.Ad >> 4;
     float* ws = sm;                       // [L rounded to 4]
     float* red = ws + ((L + 3) & ~3);     // [8]
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(256, 1) void attn_context_kernel(AttnK p) {
         }
     }
     float cprev[2] = {0.f, 0.f};   // previous cumulative weights for the (<= 2) positions this thread writes
-    if (blockIdx.y == 0 && p.cum_prev) {
+    if (es0 == 0 && p.cum_prev) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) cprev[r] = p.cum_prev[(long)b * p.ldcum + imin(tid + 256 * r, L - 1)];
     }
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(256, 1) void attn_context_kernel(AttnK p) {
     for (int l = tid, r = 0; l < L; l += 256, ++r) {
         const float wv = ws[l] / sum;
         ws[l] = wv;
-        if (blockIdx.y == 0) {
+        if (es0 == 0) {
             p.w_out[(long)b * p.ldwo + l] = wv;
             if (p.cum_out) {
                 const float cp = r < 2 ? cprev[r] : (p.cum_prev ? p.cum_prev[(long)b * p.ldcum + l] : 0.f);
@@ -278,6 +284,22 @@ __global__ __launch_bounds__(256, 1) void attn_context_kernel(AttnK p) {
         if (p.ctx_out2) p.ctx_out2[(long)b * p.ldctx2 + es0 + tid] = s2;
         if (p.ctxt_out) { const int col = p.ctxt_col0 + es0 + tid; p.ctxt_out[(long)(col >> 4) * p.ctxt_cs + b * 16 + (col & 15)] = s2; }
     }
+}
+
+__global__ __launch_bounds__(256, 1) void attn_context_kernel(AttnK p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    attn_context_body(p, blockIdx.x, blockIdx.y * 32, sm);
+}
+
+// Heterogeneous launch: workgroups [0, nC) are the context workgroups (b = id % B, column slice id / B), workgroups
+// [nC, nC + H/4) run one step of a co-scheduled LSTM cell (t2_lstm_step.hpp).  3 waves per SIMD (<= 168 VGPRs) so that two
+// context workgroups and one cell workgroup fit on a CU.
+template <int MT>
+__global__ __launch_bounds__(256, 3) void attn_context_co_kernel(AttnK p, LstmK c, int nC) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int bid = blockIdx.x;
+    if (bid < nC) attn_context_body(p, bid % p.B, (bid / p.B) * 32, sm);
+    else t2_lstm_fwd_fast_body<MT, 4>(c, bid - nC, sm);
 }
 
 // U[a][c][k] = sum_f Wd[a][f] * Wc[f][c][k]
@@ -309,14 +331,27 @@ void to_ak(const T2AttnStep& s, AttnK& k) {
     k.ctxt_out = s.ctxt_out; k.ctxt_col0 = s.ctxt_col0; k.ctxt_cs = (long)((s.B + 15) / 16 * 16) * 16;
 }
 
-int launch_attn(const T2AttnStep& s, hipStream_t st) {
+// A cell step can ride in the context launch if it takes the packed single-segment path with <= 32 batch rows.
+bool co_eligible(const T2LstmStep& c) { return c.wpacked && c.nseg == 1 && c.B <= 32 && c.H % 4 == 0; }
+
+int launch_attn(const T2AttnStep& s, hipStream_t st, const T2LstmStep* co = nullptr) {
     AttnK k;
     to_ak(s, k);
     const int NG = (s.L + 3) >> 2, Lp = 4 * NG + 36;
     const size_t sm_e = (size_t)(2 * Lp + 16 * 64 + 16 + 16 * 4 * NG) * sizeof(float);
     const size_t sm_c = (size_t)(((s.L + 3) & ~3) + 8 + 256) * sizeof(float);
     hipLaunchKernelGGL(attn_energy_kernel, dim3(s.B, s.Ad / 16), dim3(ENT), sm_e, st, k);
-    hipLaunchKernelGGL(attn_context_kernel, dim3(s.B, s.Ef / 32), dim3(256), sm_c, st, k);
+    if (co) {
+        T2_TRY(t2_lstm_check_step(*co));
+        LstmK ck;
+        t2_lstm_to_k(*co, ck, 0, co->B);
+        const int MT = co->B <= 16 ? 1 : 2, nC = s.B * (s.Ef / 32);
+        const size_t sm_co = (size_t)4 * MT * 256 * sizeof(float), smx = sm_c > sm_co ? sm_c : sm_co;
+        if (MT == 1) hipLaunchKernelGGL(attn_context_co_kernel<1>, dim3(nC + co->H / 4), dim3(256), smx, st, k, ck, nC);
+        else hipLaunchKernelGGL(attn_context_co_kernel<2>, dim3(nC + co->H / 4), dim3(256), smx, st, k, ck, nC);
+    } else {
+        hipLaunchKernelGGL(attn_context_kernel, dim3(s.B, s.Ef / 32), dim3(256), sm_c, st, k);
+    }
     T2_CHECK_LAUNCH();
     return T2_OK;
 }
@@ -351,6 +386,13 @@ extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
     const int tb = (a->t_begin == 0 && a->t_end == 0) ? 0 : a->t_begin, te = (a->t_begin == 0 && a->t_end == 0) ? T : a->t_end;
     T2_REQUIRE(tb >= 0 && te <= T && tb <= te, "t2_attn_seq_fwd: bad frame range");
     T2_REQUIRE(!a->xdec_t || (a->wpacked && (A + Ef) % 16 == 0 && A % 16 == 0), "t2_attn_seq_fwd: xdec_t needs wpacked and A, Ef multiples of 16");
+    T2LstmStep co;
+    int co_left = 0;
+    bool co_ride = false;
+    if (a->co_step && a->co_steps > 0) {
+        T2_REQUIRE(a->co_inc != nullptr, "t2_attn_seq_fwd: co_inc required with co_step");
+        co = *a->co_step; co_left = a->co_steps; co_ride = co_eligible(co);
+    }
     for (int t = tb; t < te; ++t) {
         T2LstmStep s;
         memset(&s, 0, sizeof(s));
@@ -390,7 +432,16 @@ extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
         if (a->xproj_ctx) { q.ctx_out2 = a->xproj_ctx + (long)t * B * a->ld_xproj; q.ldctx2 = a->ld_xproj; }
         if (a->xdec_t) { q.ctxt_out = a->xdec_t + (long)(t + 1) * xts; q.ctxt_col0 = A; }
         if (t == tb) T2_TRY(check_attn(q));
-        T2_TRY(launch_attn(q, st));
+        if (co_left > 0 && co_ride) {
+            T2_TRY(launch_attn(q, st, &co));
+            t2_lstm_fwd_advance(co, *a->co_inc); --co_left;
+        } else {
+            T2_TRY(launch_attn(q, st));
+        }
+    }
+    for (; co_left > 0; --co_left) {   // co-scheduled steps that did not ride in an energy launch
+        T2_TRY(t2_lstm_step_fwd_launch(&co, 1, st));
+        t2_lstm_fwd_advance(co, *a->co_inc);
     }
     return T2_OK;
 }

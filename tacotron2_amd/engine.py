@@ -58,6 +58,10 @@ class Engine:
         self._ws: Dict[str, torch.Tensor] = {}
         self._side = None
         self.chunk = 64               # frames per pipeline chunk (two-stream overlap of the two recurrences)
+        self.co_schedule = True       # decoder-LSTM steps ride in the attention-context launches (T2AttnSeq.co_step)
+        import os as _os               # tuning overrides for experiments (tools/): T2_CHUNK, T2_CO_SCHEDULE
+        self.chunk = int(_os.environ.get("T2_CHUNK", self.chunk))
+        self.co_schedule = _os.environ.get("T2_CO_SCHEDULE", "1") != "0"
         self.profile = False          # when True, mark() records HIP events at segment boundaries
         self.marks = []               # [(name, event)] of the current step
 
@@ -315,12 +319,13 @@ class Engine:
         dd = masks.get("dec_drop")
         ldp = D + Ef
         wp_dec = self.pack_fwd("dec", [(P["decoder.lstm.weight_hh"], D, D)], D)
-        # Two-stream pipeline over chunks of CH frames: the attention chain of chunk c+1 (main stream) runs while the hoisted
-        # input-projection GEMM + decoder-LSTM chain of chunk c sit on the side stream; in teacher-forced mode the attention
-        # chain never reads the decoder LSTM (model/decoder.py:70-101), so the only dependency is chunk c -> chunk c.
-        # Measured (tools/ubench_cell.hip, profiles/): step kernels of the two streams do NOT overlap each other (each
-        # saturates the per-CU miss queue; two cells sharing one launch take exactly the sum), but the large GEMMs of
-        # the side stream do fill the latency gaps of the main stream's chain.
+        # Software pipeline over chunks of CH frames.  In teacher-forced mode the attention chain never reads the decoder
+        # LSTM (model/decoder.py:70-101), so the decoder-LSTM chain of chunk i-2 is CO-SCHEDULED inside the attention
+        # chain of chunk i: its step rides in the attention-context launch of a frame (extra workgroups in the same
+        # launch, T2AttnSeq.co_step), and the hoisted input-projection GEMM of chunk i-1 runs meanwhile on the side stream.
+        # Measured (tools/ubench_cell.hip, profiles/): step kernels of two streams do NOT overlap each other and two cells
+        # in one launch take the sum of their times, but a cell step next to the latency-bound context workgroups does
+        # overlap, and the large side-stream GEMMs fill the gaps of the main chain.
         CH = self.chunk
 
         def dec_chunk(c0, c1):
@@ -343,18 +348,32 @@ class Engine:
 
         main, side = torch.cuda.current_stream(), self.side_stream()
         side.wait_stream(main)
-        for c0 in range(0, T, CH):
-            c1 = min(T, c0 + CH)
+        import ctypes as _C
+        chunks = [(c0, min(T, c0 + CH)) for c0 in range(0, T, CH)]
+        co = B <= 32 and self.co_schedule     # co-scheduling needs <= 32 batch rows; otherwise plain two-stream pipeline
+        for i, (c0, c1) in enumerate(chunks):
             seq.t_begin, seq.t_end = c0, c1
+            if co and i >= 1:
+                stp, inc = dec_chunk(*chunks[i - 1])
+                seq.co_step, seq.co_inc = _C.pointer(stp), _C.pointer(inc)
+                seq.co_steps = chunks[i - 1][1] - chunks[i - 1][0]
+            else:
+                seq.co_step, seq.co_inc, seq.co_steps = None, None, 0
             call("t2_attn_seq_fwd", seq, st)
-            ev = main.record_event()
-            with torch.cuda.stream(side):
-                side.wait_event(ev)
+            if co:
                 pre_dec_gemm(c0, c1)
-                stp, inc = dec_chunk(c0, c1)
-                call("t2_lstm_seq_fwd", stp, inc, 1, c1 - c0, side.cuda_stream)
+            else:
+                ev = main.record_event()
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    pre_dec_gemm(c0, c1)
+                    stp, inc = dec_chunk(c0, c1)
+                    call("t2_lstm_seq_fwd", stp, inc, 1, c1 - c0, side.cuda_stream)
         self.mark("fwd.dec.attn_chain")
         main.wait_stream(side)
+        if co:                                  # drain: the last decoder-LSTM chunk
+            stp, inc = dec_chunk(*chunks[-1])
+            call("t2_lstm_seq_fwd", stp, inc, 1, chunks[-1][1] - chunks[-1][0], st)
         self.mark("fwd.dec.lstm_chain_tail")
 
         # mel + stop projection over all frames: [mel_out.weight ; gate.weight] is one (M+1, D+Ef) matrix

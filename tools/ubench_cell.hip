@@ -132,6 +132,81 @@ __global__ __launch_bounds__(256, 1) void cell_pipe_kernel(const float* __restri
   }
 }
 
+// Heterogeneous launch: workgroups [0, nE) run a VALU/latency-bound body shaped like the attention-energy kernel
+// (64 KB of L2-resident loads, ~600 dependent-free FMAs per thread, one store), workgroups [nE, nE+nC) run the cell loop
+// with 8 waves.  Do the two kinds overlap on a CU, or do they add up like two cells in one launch?
+template <int NCH>
+__global__ __launch_bounds__(512, 2) void hetero_kernel(const float* __restrict__ W, const float* __restrict__ X, const float* __restrict__ Q,
+                                                        float* out, int K, int nE) {
+  __shared__ float red[8 * 2 * 256];
+  const int tid = threadIdx.x, lane = tid & 63;
+  if ((int)blockIdx.x < nE) {
+    const float4* q = reinterpret_cast<const float4*>(Q) + (size_t)(blockIdx.x & 7) * 4096 + tid;
+    float4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = q[i * 512];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { acc[0] += v[i].x; acc[1] += v[i].y; acc[2] += v[i].z; acc[3] += v[i].w; }
+    float t0 = acc[0], t1 = acc[1], t2 = acc[2], t3 = acc[3];
+#pragma unroll 16
+    for (int k = 0; k < 160; ++k) {
+      t0 = fmaf(t0, 1.0001f, acc[1]); t1 = fmaf(t1, 0.9999f, acc[2]); t2 = fmaf(t2, 1.0002f, acc[3]); t3 = fmaf(t3, 0.9998f, acc[0]);
+    }
+    red[tid] = t0 + t1 + t2 + t3;
+    __syncthreads();
+    if (tid < 64) out[(size_t)blockIdx.x * 64 + tid] = red[tid] + red[tid + 64];
+    return;
+  }
+  const int bx = blockIdx.x - nE;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const float* wb = W + (long)bx * (NCH * 8) * 256 + lane * 4;
+  const float* xb[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) xb[m] = X + (long)m * 16 * K + lane * 4;
+  f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  f32x4 bw[NCH], ax[NCH][2];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int c = 8 * j + w;
+    bw[j] = *reinterpret_cast<const f32x4*>(wb + (long)c * 256);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) ax[j][m] = *reinterpret_cast<const f32x4*>(xb[m] + 256 * c);
+  }
+#pragma unroll
+  for (int j = 0; j < NCH; ++j)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[j][m][s], bw[j][s], acc[m], 0, 0, 0);
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) red[((w * 2 + m) * 16 + (q * 4 + g)) * 16 + r] = acc[m][g];
+  __syncthreads();
+  if (tid < 256) {
+    float s = 0.f;
+    for (int ww = 0; ww < 8; ++ww) s += red[ww * 512 + tid];
+    out[(size_t)nE * 64 + (long)bx * 256 + tid] = s;
+  }
+}
+
+template <int NCH>
+void run_hetero(const char* name, const float* W, const float* X, float* out, hipStream_t st, float base, int nE, int nC) {
+  const int K = 8 * NCH * 16, iters = 500;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float ms = 0;
+  for (int rep = 0; rep < 2; ++rep) {
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((hetero_kernel<NCH>), dim3(nE + nC), dim3(512), 0, st, W, X, X, out, K, nE);
+    CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+  }
+  CK(hipGetLastError());
+  printf("%-44s K=%4d nE=%3d nC=%3d : %6.2f us (%.2f over empty)\n", name, K, nE, nC, ms * 1e3 / iters, ms * 1e3 / iters - base);
+  fflush(stdout);
+}
+
 template <int NCH, int MT, int SCHED>
 void run_pipe(const char* name, const float* W, const float* X, float* out, hipStream_t st, float base, int nwg = 256) {
   const int K = 4 * NCH * 16, iters = 500;
@@ -185,6 +260,11 @@ int main() {
   run_pipe<24, 2, 1>("per-chunk pipeline, 2 WGs per CU", W, X, out, st, base, 512);
   run_pipe<24, 1, 0>("tiled, grouped", W, X, out, st, base);
   run_pipe<24, 1, 1>("tiled, per-chunk software pipeline", W, X, out, st, base);
+  run_hetero<8>("hetero: VALU-type only", W, X, out, st, base, 256, 0);
+  run_hetero<8>("hetero: cell-type only (8 waves)", W, X, out, st, base, 0, 256);
+  run_hetero<8>("hetero: both kinds in one launch", W, X, out, st, base, 256, 256);
+  run_hetero<12>("hetero: cell-type only (8 waves)", W, X, out, st, base, 0, 256);
+  run_hetero<12>("hetero: both kinds in one launch", W, X, out, st, base, 256, 256);
   // two-stream concurrency: the same chain of launches on one stream, and split over two streams
   {
     hipStream_t s2; CK(hipStreamCreate(&s2));

@@ -76,8 +76,7 @@ def main():
         call("t2_lstm_step_fwd", sT, 1, st); torch.cuda.synchronize()
         _lib.lib().t2_debug_clock(0, out8)
         ck = [out8[i] for i in range(8)]
-        stamps = "clk(main loop, +sync, +epilogue) = %d %d %d cycles; realtime %d %d %d x10ns" % (
-            ck[2] - ck[0], ck[4] - ck[0], ck[6] - ck[0], ck[3] - ck[1], ck[5] - ck[1], ck[7] - ck[1])
+        stamps = "in-kernel entry->exit = %d shader cycles, %d x10ns" % (ck[6] - ck[0], ck[7] - ck[1])
         wmb = 4 * H * K * 4 / 1e6
         print(f"B={B} H={H} K={K} weights {wmb:.1f} MB | A same-step {tA:.2f} us | B recurrence {tB:.2f} us | C two cells alternating {tC:.2f} us | tiled same-step {tT:.2f} us | {stamps}", flush=True)
 
