@@ -33,7 +33,8 @@ extern "C" {
 const char* t2_last_error(void);
 int t2_version(void);
 int t2_sizeof(const char* struct_name); /* sizeof of an ABI struct by name, -1 if unknown */
-/* diagnostic: enable/disable in-kernel clock stamps of the LSTM step kernel, read back 8 words (memtime, memrealtime) x 4 */
+/* diagnostic: enable/disable in-kernel clock stamps of the packed LSTM step kernel and read back 8 words: [0],[1] =
+ * (s_memtime, s_memrealtime) at kernel entry of workgroup 0, [6],[7] = the same at its exit; [2..5] unused */
 int t2_debug_clock(int enable, uint64_t* out8);
 
 /* ------------------------------------------------------------------------------------------------
@@ -228,6 +229,11 @@ typedef struct {
     int t_hi, t_lo;                  /* frames t_hi-1 .. t_lo of this call (descending); 0,0 = T-1 .. 0 */
     float* dgates_t;                 /* optional x16-tiled copy of the dgates part of Z: [T+1][4A/16][Bp][16], slot T
                                         zero-filled by the caller; read by the per-frame products of dgates[t+1] */
+    /* Optional co-scheduled recurrence (see T2AttnSeq.co_step): BPTT step i of an independent LSTM (the decoder LSTM of the
+     * NEXT-lower chunk of frames) runs INSIDE the attention-ds launch of frame t_hi-1-i (extra workgroups in the same
+     * launch; the ds workgroups are VALU/LDS bound, the step MFMA/memory bound).  Needs the packed path (wtpacked, dg_next,
+     * no second segment); otherwise, and for steps beyond the frame range, the steps run as plain launches. */
+    const T2LstmBwdStep* co_step; const T2LstmBwdStride* co_inc; int co_steps;
 } T2AttnSeqBwd;
 int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream);
 

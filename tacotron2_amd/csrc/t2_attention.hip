@@ -21,6 +21,7 @@
 int t2_lstm_step_fwd_launch(const T2LstmStep* steps, int n, hipStream_t st);
 int t2_lstm_step_bwd_launch(const T2LstmBwdStep* steps, int n, hipStream_t st);
 void t2_lstm_fwd_advance(T2LstmStep& c, const T2LstmStride& inc);
+void t2_lstm_bwd_advance(T2LstmBwdStep& c, const T2LstmBwdStride& inc);
 
 namespace {
 
@@ -553,9 +554,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dw_kernel(AttnBwdK p) {
     if (sub == 0 && l < L) p.de[(long)b * L + l] = wme * (acc + dwx_s[l] - sigma);
 }
 
-__global__ __launch_bounds__(ENT, 2) void attn_bwd_ds_kernel(AttnBwdK p) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int b = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
+__device__ __forceinline__ void attn_bwd_ds_body(const AttnBwdK& p, const int b, const int j, float* sm) {
+    const int tid = threadIdx.x;
     const int al = tid >> 5, sub = tid & 31, a = j * 16 + al;
     const int L = p.L, NG = (L + 3) >> 2, Lp = 4 * NG + 36, L4 = 4 * NG;
     constexpr int DH = 16;         // halo of the ds rows (16, not 15: keeps every 4-position read 16-byte aligned)
@@ -714,8 +714,23 @@ __global__ __launch_bounds__(ENT, 2) void attn_bwd_ds_kernel(AttnBwdK p) {
         float s2 = 0.f;
 #pragma unroll
         for (int al2 = 0; al2 < 16; ++al2) s2 += dinq[(al2 * 2 + c) * L4 + l];
-        p.din_part_out[(((long)b * gridDim.y + j) * 2 + c) * L + l] = s2;
+        p.din_part_out[(((long)b * (p.Ad >> 4) + j) * 2 + c) * L + l] = s2;
     }
+}
+
+__global__ __launch_bounds__(ENT, 2) void attn_bwd_ds_kernel(AttnBwdK p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    attn_bwd_ds_body(p, blockIdx.x, blockIdx.y, sm);
+}
+
+// Heterogeneous launch: workgroups [0, nD) are the ds workgroups (b = id % B, j = id / B); workgroups [nD, nD + ntx*nty)
+// run one BPTT step of a co-scheduled LSTM (16 x 16 tiles, 8 waves split K).  4 waves per SIMD (<= 128 VGPRs) so that one
+// workgroup of each kind fits on a CU: the ds workgroups are VALU/LDS bound, the step workgroups MFMA/memory bound.
+__global__ __launch_bounds__(ENT, 4) void attn_bwd_ds_co_kernel(AttnBwdK p, BwdK c, int nD, int ntx) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int bid = blockIdx.x;
+    if (bid < nD) attn_bwd_ds_body(p, bid % p.B, bid / p.B, sm);
+    else t2_lstm_bwd_fast_body<8, 4>(c, (bid - nD) % ntx, (bid - nD) / ntx, sm);
 }
 
 }  // namespace
@@ -741,6 +756,14 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
     const int thi = (a->t_hi == 0 && a->t_lo == 0) ? T : a->t_hi, tlo = (a->t_hi == 0 && a->t_lo == 0) ? 0 : a->t_lo;
     T2_REQUIRE(tlo >= 0 && thi <= T && tlo <= thi, "t2_attn_seq_bwd: bad frame range");
     T2LstmBwdStep s2[2];
+    T2LstmBwdStep co;
+    int co_left = 0;
+    bool co_ride = false;
+    if (a->co_step && a->co_steps > 0) {
+        T2_REQUIRE(a->co_inc != nullptr, "t2_attn_seq_bwd: co_inc required with co_step");
+        co = *a->co_step; co_left = a->co_steps;
+        co_ride = co.wtpacked && co.dg_next && !co.dg2;
+    }
     for (int t = thi - 1; t >= tlo; --t) {
         const bool last = (t == T - 1);
         const float* zrow = Z + (long)(t + 1) * B * ldz;
@@ -780,7 +803,17 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         k.dpmT = a->dpmT; k.dq = Z + (long)(t + 1) * B * ldz + 4 * A; k.lddq = ldz;
         k.dv_part = a->dv_part; k.dU_part = a->dU_part; k.din_part_out = a->din_part;
         hipLaunchKernelGGL(attn_bwd_dw_kernel, dim3(B, t2_cdiv(L, 32)), dim3(256), sm_dw, st, k);
-        hipLaunchKernelGGL(attn_bwd_ds_kernel, dim3(B, NA), dim3(ENT), sm_ds, st, k);
+        if (co_left > 0 && co_ride) {   // ds workgroups + one BPTT step of the co-scheduled recurrence in one launch
+            T2_TRY(t2_lstm_check_bwd(co));
+            BwdK ck;
+            t2_lstm_to_bk(co, ck);
+            const int ntx = t2_cdiv(co.ncols, 16), nty = t2_cdiv(co.B, 16), nD = B * NA;
+            const size_t sm_co = (size_t)8 * 256 * sizeof(float), smx = sm_ds > sm_co ? sm_ds : sm_co;
+            hipLaunchKernelGGL(attn_bwd_ds_co_kernel, dim3(nD + ntx * nty), dim3(ENT), smx, st, k, ck, nD, ntx);
+            t2_lstm_bwd_advance(co, *a->co_inc); --co_left;
+        } else {
+            hipLaunchKernelGGL(attn_bwd_ds_kernel, dim3(B, NA), dim3(ENT), sm_ds, st, k);
+        }
         // (4) attention-LSTM cell backward: dh = (dh_ext + dgates_{t+1}.W_hh) + dq_t.Wq  (short K = Ad product + pointwise)
         T2LstmBwdStep c;
         memset(&c, 0, sizeof(c));
@@ -795,6 +828,10 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         c.dg_out = Z + (long)t * B * ldz; c.ldgo = ldz;
         if (a->dgates_t) c.dgt_out = a->dgates_t + (long)t * zts;
         T2_TRY(t2_lstm_step_bwd_launch(&c, 1, st));
+    }
+    for (; co_left > 0; --co_left) {   // co-scheduled steps that did not ride in a ds launch
+        T2_TRY(t2_lstm_step_bwd_launch(&co, 1, st));
+        t2_lstm_bwd_advance(co, *a->co_inc);
     }
     T2_CHECK_LAUNCH();
     return T2_OK;

@@ -195,26 +195,7 @@ int launch_fwd(const T2LstmStep* steps, int n, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
-struct BwdK {
-    int B, H, N4;                       // N4 = reduction length (4H of the producing cell)
-    const float* dg_next; long lddg;    // [b][N4] or null (no recurrent contribution)
-    const float* W; long ldw;           // element (n,u) at W[n*ldw + u]
-    const float* dg2; long lddg2; const float* W2; long ldw2; int N2;   // optional second K segment
-    const float* wtpacked;              // optional: [ncols/16][NCH][64 lanes][4] lane-contiguous transposed weights
-    int ncols;                          // number of output columns u (H for the recurrent path)
-    int epi;                            // 0: plain store of dx (+ext), 1: LSTM pointwise backward
-    const float* ext1; long ldx1; const float* ext2; long ldx2;
-    float* dx_out; long lddx;           // epi 0
-    const float* drop; long lddrop;
-    const float* gates; long ldgs;
-    const float* c_prev; long ldcp; const float* c_cur; long ldcc;
-    float* dc; long lddc;
-    float* dg_out; long ldgo;
-    float* dg_out2; long ldgo2;
-    const int32_t* len; int t;
-    const float* dgt; long dgt_cs; float* dgt_out;   // x16-tiled dg_next / dg_out (chunk stride Bp*16 floats)
-};
-struct BwdK2 { BwdK s[2]; };
+
 
 __device__ __forceinline__ void bwd_epilogue(const BwdK& p, const float* red, int tid, int u0, int b0) {
     {
@@ -329,161 +310,15 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(BwdK2 pp) {
 
 // Fast path of the backward step: ONE contiguous gradient row block dg[b][0:K) (K = N4 + N2) against the packed,
 // zero-padded transposed weight stream; same branch-free double-buffered structure as the forward fast path.
-struct BwdEpi { float ext, drop, gi, gf, gg, go, cp, cc, dc; int len; };
-
-__device__ __forceinline__ BwdEpi bwd_epi_load(const BwdK& p, int tid, int u0, int b0) {
-    BwdEpi e;
-    const int bl = tid >> 4, ul = tid & 15;
-    const long b = (b0 + bl) < p.B ? (b0 + bl) : p.B - 1;
-    const int u = (u0 + ul) < p.ncols ? (u0 + ul) : p.ncols - 1;
-    e.ext = 0.f; e.drop = 1.f; e.gi = e.gf = e.gg = e.go = 0.f; e.cp = 0.f; e.cc = 0.f; e.dc = 0.f; e.len = 0x7fffffff;
-    if (p.ext1) e.ext = p.ext1[b * p.ldx1 + u];
-    if (p.ext2) e.ext += p.ext2[b * p.ldx2 + u];
-    if (p.epi == 1) {
-        const int H = p.H;
-        if (p.drop) e.drop = p.drop[b * p.lddrop + u];
-        const float* gs = p.gates + b * p.ldgs + u;
-        e.gi = gs[0]; e.gf = gs[H]; e.gg = gs[2 * H]; e.go = gs[3 * H];
-        if (p.c_prev) e.cp = p.c_prev[b * p.ldcp + u];
-        e.cc = p.c_cur[b * p.ldcc + u];
-        e.dc = p.dc[b * p.lddc + u];
-        if (p.len) e.len = p.len[b];
-    }
-    return e;
-}
-
-__device__ __forceinline__ void bwd_epi_apply(const BwdK& p, const BwdEpi& e, const float* red, int tid, int u0, int b0) {
-    const int bl = tid >> 4, ul = tid & 15;
-    const int b = b0 + bl, u = u0 + ul;
-    if (b < p.B && u < p.ncols) {
-        const float dx = red[(0 * 16 + bl) * 16 + ul] + red[(1 * 16 + bl) * 16 + ul] + red[(2 * 16 + bl) * 16 + ul] +
-                         red[(3 * 16 + bl) * 16 + ul] + e.ext;
-        if (p.epi == 0) {
-            p.dx_out[(long)b * p.lddx + u] = dx;
-        } else {
-            const int H = p.H;
-            const bool active = p.t < e.len;
-            const float dh = dx * e.drop;
-            const float tc = t2_tanh(e.cc);
-            const float dcv = e.dc + dh * e.go * (1.f - tc * tc);
-            float d_o = dh * tc * e.go * (1.f - e.go);
-            float d_i = dcv * e.gg * e.gi * (1.f - e.gi);
-            float d_f = dcv * e.cp * e.gf * (1.f - e.gf);
-            float d_g = dcv * e.gi * (1.f - e.gg * e.gg);
-            float dcp = dcv * e.gf;
-            if (!active) { d_i = d_f = d_g = d_o = 0.f; dcp = 0.f; }
-            p.dc[(long)b * p.lddc + u] = dcp;
-            float* dgo = p.dg_out + (long)b * p.ldgo + u;
-            dgo[0] = d_i; dgo[H] = d_f; dgo[2 * H] = d_g; dgo[3 * H] = d_o;
-            if (p.dg_out2) {
-                float* dg2o = p.dg_out2 + (long)b * p.ldgo2 + u;
-                dg2o[0] = d_i; dg2o[H] = d_f; dg2o[2 * H] = d_g; dg2o[3 * H] = d_o;
-            }
-            if (p.dgt_out) {   // H % 16 == 0 (checked on the host): the four gate columns share (u & 15)
-                float* dt_ = p.dgt_out + (long)(u >> 4) * p.dgt_cs + b * 16 + (u & 15);
-                const long gs = (long)(H >> 4) * p.dgt_cs;
-                dt_[0] = d_i; dt_[gs] = d_f; dt_[2 * gs] = d_g; dt_[3 * gs] = d_o;
-            }
-        }
-    }
-}
-
 __global__ __launch_bounds__(256, 1) void lstm_step_bwd_fast_kernel(BwdK2 pp) {
-    const BwdK& p = pp.s[blockIdx.z];
     __shared__ float red[4 * 256];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 15, q = lane >> 4;
-    const int u0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
-    if (u0 >= p.ncols) return;   // descriptors of one launch may have different widths (whole workgroup exits)
-    const int NCH = (p.N4 + p.N2) >> 4, NCHpad = (NCH + 31) & ~31, G = NCHpad >> 5;
-    const float* wb = p.wtpacked + (long)blockIdx.x * NCHpad * 256 + lane * 4;
-    // x16-tiled gradients: one contiguous 1 KB block per (chunk, row tile) instead of 16 rows x 64 B
-    const float* ab = p.dgt ? p.dgt + (long)(b0 + r) * 16 + 4 * q
-                            : p.dg_next + (long)((b0 + r) < p.B ? (b0 + r) : 0) * p.lddg + 4 * q;
-    const long acs = p.dgt ? p.dgt_cs : 16;
-    const BwdEpi epi = bwd_epi_load(p, tid, u0, b0);   // hoisted: in flight during the GEMM
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    constexpr int U = 8;
-    auto load_chunk = [&](int g, int j, f32x4& a, f32x4& b) {
-        const int c = 32 * g + 4 * j + w;
-        const int cx = c < NCH ? c : NCH - 1;   // padding chunks: finite gradients x the zero weight chunk
-        b = *reinterpret_cast<const f32x4*>(wb + (long)c * 256);
-        a = *reinterpret_cast<const f32x4*>(ab + acs * cx);
-    };
-    auto mma_chunk = [&](const f32x4& a, const f32x4& b) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc1, 0, 0, 0);
-    };
-    // chunk-granular software pipeline (see the forward kernel)
-    auto pipe_group = [&](int gl, f32x4 (&aL)[U], f32x4 (&bL)[U], const f32x4 (&aM)[U], const f32x4 (&bM)[U]) {
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            load_chunk(gl, j, aL[j], bL[j]);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_chunk(aM[j], bM[j]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    {
-        f32x4 aA[U], bA[U], aB[U], bB[U];
-#pragma unroll
-        for (int j = 0; j < U; ++j) load_chunk(0, j, aA[j], bA[j]);
-        int g = 0;
-        for (; g + 2 < G; g += 2) {
-            pipe_group(g + 1, aB, bB, aA, bA);
-            pipe_group(g + 2, aA, bA, aB, bB);
-        }
-        if (g + 1 < G) {
-            pipe_group(g + 1, aB, bB, aA, bA);
-#pragma unroll
-            for (int j = 0; j < U; ++j) mma_chunk(aB[j], bB[j]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < U; ++j) mma_chunk(aA[j], bA[j]);
-        }
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) red[(w * 16 + (q * 4 + g)) * 16 + r] = acc0[g] + acc1[g];
-    __syncthreads();
-    bwd_epi_apply(p, epi, red, tid, u0, b0);
-}
-
-void to_bk(const T2LstmBwdStep& s, BwdK& k) {
-    k.B = s.B; k.H = s.H; k.N4 = s.N4;
-    k.dg_next = s.dg_next; k.lddg = s.lddg; k.W = s.W; k.ldw = s.ldw; k.ncols = s.ncols; k.epi = s.epi;
-    k.dg2 = s.dg2; k.lddg2 = s.lddg2; k.W2 = s.W2; k.ldw2 = s.ldw2; k.N2 = s.N2; k.dg_out2 = s.dg_out2; k.ldgo2 = s.ldgo2;
-    k.wtpacked = s.wtpacked;
-    k.ext1 = s.ext1; k.ldx1 = s.ldx1; k.ext2 = s.ext2; k.ldx2 = s.ldx2;
-    k.dx_out = s.dx_out; k.lddx = s.lddx; k.drop = s.drop; k.lddrop = s.lddrop;
-    k.gates = s.gates; k.ldgs = s.ldgs; k.c_prev = s.c_prev; k.ldcp = s.ldcp; k.c_cur = s.c_cur; k.ldcc = s.ldcc;
-    k.dc = s.dc; k.lddc = s.lddc; k.dg_out = s.dg_out; k.ldgo = s.ldgo; k.len = s.len; k.t = s.t;
-    k.dgt = s.dgt_next; k.dgt_out = s.dgt_out; k.dgt_cs = (long)((s.B + 15) / 16 * 16) * 16;
-}
-
-int check_bwd(const T2LstmBwdStep& s) {
-    T2_REQUIRE(s.B >= 1 && s.ncols >= 1, "lstm bwd step: empty");
-    if (s.dg_next) {
-        T2_REQUIRE(s.N4 % 16 == 0 && s.lddg % 4 == 0 && t2_aligned16(s.dg_next), "lstm bwd step: dg_next alignment");
-        T2_REQUIRE(s.W != nullptr || s.wtpacked != nullptr, "lstm bwd step: W required with dg_next");
-    }
-    if (s.dg2) {
-        T2_REQUIRE(s.N2 % 16 == 0 && s.lddg2 % 4 == 0 && t2_aligned16(s.dg2) && (s.W2 || s.wtpacked), "lstm bwd step: dg2 alignment");
-    }
-    if (s.epi == 1) {
-        T2_REQUIRE(s.gates && s.c_cur && s.dc && s.dg_out && s.ncols == s.H, "lstm bwd step: epilogue operands");
-    } else {
-        T2_REQUIRE(s.dx_out != nullptr, "lstm bwd step: dx_out required");
-    }
-    return T2_OK;
+    t2_lstm_bwd_fast_body<4, 8>(pp.s[blockIdx.z], blockIdx.x, blockIdx.y, red);
 }
 
 int launch_bwd(const T2LstmBwdStep* steps, int n, hipStream_t st) {
     T2_REQUIRE(n == 1 || n == 2, "lstm bwd step: n must be 1 or 2");
     BwdK2 kk;
-    for (int i = 0; i < n; ++i) { T2_TRY(check_bwd(steps[i])); to_bk(steps[i], kk.s[i]); }
+    for (int i = 0; i < n; ++i) { T2_TRY(t2_lstm_check_bwd(steps[i])); t2_lstm_to_bk(steps[i], kk.s[i]); }
     bool fast = true;
     for (int i = 0; i < n; ++i) fast = fast && steps[i].wtpacked && steps[i].dg_next && !steps[i].dg2;
     for (int i = 1; i < n; ++i)
@@ -560,7 +395,7 @@ void t2_lstm_fwd_advance(T2LstmStep& c, const T2LstmStride& inc) {
     adv(c.xt, inc.xt); adv(c.ht_out, inc.ht_out);
     c.t += inc.dt;
 }
-static void t2_lstm_bwd_advance(T2LstmBwdStep& c, const T2LstmBwdStride& inc) {
+void t2_lstm_bwd_advance(T2LstmBwdStep& c, const T2LstmBwdStride& inc) {
     adv(c.dg_next, inc.dg);
     adv(c.ext1, inc.ext1); adv(c.ext2, inc.ext2); adv(c.drop, inc.drop);
     adv(c.gates, inc.gates); adv(c.c_prev, inc.c_prev); adv(c.c_cur, inc.c_cur);

@@ -58,10 +58,15 @@ class Engine:
         self._ws: Dict[str, torch.Tensor] = {}
         self._side = None
         self.chunk = 64               # frames per pipeline chunk (two-stream overlap of the two recurrences)
-        self.co_schedule = True       # decoder-LSTM steps ride in the attention-context launches (T2AttnSeq.co_step)
-        import os as _os               # tuning overrides for experiments (tools/): T2_CHUNK, T2_CO_SCHEDULE
+        self.chunk_bwd = 80           # frames per chunk of the backward pipeline (80*32 rows = 240 tiles of the dxdec GEMM)
+        self.co_schedule = True       # forward: decoder-LSTM steps ride in the attention-context launches (T2AttnSeq.co_step)
+        self.co_schedule_bwd = False  # backward: decoder-LSTM BPTT steps ride in the attention-ds launches (measured
+                                      # slower than the two-stream pipeline at B=32: 41.5 vs 39.9 ms, profiles/README.md)
+        import os as _os               # tuning overrides for experiments (tools/)
         self.chunk = int(_os.environ.get("T2_CHUNK", self.chunk))
+        self.chunk_bwd = int(_os.environ.get("T2_CHUNK_BWD", self.chunk_bwd))
         self.co_schedule = _os.environ.get("T2_CO_SCHEDULE", "1") != "0"
+        self.co_schedule_bwd = _os.environ.get("T2_CO_SCHEDULE_BWD", "0") != "0"
         self.profile = False          # when True, mark() records HIP events at segment boundaries
         self.marks = []               # [(name, event)] of the current step
 
@@ -523,7 +528,7 @@ class Engine:
         self.mark("bwd.dec.proj")
         main, side = torch.cuda.current_stream(), self.side_stream()
         side.wait_stream(main)
-        CH = self.chunk
+        CH = self.chunk_bwd
 
         def dec_bwd_chunk(hi, lo):
             s = make("T2LstmBwdStep", B=B, H=D, N4=4 * D, dg_next=_ptr(dgd, hi * B * 4 * D), lddg=4 * D,
@@ -542,21 +547,47 @@ class Engine:
             gemm(_ptr(dgd, lo * B * 4 * D), P["decoder.lstm.weight_ih"], _ptr(dxdec, lo * B * ldx), (hi - lo) * B, ldx, 4 * D,
                  4 * D, ldx, ldx, a_k=1, b_k=0)
 
-        for hi in range(T, 0, -CH):
-            lo = max(0, hi - CH)
+        def dec_wgrads():   # decoder-LSTM weight gradients, on the side stream next to the attention chain's tail
             with torch.cuda.stream(side):
-                s, inc = dec_bwd_chunk(hi, lo)
-                call("t2_lstm_seq_bwd", s, inc, 1, hi - lo, side.cuda_stream)
-                dxdec_gemm(hi, lo)
-                ev = side.record_event()
-            main.wait_event(ev)
-            sb.t_hi, sb.t_lo = hi, lo
-            call("t2_attn_seq_bwd", sb, st)
-        with torch.cuda.stream(side):   # decoder-LSTM weight gradients overlap the attention chain's tail
-            self._wgrad(dgd, 4 * D, _ptr(xdec, B * ldx), ldx, G["decoder.lstm.weight_ih"], ldx, 4 * D, ldx, R)
-            self._wgrad(dgd, 4 * D, xproj, ldp, G["decoder.lstm.weight_hh"], D, 4 * D, D, R)
-            call("t2_colsum", dgd, 4 * D, R, 4 * D, G["decoder.lstm.bias_ih"], side.cuda_stream)
-            call("t2_colsum", dgd, 4 * D, R, 4 * D, G["decoder.lstm.bias_hh"], side.cuda_stream)
+                self._wgrad(dgd, 4 * D, _ptr(xdec, B * ldx), ldx, G["decoder.lstm.weight_ih"], ldx, 4 * D, ldx, R)
+                self._wgrad(dgd, 4 * D, xproj, ldp, G["decoder.lstm.weight_hh"], D, 4 * D, D, R)
+                db = self.buf("db_dec", 4 * D, zero=True)                      # both biases see the same gate gradients
+                call("t2_colsum", dgd, 4 * D, R, 4 * D, db, side.cuda_stream)
+                G["decoder.lstm.bias_ih"].add_(db); G["decoder.lstm.bias_hh"].add_(db)
+
+        chunks = [(hi, max(0, hi - CH)) for hi in range(T, 0, -CH)]
+        if self.co_schedule_bwd:
+            # the decoder-LSTM BPTT of chunk k+1 is co-scheduled inside the attention chain of chunk k (its step rides in
+            # the attention-ds launch, T2AttnSeqBwd.co_step); the GEMM that turns a chunk's decoder gate gradients into
+            # d[att_h, ctx] runs between chunks
+            import ctypes as _C
+            s, inc = dec_bwd_chunk(*chunks[0])
+            call("t2_lstm_seq_bwd", s, inc, 1, chunks[0][0] - chunks[0][1], st)
+            dxdec_gemm(*chunks[0])
+            for k, (hi, lo) in enumerate(chunks):
+                nxt = chunks[k + 1] if k + 1 < len(chunks) else None
+                sb.t_hi, sb.t_lo = hi, lo
+                if nxt is not None:
+                    s, inc = dec_bwd_chunk(*nxt)
+                    sb.co_step, sb.co_inc, sb.co_steps = _C.pointer(s), _C.pointer(inc), nxt[0] - nxt[1]
+                else:
+                    sb.co_step, sb.co_inc, sb.co_steps = None, None, 0
+                    side.wait_stream(main)
+                    dec_wgrads()
+                call("t2_attn_seq_bwd", sb, st)
+                if nxt is not None:
+                    dxdec_gemm(*nxt)
+        else:
+            for hi, lo in chunks:
+                with torch.cuda.stream(side):
+                    s, inc = dec_bwd_chunk(hi, lo)
+                    call("t2_lstm_seq_bwd", s, inc, 1, hi - lo, side.cuda_stream)
+                    dxdec_gemm(hi, lo)
+                    ev = side.record_event()
+                main.wait_event(ev)
+                sb.t_hi, sb.t_lo = hi, lo
+                call("t2_attn_seq_bwd", sb, st)
+            dec_wgrads()
         self.mark("bwd.dec.chains")
 
         # weight gradients of the attention chain (large GEMMs over all frames)
@@ -564,8 +595,9 @@ class Engine:
         self._wgrad(dga, ldz, ctx["p2"], Pd, gWih, Pd + Ef, 4 * A, Pd, R)
         self._wgrad(dga, ldz, _ptr(xdec, A), ldx, _ptr(gWih, Pd), Pd + Ef, 4 * A, Ef, R)
         self._wgrad(dga, ldz, xdec, ldx, G["decoder.att_rnn.weight_hh"], A, 4 * A, A, R)
-        call("t2_colsum", dga, ldz, R, 4 * A, G["decoder.att_rnn.bias_ih"], st)
-        call("t2_colsum", dga, ldz, R, 4 * A, G["decoder.att_rnn.bias_hh"], st)
+        db = self.buf("db_att", 4 * A, zero=True)
+        call("t2_colsum", dga, ldz, R, 4 * A, db, st)
+        G["decoder.att_rnn.bias_ih"].add_(db); G["decoder.att_rnn.bias_hh"].add_(db)
         self._wgrad(dq, ldz, _ptr(xdec, B * ldx), ldx, G["decoder.attention.query_layer.weight"], A, Ad, A, R)
         call("t2_colsum", dv_part, Ad, B, Ad, G["decoder.attention.v.weight"], st)
         dU = self.buf("dU", Ad, 2 * KL, zero=True)

@@ -222,6 +222,32 @@ def test_train_step_midsize_matches_oracle():
         ps.load_state_dict({k: v.detach() for k, v in Pc.items()})
 
 
+@pytest.mark.parametrize("co_fwd,co_bwd,chunk", [(True, True, 8), (False, False, 8), (True, False, 64), (False, True, 5)])
+def test_pipeline_variants_match_oracle(co_fwd, co_bwd, chunk):
+    """The frame loop's schedule (chunk size, decoder-LSTM steps co-scheduled inside attention launches or on the side
+    stream) must not change results: every variant against the CPU oracle on the same inputs."""
+    dev = _dev()
+    d = R.default_dims(num_chars=39, encoded_dim=64, prenet_dim=32, att_rnn_dim=64, att_dim=32, rnn_hidden_dim=64,
+                       postnet_dim=64, num_mels=16, dropout=0.5)
+    P = R.init_params(d, seed=11)
+    eng, ps = build_engine(d, P, dev)
+    eng.co_schedule, eng.co_schedule_bwd, eng.chunk, eng.chunk_bwd = co_fwd, co_bwd, chunk, chunk
+    ci, lens, mel, tl, gate, masks = random_case(d, 5, 17, 23, 77, dev)
+    Pc = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not R.is_buffer(k)) else v.clone()) for k, v in P.items()}
+    o = R.tacotron2_fwd(Pc, d, ci, lens, True, mel, tl, training=True, masks=masks, new_stats={})
+    loss = R.tts_loss(o[0], o[1], o[2], mel, gate)[0]
+    names = [k for k, v in Pc.items() if v.requires_grad]
+    grads = torch.autograd.grad(loss, [Pc[k] for k in names])
+    outs, ctx = eng.forward_tf(ci.to(dev), lens.to(dev), mel.to(dev), tl.to(dev), training=True, masks=masks_to_device(masks, dev))
+    ps.grad.zero_()
+    loss3 = eng.loss_and_grads(outs, ctx, mel.to(dev), gate.to(dev))
+    torch.cuda.synchronize()
+    assert float((outs[1].cpu() - o[1].detach()).abs().mean()) < 1e-4          # mel L1 (north_star tolerance)
+    assert float((outs[3].cpu() - o[3].detach()).abs().max()) < 1e-5          # alignments
+    assert abs(float(loss3.sum()) - float(loss)) < 2e-5 * max(1.0, abs(float(loss)))
+    _grad_check(ps, {k: g for k, g in zip(names, grads)})
+
+
 # ------------------------------------------------------------------------------------------------------
 # autoregressive inference
 # ------------------------------------------------------------------------------------------------------
