@@ -153,7 +153,8 @@ int t2_lstm_seq_bwd(const T2LstmBwdStep* base, const T2LstmBwdStride* inc, int n
  *                      t2_attn_fold_location (pure re-association of two linear maps)
  *   pmT [B][Ad][L]   = processed memory (att_encoder output, model/tacotron2.py:229) stored transposed
  *   len [B] int32    : positions l >= len[b] are masked to -inf before the softmax (model/attention.py:63)
- *   e_part           : workspace [B][Ad/16][L];  th_out: optional stash [B][Ad][L] of tanh(.) for backward
+ *   e_part           : workspace [B][Ad/16][L];  th_out: optional stash [B][Ad][L4] of tanh(.) for backward, rows padded
+ *                      to L4 = round_up(L,4) floats (16-byte aligned; must be 16-byte aligned itself)
  * Writes w_out (new attention weights = the alignments row), cum_out = cum_prev + w, ctx_out (context). */
 typedef struct {
     int B, L, A, Ad, Ef, Kl;
@@ -176,7 +177,7 @@ int t2_attn_step_fwd(const T2AttnStep* s, void* stream);
  * Time-major stashes use slot s = t+1; the caller zero-fills slot 0 (initial states, model/tacotron2.py:126-153).
  *   pre   [T][B][4A]     prenet part of att_rnn.weight_ih + both biases (hoisted GEMM)
  *   xdec  [T+1][B][A+Ef] cols [0,A) = att_h_t (post-dropout), cols [A,A+Ef) = context_t
- *   att_c [T+1][B][A], gates [T][B][4A] (activated, optional), cum [T+1][B][L], th [T][B][Ad][L] (optional)
+ *   att_c [T+1][B][A], gates [T][B][4A] (activated, optional), cum [T+1][B][L], th [T][B][Ad][L4] (optional, L4 = round_up(L,4))
  *   align [B][T][L]      the alignments output
  *   xproj_ctx            optional second copy of context_t, row (t,b) at xproj_ctx[(t*B+b)*ld_xproj] */
 typedef struct {

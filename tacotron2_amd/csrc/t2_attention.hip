@@ -184,15 +184,17 @@ __device__ __forceinline__ void attn_energy_body(const AttnK& p, const int b, co
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[i] = fmaf(uk[c][k], win[i + k], acc[i]);
             }
+            f32x4 th4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int l = 4 * lg + i;
                 if (l < L) {
-                    const float th = t2_tanh(qa + acc[i] + pmv[it][i]);
-                    if (p.th_out) p.th_out[rowoff + l] = th;
-                    ec[al * 4 * NG + l] = va * th;
+                    th4[i] = t2_tanh(qa + acc[i] + pmv[it][i]);
+                    ec[al * 4 * NG + l] = va * th4[i];
                 }
             }
+            // tanh stash rows are padded to 4*NG floats: one aligned 16-byte store per item
+            if (p.th_out) *reinterpret_cast<f32x4*>(p.th_out + ((long)b * p.Ad + a) * (4 * NG) + 4 * lg) = th4;
         }
     }
     __syncthreads();
@@ -319,6 +321,7 @@ int check_attn(const T2AttnStep& s) {
     T2_REQUIRE(s.Ad % 16 == 0 && s.Ef % 32 == 0 && s.A % 4 == 0, "attention: need Ad%16==0, Ef%32==0, A%4==0");
     T2_REQUIRE(s.ldh % 4 == 0 && t2_aligned16(s.att_h) && t2_aligned16(s.Wq), "attention: att_h/Wq alignment");
     T2_REQUIRE(s.e_part && s.w_out && s.ctx_out && s.pmT && s.memory && s.len && s.U && s.v, "attention: null operand");
+    T2_REQUIRE(!s.th_out || t2_aligned16(s.th_out), "attention: th_out must be 16-byte aligned (rows are padded to 4 floats)");
     return T2_OK;
 }
 
@@ -426,7 +429,7 @@ extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
         if (t > 0) { q.w_prev = a->align + (long)(t - 1) * L; q.ldw = (long)T * L; }
         q.cum_prev = a->cum + (long)t * B * L; q.ldcum = L;
         q.pmT = a->pmT; q.memory = a->memory; q.len = a->len; q.e_part = a->e_part;
-        if (a->th) q.th_out = a->th + (long)t * B * Ad * L;
+        if (a->th) q.th_out = a->th + (long)t * B * Ad * ((L + 3) & ~3);
         q.w_out = a->align + (long)t * L; q.ldwo = (long)T * L;
         q.cum_out = a->cum + (long)(t + 1) * B * L; q.ldco = L;
         q.ctx_out = slot1 + A; q.ldctx = ldx;
@@ -569,13 +572,15 @@ __device__ __forceinline__ void attn_bwd_ds_body(const AttnBwdK& p, const int b,
     // ---- issue: tanh stash + old dpmT of the first round, de, location inputs, filter rows, old accumulator values ----
     float thv[EMAXI][4], dpv[EMAXI][4];
     const float va = p.v[a];
+    const float* th_row = p.th + ((long)b * p.Ad + a) * L4;   // stash rows are padded to L4 floats (16-byte aligned items)
 #pragma unroll
     for (int it = 0; it < EMAXI; ++it) {
         const int lg = imin(sub + 32 * it, NG - 1);
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(th_row + 4 * lg);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int l = imin(4 * lg + i, L - 1);
-            thv[it][i] = p.th[rowoff + l];
+            thv[it][i] = t4[i];
             dpv[it][i] = p.dpmT[rowoff + l];
         }
     }
@@ -606,10 +611,11 @@ __device__ __forceinline__ void attn_bwd_ds_body(const AttnBwdK& p, const int b,
             const int lg = base + sub + 32 * it;
             if (lg >= NG) continue;
             if (base > 0) {
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(th_row + 4 * lg);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int l = imin(4 * lg + i, L - 1);
-                    thv[it][i] = p.th[rowoff + l];
+                    thv[it][i] = t4[i];
                     dpv[it][i] = p.dpmT[rowoff + l];
                 }
             }
@@ -797,7 +803,7 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         k.G_in = last ? nullptr : a->G + (long)((t + 1) & 1) * B * L;
         k.G_out = a->G + (long)(t & 1) * B * L;
         k.de = a->de;
-        k.th = a->th + (long)t * B * Ad * L; k.v = a->v; k.U = a->U;
+        k.th = a->th + (long)t * B * Ad * ((L + 3) & ~3); k.v = a->v; k.U = a->U;
         if (t > 0) { k.w_prev = a->align + (long)(t - 1) * L; k.ldwp = (long)T * L; }
         k.cum_prev = a->cum + (long)t * B * L; k.ldcp = L;
         k.dpmT = a->dpmT; k.dq = Z + (long)(t + 1) * B * ldz + 4 * A; k.lddq = ldz;

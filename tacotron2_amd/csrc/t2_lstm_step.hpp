@@ -183,7 +183,9 @@ __device__ __forceinline__ void t2_lstm_fwd_fast_body(const LstmK& p, const int 
             if (p.c_out) p.c_out[(long)b * p.ldc_out + u] = cn;
             if (p.gates_out) {
                 float* go_ = p.gates_out + (long)b * p.ldg + u;
-                go_[0] = gi; go_[H] = gf; go_[2 * H] = gg; go_[3 * H] = go;
+                // stash for the backward pass: read once, much later -> non-temporal (does not stay dirty in L2)
+                __builtin_nontemporal_store(gi, go_); __builtin_nontemporal_store(gf, go_ + H);
+                __builtin_nontemporal_store(gg, go_ + 2 * H); __builtin_nontemporal_store(go, go_ + 3 * H);
             }
         }
     }

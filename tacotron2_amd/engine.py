@@ -304,7 +304,7 @@ class Engine:
         dech_t = self.buf("dech_t", T + 1, D // 16, Bp, 16, zero=(B != Bp))
         dech_t[0].zero_()
         gates_att = self.buf("gates_att", T, B, 4 * A) if save_for_backward else None
-        th = self.buf("th", T, B, Ad, L) if save_for_backward else None
+        th = self.buf("th", T, B, Ad, (L + 3) // 4 * 4) if save_for_backward else None
         align = torch.empty(B, T, L, dtype=torch.float32, device=self.dev)
         e_part = self.buf("e_part", B, Ad // 16, L)
         # packed in the column order of the xdec row [att_h | ctx], so each step reads ONE contiguous activation segment

@@ -165,7 +165,7 @@ def test_attention_step_fwd(dev, B, L, A, Ad, Ef):
     U = torch.empty(Ad, 2, 31, device=dev)
     Wd, Wc = f(P["decoder.attention.location_dense.weight"]), f(P["decoder.attention.location_conv.weight"])
     _lib.call("t2_attn_fold_location", Wd, Wc, U, Ad, 32, 31, st)
-    e_part = torch.empty(B, Ad // 16, L, device=dev); th = torch.empty(B, Ad, L, device=dev)
+    e_part = torch.empty(B, Ad // 16, L, device=dev); th = torch.empty(B, Ad, (L + 3) // 4 * 4, device=dev)
     w_out = torch.empty(B, L, device=dev); cum_out = torch.empty(B, L, device=dev); ctx = torch.empty(B, Ef, device=dev)
     keep = [f(att_h), f(P["decoder.attention.query_layer.weight"]), f(P["decoder.attention.v.weight"]), f(w), f(cum),
             f(pm.transpose(1, 2)), f(mem), lens.to(torch.int32).to(dev)]
