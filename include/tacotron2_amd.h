@@ -303,10 +303,14 @@ int t2_tanh_bwd(const float* g, const float* y, float* out, int64_t n, void* str
  *   t2_linear_rows  out[b][n] = act(x[b][:] . w[n][:] + bias[n]) * mask[b][n]   (nn.Linear on <= batch rows; K % 16 == 0)
  *   t2_decoder_infer runs frames [t0, t1) with no host synchronisation: state[0] = all-done flag, state[1] = number of
  *   emitted frames, done [B] int32, lengths [B] int64 (counts every frame whose stop logit is >= 0, Appendix C.4).
- * Buffers: xatt [2][B][A+Ef+P] rows [att_h | ctx | prenet_out]; xdec [2][B][A+Ef+D] rows [att_h | ctx | dec_h];
- * att_c [2][B][A], dec_c [2][B][D], cum [2][B][L] (ping-pong, slot 0 zero-filled by the caller); xproj [B][D+Ef];
- * proj [Tcap][B][ld_proj] (cols 0..M-1 mel, col M stop logit; ld_proj % 4 == 0); align [B][Tcap][L];
- * prenet_mask [Tcap][2][B][P] or NULL; wp_att / wp_dec = t2_lstm_pack_fwd streams in the row order above. */
+ * Buffers: xs [2][(P+A+Ef+D)/16][Bp][16] = the recurrent state in the x16-tiled layout of T2LstmStep.xt, columns
+ * [prenet_out | att_h | ctx | dec_h], two ping-pong slots, zero-filled by the caller (P, A, Ef, D multiples of 16);
+ * att_h [B][A] and xproj [B][D+Ef] = [dec_h | ctx] row-major copies; p1, p2 [B][P] prenet activations;
+ * att_c [2][B][A], dec_c [2][B][D], cum [2][B][L] (ping-pong, slot 0 zero-filled by the caller);
+ * proj [Tcap][B][ld_proj] (cols 0..M-1 mel, col M stop logit; ld_proj % 4 == 0), ZERO-FILLED by the caller (the projection
+ * accumulates K slices atomically); align [B][Tcap][L]; prenet_mask [Tcap][2][B][P] or NULL;
+ * wp_att = t2_lstm_pack_fwd of the attention-LSTM weights in the column order [prenet | att_h | ctx],
+ * wp_dec = t2_lstm_pack_fwd of the decoder-LSTM weights in the column order [att_h | ctx | dec_h]. */
 int t2_linear_rows(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* mask,
                    int64_t ldmask, int relu, float* out, int64_t ldo, int B, int N, int K, void* stream);
 typedef struct {
@@ -318,7 +322,7 @@ typedef struct {
     const float* W_proj; const float* b_proj;
     const float* pmT; const float* memory; const int32_t* len;
     const float* prenet_mask; const float* zero_frame;
-    float* xatt; float* xdec; float* att_c; float* dec_c; float* cum; float* xproj; float* p1; float* e_part;
+    float* xs; float* att_h; float* att_c; float* dec_c; float* cum; float* xproj; float* p1; float* p2; float* e_part;
     float* proj; int64_t ld_proj; float* align;
     int32_t* done; int64_t* lengths; int32_t* state;
 } T2Infer;

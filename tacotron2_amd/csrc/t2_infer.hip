@@ -3,9 +3,13 @@
 // as 8 dependent launches with NO host synchronisation inside the loop: `done`, `lengths`, the all-done flag and the
 // emitted frame count live on the device (the reference syncs `done.all()` every frame, model/tacotron2.py:321).
 //
-// State rows are laid out so that each LSTM cell reads ONE contiguous activation segment against its packed weight
-// stream (t2_lstm_pack_fwd):   xatt[b] = [att_h | ctx | prenet_out]     xdec[b] = [att_h | ctx | dec_h]
-// with two ping-pong slots each; xproj[b] = [dec_h | ctx] feeds the projection.
+// Recurrent state lives in ONE x16-tiled buffer (layout of T2LstmStep.xt) with two ping-pong slots and the column order
+//   xs[slot] = [ prenet_out (P) | att_h (A) | ctx (Ef) | dec_h (D) ]
+// so that both LSTM cells read ONE contiguous chunk range against their packed weight streams (t2_lstm_pack_fwd):
+//   attention cell of frame t : slot t&1,     chunks [0, (P+A+Ef)/16)    = [prenet_t | att_h_{t-1} | ctx_{t-1}]
+//   decoder  cell of frame t : slot (t+1)&1, chunks [P/16, (P+A+Ef+D)/16) = [att_h_t  | ctx_t       | dec_h_{t-1}]
+// Writers: prenet -> slot t&1; attention cell / context kernel -> slot (t+1)&1; decoder cell -> slot t&1 (read next frame).
+// Row-major copies exist only where another kernel needs rows: att_h [B][A] (query projection) and xproj = [dec_h | ctx].
 #include "t2_common.hpp"
 
 int t2_lstm_step_fwd_launch(const T2LstmStep* steps, int n, hipStream_t st);
@@ -21,6 +25,9 @@ struct LinK {
     const float* mask; long ldmask;
     int relu;
     float* out; long ldo;
+    float* out_t; int out_col0; long out_cs;   // optional x16-tiled copy of the output (chunk stride out_cs floats)
+    int ksplit;                                // > 1: blockIdx.y owns a K slice, partial sums are atomically added into a
+                                               // ZERO-FILLED out (bias by slice 0; no relu/mask/out_t)
 };
 
 // out[b][n] = act(sum_k x[b][k] w[n][k] + bias[n]) * mask[b][n]; M = batch rows on the MFMA M axis (<= 64), one
@@ -43,9 +50,10 @@ __global__ __launch_bounds__(256, 1) void linear_rows_kernel(LinK p) {
     f32x4 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int NT = p.K >> 4;
+    const int NTall = p.K >> 4, per = (NTall + p.ksplit - 1) / p.ksplit;
+    const int cbeg = blockIdx.y * per, NT = (cbeg + per) < NTall ? (cbeg + per) : NTall;
     constexpr int U = 4;
-    for (int c0 = w; c0 < NT; c0 += 4 * U) {
+    for (int c0 = cbeg + w; c0 < NT; c0 += 4 * U) {
         f32x4 bw[U], ax[U][MT];
 #pragma unroll
         for (int j = 0; j < U; ++j) {
@@ -75,10 +83,16 @@ __global__ __launch_bounds__(256, 1) void linear_rows_kernel(LinK p) {
             float s = 0.f;
 #pragma unroll
             for (int ww = 0; ww < 4; ++ww) s += red[((ww * MT + (b >> 4)) * 16 + (b & 15)) * 16 + nl];
+            if (p.ksplit > 1) {
+                if (p.bias && blockIdx.y == 0) s += p.bias[n];
+                atomicAdd(&p.out[(long)b * p.ldo + n], s);
+                continue;
+            }
             if (p.bias) s += p.bias[n];
             if (p.relu) s = fmaxf(s, 0.f);
             if (p.mask) s *= p.mask[(long)b * p.ldmask + n];
             p.out[(long)b * p.ldo + n] = s;
+            if (p.out_t) { const int col = p.out_col0 + n; p.out_t[(long)(col >> 4) * p.out_cs + b * 16 + (col & 15)] = s; }
         }
     }
 }
@@ -87,7 +101,8 @@ int launch_linear(const LinK& k, hipStream_t st) {
     T2_REQUIRE(k.K % 16 == 0 && k.ldx % 4 == 0 && k.ldw % 4 == 0 && t2_aligned16(k.x) && t2_aligned16(k.w),
                "linear rows: K % 16 == 0 and 16-byte aligned operands required");
     T2_REQUIRE(k.B >= 1 && k.B <= 64, "linear rows: 1 <= B <= 64");
-    dim3 grid(t2_cdiv(k.N, 16)), block(256);
+    T2_REQUIRE(k.ksplit >= 1 && (k.ksplit == 1 || (!k.relu && !k.mask && !k.out_t)), "linear rows: K split needs a plain linear");
+    dim3 grid(t2_cdiv(k.N, 16), k.ksplit), block(256);
     if (k.B <= 16) hipLaunchKernelGGL((linear_rows_kernel<1>), grid, block, 0, st, k);
     else if (k.B <= 32) hipLaunchKernelGGL((linear_rows_kernel<2>), grid, block, 0, st, k);
     else hipLaunchKernelGGL((linear_rows_kernel<4>), grid, block, 0, st, k);
@@ -126,6 +141,7 @@ extern "C" int t2_linear_rows(const float* x, int64_t ldx, const float* w, int64
         k.x = x + (long)b0 * ldx; k.ldx = ldx; k.w = w; k.ldw = ldw; k.bias = bias;
         k.mask = mask ? mask + (long)b0 * ldmask : nullptr; k.ldmask = ldmask; k.relu = relu;
         k.out = out + (long)b0 * ldo; k.ldo = ldo;
+        k.out_t = nullptr; k.out_col0 = 0; k.out_cs = 0; k.ksplit = 1;
         T2_TRY(launch_linear(k, st));
     }
     return T2_OK;
@@ -136,60 +152,74 @@ extern "C" int t2_decoder_infer(const T2Infer* a, int t0, int t1, void* stream) 
     T2_REQUIRE(a->B <= 64, "t2_decoder_infer: B <= 64 per call (split larger batches)");
     hipStream_t st = (hipStream_t)stream;
     const int B = a->B, L = a->L, A = a->A, D = a->D, Ef = a->Ef, Ad = a->Ad, P = a->P, M = a->M;
-    const long lda = A + Ef + P, ldd = A + Ef + D, ldp = D + Ef, ldo = a->ld_proj;
+    T2_REQUIRE(P % 16 == 0 && A % 16 == 0 && Ef % 16 == 0 && D % 16 == 0, "t2_decoder_infer: P, A, Ef, D must be multiples of 16");
+    const long ldp = D + Ef, ldo = a->ld_proj;
+    const int Bp = (B + 15) / 16 * 16;
+    const long cs = (long)Bp * 16;                               // chunk stride of the tiled state
+    const long slot = (long)((P + A + Ef + D) / 16) * cs;        // one tiled slot
+    const int ksplit = (D + Ef) >= 512 ? 8 : 1;                  // the 6-workgroup projection is latency bound: split K
     for (int t = t0; t < t1; ++t) {
-        float* xa_cur = a->xatt + (long)(t & 1) * B * lda;
-        float* xa_nxt = a->xatt + (long)((t + 1) & 1) * B * lda;
-        float* xd_cur = a->xdec + (long)(t & 1) * B * ldd;
-        float* xd_nxt = a->xdec + (long)((t + 1) & 1) * B * ldd;
+        float* xs_cur = a->xs + (long)(t & 1) * slot;
+        float* xs_nxt = a->xs + (long)((t + 1) & 1) * slot;
         // prenet on the previous frame (zeros for t = 0), AlwaysDropout masks (model/modules.py)
         const float* prev = t == 0 ? a->zero_frame : a->proj + (long)(t - 1) * B * ldo;
         const long ldprev = t == 0 ? 0 : ldo;
         const float* m1 = a->prenet_mask ? a->prenet_mask + ((long)t * 2 + 0) * B * P : nullptr;
         const float* m2 = a->prenet_mask ? a->prenet_mask + ((long)t * 2 + 1) * B * P : nullptr;
         T2_TRY(t2_linear_rows(prev, ldprev, a->W_pre1, M, nullptr, m1, P, 1, a->p1, P, B, P, M, stream));
-        T2_TRY(t2_linear_rows(a->p1, P, a->W_pre2, P, nullptr, m2, P, 1, xa_cur + A + Ef, lda, B, P, P, stream));
-        // attention LSTM cell
+        {
+            LinK k;
+            k.B = B; k.N = P; k.K = P; k.x = a->p1; k.ldx = P; k.w = a->W_pre2; k.ldw = P; k.bias = nullptr;
+            k.mask = m2; k.ldmask = P; k.relu = 1; k.out = a->p2; k.ldo = P;
+            k.out_t = xs_cur; k.out_col0 = 0; k.out_cs = cs; k.ksplit = 1;
+            T2_TRY(launch_linear(k, st));
+        }
+        // attention LSTM cell: [prenet_t | att_h_{t-1} | ctx_{t-1}]
         T2LstmStep s;
         memset(&s, 0, sizeof(s));
         s.B = B; s.H = A; s.nseg = 1; s.wpacked = a->wp_att;
-        s.seg[0].x = xa_cur; s.seg[0].ldx = lda; s.seg[0].K = (int)lda;
+        s.seg[0].x = a->att_h; s.seg[0].ldx = A; s.seg[0].K = P + A + Ef;   // (row-major operand unused: xt is set)
+        s.xt = xs_cur;
         s.bias1 = a->b_att_ih; s.bias2 = a->b_att_hh;
         s.c_prev = a->att_c + (long)(t & 1) * B * A; s.ldc_prev = A;
-        s.h_out = xa_nxt; s.ldh = lda; s.h_out2 = xd_cur; s.ldh2 = ldd;
+        s.h_out = a->att_h; s.ldh = A;
+        s.ht_out = xs_nxt; s.ht_col0 = P;
         s.c_out = a->att_c + (long)((t + 1) & 1) * B * A; s.ldc_out = A;
         T2_TRY(t2_lstm_step_fwd_launch(&s, 1, st));
         // attention
         T2AttnStep q;
         memset(&q, 0, sizeof(q));
         q.B = B; q.L = L; q.A = A; q.Ad = Ad; q.Ef = Ef; q.Kl = a->Kl;
-        q.att_h = xa_nxt; q.ldh = lda; q.Wq = a->Wq; q.U = a->U; q.v = a->v;
+        q.att_h = a->att_h; q.ldh = A; q.Wq = a->Wq; q.U = a->U; q.v = a->v;
         if (t > 0) { q.w_prev = a->align + (long)(t - 1) * L; q.ldw = (long)a->Tcap * L; }
         q.cum_prev = a->cum + (long)(t & 1) * B * L; q.ldcum = L;
         q.pmT = a->pmT; q.memory = a->memory; q.len = a->len; q.e_part = a->e_part;
         q.w_out = a->align + (long)t * L; q.ldwo = (long)a->Tcap * L;
         q.cum_out = a->cum + (long)((t + 1) & 1) * B * L; q.ldco = L;
-        q.ctx_out = xa_nxt + A; q.ldctx = lda; q.ctx_out2 = xd_cur + A; q.ldctx2 = ldd;
+        q.ctx_out = a->xproj + D; q.ldctx = ldp;
+        q.ctxt_out = xs_nxt; q.ctxt_col0 = P + A;
         T2_TRY(t2_attn_step_launch(&q, st));
-        // decoder LSTM cell: [att_h | ctx | dec_h_prev]
+        // decoder LSTM cell: [att_h_t | ctx_t | dec_h_{t-1}]
         T2LstmStep d;
         memset(&d, 0, sizeof(d));
         d.B = B; d.H = D; d.nseg = 1; d.wpacked = a->wp_dec;
-        d.seg[0].x = xd_cur; d.seg[0].ldx = ldd; d.seg[0].K = (int)ldd;
+        d.seg[0].x = a->xproj; d.seg[0].ldx = ldp; d.seg[0].K = A + Ef + D;    // (row-major operand unused: xt is set)
+        d.xt = xs_nxt + (long)(P / 16) * cs;
         d.bias1 = a->b_dec_ih; d.bias2 = a->b_dec_hh;
         d.c_prev = a->dec_c + (long)(t & 1) * B * D; d.ldc_prev = D;
-        d.h_out = xd_nxt + A + Ef; d.ldh = ldd; d.h_out2 = a->xproj; d.ldh2 = ldp;
+        d.h_out = a->xproj; d.ldh = ldp;
+        d.ht_out = xs_cur; d.ht_col0 = P + A + Ef;
         d.c_out = a->dec_c + (long)((t + 1) & 1) * B * D; d.ldc_out = D;
         T2_TRY(t2_lstm_step_fwd_launch(&d, 1, st));
-        // xproj = [dec_h | ctx]: ctx copied by a strided device copy (B x Ef floats)
-        if (hipMemcpy2DAsync(a->xproj + D, ldp * sizeof(float), xd_cur + A, ldd * sizeof(float), Ef * sizeof(float), B,
-                             hipMemcpyDeviceToDevice, st) != hipSuccess) {
-            t2_set_error("hipMemcpy2DAsync failed", __FILE__, __LINE__);
-            return T2_ERR_LAUNCH;
-        }
-        // mel + stop projection, then the device-side stop logic
+        // mel + stop projection over xproj = [dec_h | ctx] (K split, atomics into the zero-filled row block), stop logic
         float* out = a->proj + (long)t * B * ldo;
-        T2_TRY(t2_linear_rows(a->xproj, ldp, a->W_proj, ldp, a->b_proj, nullptr, 0, 0, out, ldo, B, M + 1, (int)ldp, stream));
+        {
+            LinK k;
+            k.B = B; k.N = M + 1; k.K = (int)ldp; k.x = a->xproj; k.ldx = ldp; k.w = a->W_proj; k.ldw = ldp; k.bias = a->b_proj;
+            k.mask = nullptr; k.ldmask = 0; k.relu = 0; k.out = out; k.ldo = ldo;
+            k.out_t = nullptr; k.out_col0 = 0; k.out_cs = 0; k.ksplit = ksplit;
+            T2_TRY(launch_linear(k, st));
+        }
         hipLaunchKernelGGL(stop_kernel, dim3(1), dim3(256), 0, st, out, ldo, M, B, t, a->done, a->lengths, a->state);
     }
     T2_CHECK_LAUNCH();

@@ -758,19 +758,22 @@ class Engine:
         lda, ldd, ldp = A + Ef + Pd, A + Ef + D, D + Ef
         ldo = (M + 1 + 3) // 4 * 4
         Wih_a, Wih_d = P["decoder.att_rnn.weight_ih"], P["decoder.lstm.weight_ih"]
-        wp_att = self.pack_fwd("inf.att", [(P["decoder.att_rnn.weight_hh"], A, A), (_ptr(Wih_a, Pd), Pd + Ef, Ef),
-                                           (Wih_a, Pd + Ef, Pd)], A)
+        # packed in the column order of the tiled state [prenet | att_h | ctx | dec_h] (csrc/t2_infer.hip)
+        wp_att = self.pack_fwd("inf.att", [(Wih_a, Pd + Ef, Pd), (P["decoder.att_rnn.weight_hh"], A, A),
+                                           (_ptr(Wih_a, Pd), Pd + Ef, Ef)], A)
         wp_dec = self.pack_fwd("inf.dec", [(Wih_d, A + Ef, A), (_ptr(Wih_d, A), A + Ef, Ef),
                                            (P["decoder.lstm.weight_hh"], D, D)], D)
-        xatt = self.buf("inf.xatt", 2, B, lda, zero=True)
-        xdec = self.buf("inf.xdec", 2, B, ldd, zero=True)
+        Bp = (B + 15) // 16 * 16
+        xs = self.buf("inf.xs", 2, (Pd + A + Ef + D) // 16, Bp, 16, zero=True)
+        att_h = self.buf("inf.att_h", B, A, zero=True)
         att_c = self.buf("inf.att_c", 2, B, A, zero=True)
         dec_c = self.buf("inf.dec_c", 2, B, D, zero=True)
         cum = self.buf("inf.cum", 2, B, L, zero=True)
         xproj = self.buf("inf.xproj", B, ldp)
         p1 = self.buf("inf.p1", B, Pd)
+        p2 = self.buf("inf.p2", B, Pd)
         e_part = self.buf("e_part", B, Ad // 16, L)
-        proj = self.buf("inf.proj", Tcap, B, ldo)
+        proj = self.buf("inf.proj", Tcap, B, ldo, zero=True)     # the projection accumulates K slices atomically
         align = torch.zeros(B, Tcap, L, dtype=torch.float32, device=self.dev)
         zero_frame = self.buf("inf.zero", max(M, 64), zero=True)
         done = self.buf("inf.done", B, dtype=torch.int32, zero=True)
@@ -801,7 +804,7 @@ class Engine:
                      b_dec_ih=P["decoder.lstm.bias_ih"], b_dec_hh=P["decoder.lstm.bias_hh"],
                      Wq=P["decoder.attention.query_layer.weight"], U=U, v=P["decoder.attention.v.weight"],
                      W_proj=wproj, b_proj=bproj, pmT=pmT, memory=memory, len=len32, prenet_mask=pm_ptr,
-                     zero_frame=zero_frame, xatt=xatt, xdec=xdec, att_c=att_c, dec_c=dec_c, cum=cum, xproj=xproj, p1=p1,
+                     zero_frame=zero_frame, xs=xs, att_h=att_h, att_c=att_c, dec_c=dec_c, cum=cum, xproj=xproj, p1=p1, p2=p2,
                      e_part=e_part, proj=proj, ld_proj=ldo, align=align, done=done, lengths=lengths, state=state)
             call("t2_decoder_infer", a, t0, t1, st)
             t0 = t1
