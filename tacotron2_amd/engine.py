@@ -42,10 +42,19 @@ def _ptr(t: torch.Tensor, elem_off: int = 0) -> int:
 
 
 def splitk_for(M: int, N: int, K: int) -> int:
-    """Enough K-slices to put ~2 workgroups on each of the 256 CUs for weight-gradient shaped GEMMs."""
+    """K-slices for weight-gradient shaped GEMMs (few output tiles, very long K).  Cost model fitted to
+    profiles/r01_gemm_shapes.txt: 128x128 tiles, 256 CUs, the kernel is MFMA-bound per CU, so the time is
+    ceil(workgroups / 256) rounds of 1/sk tile-times; fewer than ~1.5 workgroups per CU hides latency worse (+15 %);
+    every extra slice adds atomic traffic (+1 %)."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    ks = max(1, min((K + 31) // 32, (512 + tiles - 1) // tiles))
-    return ks
+    kt = (K + 31) // 32
+    best, best_cost = 1, None
+    for sk in range(1, max(1, min(kt // 4, 64)) + 1):
+        w = tiles * sk
+        cost = ((w + 255) // 256) / sk * (1.15 if w < 384 else 1.0) * (1.0 + 0.01 * sk)
+        if best_cost is None or cost < best_cost - 1e-12:
+            best, best_cost = sk, cost
+    return best
 
 
 class Engine:

@@ -42,3 +42,18 @@ case("dW_hh_dec (TN split-K 4)", 4096, 1024, R, 0, 0, 4)
 case("dW_ih_att ctx (TN split-K)", 4096, 512, R, 0, 0, splitk_for(4096, 512, R))
 case("dW postnet (TN split-K)", 512, 2560, 28032, 0, 0, splitk_for(512, 2560, 28032))
 case("postnet dgrad (NT)", 28032, 512, 2560, 1, 1)
+
+print("--- split-K sweeps ---")
+for sk in (2, 3, 4, 6, 7, 8, 12):
+    case("dW postnet (TN)", 512, 2560, 28032, 0, 0, sk)
+for sk in (1, 2, 3, 4):
+    case("dW_hh_dec (TN)", 4096, 1024, R, 0, 0, sk)
+for sk in (1, 2, 4):
+    case("dxdec chunk 80 (NN)", 2560, 1536, 4096, 1, 0, sk)
+for sk in (2, 4, 8):
+    case("dW_q (TN)", 128, 1024, R, 0, 0, sk)
+for sk in (4, 8, 16, 28):
+    case("dW prenet2 (TN)", 256, 256, R, 0, 0, sk)
+case("encoder conv (NT)", 6016 + 128, 512, 2560, 1, 1)
+case("bilstm in-proj (NT)", 6016, 2048, 512, 1, 1)
+case("att_encoder batched-ish (NT)", 6016, 128, 512, 1, 1)
