@@ -115,6 +115,111 @@ def test_lstm_step_fwd(dev, B, H, Ks):
     assert _rel(gs[:, :H], i_ref) < 5e-6
 
 
+def _tile16(x, Bp):
+    """(B, K) -> x16 layout [K/16][Bp][16] (include/tacotron2_amd.h, T2LstmStep.xt)."""
+    B, K = x.shape
+    out = torch.zeros(K // 16, Bp, 16, dtype=x.dtype)
+    out[:, :B] = x.reshape(B, K // 16, 16).permute(1, 0, 2)
+    return out
+
+
+def _untile16(xt, B):
+    nch, Bp, _ = xt.shape
+    return xt[:, :B].permute(1, 0, 2).reshape(B, nch * 16)
+
+
+@pytest.mark.parametrize("B,H,Ks,col0", [(32, 1024, (1024, 512), 0), (5, 64, (48,), 16), (64, 128, (128, 64), 0), (19, 32, (32,), 32)])
+def test_lstm_step_fwd_packed_tiled(dev, B, H, Ks, col0):
+    """Packed weight stream + x16-tiled activations in / tiled h out (the product path of the frame loop) against float64;
+    the tiled input holds NaN in the rows >= B, which must not leak into any output row."""
+    from tacotron2_amd import _lib
+    g = torch.Generator().manual_seed(B * 7 + H)
+    K = sum(Ks)
+    x = torch.randn(B, K, generator=g)
+    Ws = [torch.randn(4 * H, k, generator=g) / (K ** 0.5) for k in Ks]
+    pre = torch.randn(B, 4 * H, generator=g); b1 = torch.randn(4 * H, generator=g); b2 = torch.randn(4 * H, generator=g)
+    c0 = torch.randn(B, H, generator=g)
+    lens = torch.tensor([3 if i % 4 == 1 else 9 for i in range(B)], dtype=torch.int32)
+    t = 5
+    gates = pre.double() + b1.double() + b2.double() + x.double() @ torch.cat(Ws, 1).double().t()
+    h_ref, c_ref = R.lstm_cell(gates, c0.double())
+    act = (t < lens)[:, None]
+    h_ref = h_ref * act; c_ref = c_ref * act
+    st_ = torch.cuda.current_stream().cuda_stream
+    Wd = [W.to(dev) for W in Ws]
+    segs = (_lib.S["T2Seg"] * len(Ks))()
+    for i, W in enumerate(Wd):
+        segs[i].w = W.data_ptr(); segs[i].ldw = W.shape[1]; segs[i].K = W.shape[1]
+    ntpad = (K // 16 + 15) // 16 * 16
+    wp = torch.empty(H // 4 * ntpad * 256, device=dev)
+    _lib.call("t2_lstm_pack_fwd", segs, len(Ks), H, wp, st_)
+    Bp = (B + 15) // 16 * 16
+    xt = _tile16(x, Bp)
+    xt[:, B:] = float("nan")                                   # rows >= B are never read into a valid output row
+    xt = xt.to(dev)
+    Ht = (col0 + H + 15) // 16 * 16
+    ht = torch.full((Ht // 16, Bp, 16), -7.0, device=dev)
+    h = torch.empty(B, H, device=dev); c = torch.empty(B, H, device=dev); xd = x.to(dev)
+    keep = [pre.to(dev), b1.to(dev), b2.to(dev), c0.to(dev), lens.to(dev)]
+    st = _lib.make("T2LstmStep", B=B, H=H, nseg=1, wpacked=wp, pre=keep[0], ldpre=4 * H, bias1=keep[1], bias2=keep[2],
+                   c_prev=keep[3], ldc_prev=H, h_out=h, ldh=H, c_out=c, ldc_out=H, len=keep[4], t=t, xt=xt, ht_out=ht,
+                   ht_col0=col0)
+    st.seg[0].x = xd.data_ptr(); st.seg[0].ldx = K; st.seg[0].K = K
+    _lib.call("t2_lstm_step_fwd", st, 1, st_)
+    torch.cuda.synchronize()
+    assert _rel(h, h_ref) < 5e-6 and _rel(c, c_ref) < 5e-6
+    got_t = _untile16(ht.cpu(), B)
+    assert torch.equal(got_t[:, col0:col0 + H], h.cpu())       # the tiled copy holds the same values
+    if col0:
+        assert float((got_t[:, :col0] + 7.0).abs().max()) == 0.0   # other columns untouched
+    # row-major activations through the same packed kernel give the same result (different load pattern only)
+    h2 = torch.empty(B, H, device=dev)
+    st.xt = None; st.ht_out = None; st.h_out = h2.data_ptr()
+    _lib.call("t2_lstm_step_fwd", st, 1, st_)
+    torch.cuda.synchronize()
+    assert torch.equal(h2, h)
+
+
+@pytest.mark.parametrize("B,H,N4", [(32, 1024, 4096), (7, 48, 192), (33, 64, 256)])
+def test_lstm_step_bwd_packed_tiled(dev, B, H, N4):
+    """dx = dgates . W + pointwise cell backward on the packed path with x16-tiled gradients in and out, against the same
+    step with row-major operands (bit-identical) and float64."""
+    from tacotron2_amd import _lib
+    g = torch.Generator().manual_seed(B + N4)
+    W = torch.randn(N4, H, generator=g) / (N4 ** 0.5)
+    dg = torch.randn(B, N4, generator=g)
+    ext = torch.randn(B, H, generator=g)
+    gates = torch.rand(B, 4 * H, generator=g) * 0.8 + 0.1
+    cp = torch.randn(B, H, generator=g); cc = torch.randn(B, H, generator=g); dc0 = torch.randn(B, H, generator=g)
+    st_ = torch.cuda.current_stream().cuda_stream
+    Wd = W.to(dev)
+    nchpad = (N4 // 16 + 31) // 32 * 32
+    wtp = torch.empty((H + 15) // 16 * nchpad * 256, device=dev)
+    _lib.call("t2_lstm_pack_bwd", Wd, H, N4, None, 0, 0, H, wtp, st_)
+    Bp = (B + 15) // 16 * 16
+    dgt = _tile16(dg, Bp); dgt[:, B:] = float("nan"); dgt = dgt.to(dev)
+    res = []
+    for tiled in (False, True):
+        dc = dc0.clone().to(dev)
+        dgo = torch.empty(B, 4 * H, device=dev)
+        dgo_t = torch.zeros(4 * H // 16, Bp, 16, device=dev) if tiled else None
+        keep = [dg.to(dev), ext.to(dev), gates.to(dev), cp.to(dev), cc.to(dev)]
+        s = _lib.make("T2LstmBwdStep", B=B, H=H, N4=N4, dg_next=keep[0], lddg=N4, W=Wd, ldw=H, wtpacked=wtp, ncols=H, epi=1,
+                      ext1=keep[1], ldx1=H, gates=keep[2], ldgs=4 * H, c_prev=keep[3], ldcp=H, c_cur=keep[4], ldcc=H,
+                      dc=dc, lddc=H, dg_out=dgo, ldgo=4 * H, dgt_next=dgt if tiled else None, dgt_out=dgo_t)
+        _lib.call("t2_lstm_step_bwd", s, 1, st_)
+        torch.cuda.synchronize()
+        res.append((dgo.cpu(), dc.cpu(), None if dgo_t is None else _untile16(dgo_t.cpu(), B)))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[1][2], res[1][0])
+    dh = dg.double() @ W.double() + ext.double()
+    gi, gf, gg, go = [gates[:, i * H:(i + 1) * H].double() for i in range(4)]
+    tc = torch.tanh(cc.double())
+    dcv = dc0.double() + dh * go * (1 - tc * tc)
+    ref = torch.cat([dcv * gg * gi * (1 - gi), dcv * cp.double() * gf * (1 - gf), dcv * gi * (1 - gg * gg), dh * tc * go * (1 - go)], 1)
+    assert _rel(res[1][0], ref) < 5e-6 and _rel(res[1][1], dcv * gf) < 5e-6
+
+
 def test_lstm_step_bwd_matches_autograd(dev):
     from tacotron2_amd import _lib
     B, H = 19, 48
