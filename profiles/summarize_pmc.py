@@ -2,16 +2,22 @@
 """Summarise rocprofv3 --pmc passes (counter_collection.csv) per kernel: average counter value per launch, and the HBM
 traffic of one teacher-forced decoder step (forward frame-loop kernels).  FETCH_SIZE / WRITE_SIZE are in KB; on gfx950
 FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section) - the table prints raw and
-corrected (x2) values.  usage: summarize_pmc.py <counter_collection.csv> [...]"""
+corrected (x2) values.  usage: summarize_pmc.py [--steps=N --T=872] <counter_collection.csv> [...]"""
 import collections
 import csv
 import statistics
 import sys
 
-KEYS = ["lstm_step_fwd_fast", "lstm_step_bwd_fast", "attn_energy", "attn_context", "attn_bwd_dw", "attn_bwd_ds", "gemm_f32_mfma"]
+KEYS = ["lstm_step_fwd_fast", "lstm_step_bwd_fast", "attn_energy", "attn_context_co", "attn_context", "attn_bwd_dw", "attn_bwd_ds",
+        "gemm_f32_mfma"]
+# kernels of the teacher-forced forward frame loop (the BiLSTM uses lstm_step_fwd_fast with a different grid)
+FWD_LOOP = ("lstm_step_fwd_fast grid=65536", "attn_energy", "attn_context", "attn_context_co")
 
 
-def main(paths):
+def main(argv):
+    paths = [a for a in argv if not a.startswith("--")]
+    opts = dict(a[2:].split("=") for a in argv if a.startswith("--"))
+    n_steps, T = int(opts.get("steps", 2)), int(opts.get("T", 872))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for p in paths:
         for r in csv.DictReader(open(p)):
@@ -22,17 +28,16 @@ def main(paths):
                 name += f" grid={r['Grid_Size']}"
             agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print(f"{'kernel':44s} {'counter':10s} {'launches':>8s} {'avg/launch':>14s}")
-    per_step = 0.0
+    total = 0.0
     for name, d in sorted(agg.items()):
         for c, v in sorted(d.items()):
             print(f"{name:44s} {c:10s} {len(v):8d} {statistics.mean(v):14.1f}")
-            fwd = name.startswith("lstm_step_fwd_fast grid=65536") or name in ("attn_energy", "attn_context")
-            if fwd and c in ("FETCH_SIZE", "WRITE_SIZE"):
-                # the fwd LSTM kernel is launched twice per frame (attention cell + decoder cell): mean * 2
-                mult = 2 if name.startswith("lstm_step_fwd_fast") else 1
-                per_step += statistics.mean(v) * 1024 * mult * (2 if c == "FETCH_SIZE" else 1)
-    if per_step:
-        print(f"\nHBM-side traffic of the forward frame-loop kernels per decoder step (FETCH x2 corrected + WRITE): "
+            if name in FWD_LOOP and c in ("FETCH_SIZE", "WRITE_SIZE"):
+                total += sum(v) * 1024 * (2 if c == "FETCH_SIZE" else 1)
+    if total:
+        per_step = total / (n_steps * T)
+        print(f"\nHBM-side traffic of the forward frame-loop kernels (attention cell, energies, context [+ co-scheduled decoder "
+              f"cell], decoder cell) per decoder step, FETCH x2 corrected + WRITE, {n_steps} training steps x T={T}: "
               f"{per_step / 1e6:.1f} MB   (algorithmic bytes/step 89.1 MB at B=32, L=188)")
 
 
