@@ -113,6 +113,11 @@ typedef struct {
     int64_t xt, ht_out;
 } T2LstmStride;
 int t2_lstm_seq_fwd(const T2LstmStep* base, const T2LstmStride* inc, int n, int S, void* stream);
+/* Planned variant (see T2AttnSeq.plan): the operand blocks of all S steps are written into a host table, the caller keeps a
+ * device copy, and t2_lstm_seq_fwd_run launches steps [s_begin, s_end) with (table, step index) as the only arguments.
+ * `base` supplies the launch geometry (B, H, K); packed single-segment path, B <= 64. */
+int64_t t2_lstm_seq_fwd_plan(const T2LstmStep* base, const T2LstmStride* inc, int n, int S, void* host_tab, int64_t host_bytes);
+int t2_lstm_seq_fwd_run(const void* dev_tab, const T2LstmStep* base, int n, int s_begin, int s_end, void* stream);
 
 /* One step of back-propagation through time for an LSTM cell (autograd of the cells above):
  *   dx[b][u] = sum_n dg_next[b][n] * W[n*ldw + u]          (n over N4 = 4H' rows of the producing cell)
@@ -146,6 +151,9 @@ typedef struct { int64_t dg, dg2, ext1, ext2, drop, gates, c_prev, c_cur; int dt
 /* S steps; every pointer advances by its stride each step.  The caller lays the dgates stash out with one extra
  * zero-filled slot so that base[i].dg_next (the slot 'after' the first processed step) is valid and zero. */
 int t2_lstm_seq_bwd(const T2LstmBwdStep* base, const T2LstmBwdStride* inc, int n, int S, void* stream);
+int64_t t2_lstm_seq_bwd_plan(const T2LstmBwdStep* base, const T2LstmBwdStride* inc, int n, int S, void* host_tab,
+                             int64_t host_bytes);
+int t2_lstm_seq_bwd_run(const void* dev_tab, const T2LstmBwdStep* base, int n, int s_begin, int s_end, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Location-sensitive attention, one frame (model/attention.py:52-69 + cumulative update model/decoder.py:78-90).
@@ -167,6 +175,8 @@ typedef struct {
     float* w_out; int64_t ldwo; float* cum_out; int64_t ldco;
     float* ctx_out; int64_t ldctx; float* ctx_out2; int64_t ldctx2;
     float* ctxt_out; int ctxt_col0;          /* optional x16-tiled copy of the context (see T2LstmStep) */
+    uint64_t* clk;                           /* diagnostic, normally NULL: 32 device words; workgroup (0,0) stamps the shader
+                                                clock (s_memtime) at phase boundaries: energies [0..3], context [8..13] */
 } T2AttnStep;
 int t2_attn_fold_location(const float* Wd, const float* Wc, float* U, int Ad, int F, int Kl, void* stream);
 int t2_attn_step_fwd(const T2AttnStep* s, void* stream);
@@ -200,8 +210,19 @@ typedef struct {
      * stream) next to the latency-bound context kernel uses otherwise idle pipes.  Needs the packed single-segment path and
      * co_step->B <= 32 (else, and for steps beyond the frame range, the steps run as plain launches). */
     const T2LstmStep* co_step; const T2LstmStride* co_inc; int co_steps;
+    /* Optional kernel-parameter tables ("plan").  Every launch of the chain otherwise carries a 230-600 byte by-value
+     * operand block; a dependent launch costs 2.8 us with a 16-byte block and 3.4-3.7 us with 260-520 bytes
+     * (tools/ubench_kernarg.hip), so the blocks of all T frames are written ONCE into a table:
+     *   bytes = t2_attn_seq_fwd_plan(a, NULL, 0);  t2_attn_seq_fwd_plan(a, host_buffer, bytes);   (host side only)
+     * the caller copies the table to device memory that no kernel writes and sets `plan` to the device copy; launches
+     * then pass (table, frame index).  The plan covers all frames whatever t_begin/t_end were; with a plan the co-scheduled
+     * sequence is described once for the whole chain: co step i rides frame co_first + i (steps that would ride frames
+     * >= T are left to the caller).  The table must be rebuilt whenever any pointer or dimension changes. */
+    const void* plan; int co_first;
+    uint64_t* clk;                   /* diagnostic (T2AttnStep.clk), normally NULL */
 } T2AttnSeq;
 int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream);
+int64_t t2_attn_seq_fwd_plan(const T2AttnSeq* a, void* host_tab, int64_t host_bytes);   /* bytes required / written, -1 on error */
 
 /* Back-propagation through the attention chain, frames T-1 .. 0 (autograd of t2_attn_seq_fwd), 4 launches / frame:
  *   one launch for both products of dgates[t+1] (dctx_tot[t] = dctx_ext1[t] + dctx_ext2[t] + dgates[t+1].W_ih_ctx and
@@ -235,6 +256,8 @@ typedef struct {
      * launch; the ds workgroups are VALU/LDS bound, the step MFMA/memory bound).  Needs the packed path (wtpacked, dg_next,
      * no second segment); otherwise, and for steps beyond the frame range, the steps run as plain launches. */
     const T2LstmBwdStep* co_step; const T2LstmBwdStride* co_inc; int co_steps;
+    uint64_t* clk;                   /* diagnostic, normally NULL: 32 device words, s_memtime stamps of workgroup (0,0) at phase
+                                        boundaries of the dw kernel [16..19] and the ds kernel [24..30] */
 } T2AttnSeqBwd;
 int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream);
 

@@ -50,7 +50,7 @@ def _parse_header(path: str):
         structs[name] = fields
         order.append(name)
     funcs = {}
-    for m in re.finditer(r"\b(int|const\s+char\s*\*)\s+(t2_\w+)\s*\((.*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(int64_t|int|const\s+char\s*\*)\s+(t2_\w+)\s*\((.*?)\)\s*;", src, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         alist = []
         if args and args != "void":
@@ -97,7 +97,7 @@ def lib():
     L = C.CDLL(LIB_PATH)
     for name, (ret, alist) in _funcs.items():
         fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
-        fn.restype = C.c_char_p if "char" in ret else C.c_int
+        fn.restype = C.c_char_p if "char" in ret else (C.c_int64 if ret == "int64_t" else C.c_int)
         fn.argtypes = [C.c_void_p if p else _SCALARS[b] for b, p in alist]
     _lib = L
     return L
@@ -123,6 +123,14 @@ def call(name: str, *args):
     rc = fn(*conv)
     if rc != 0:
         raise T2Error(f"{name} failed (rc={rc}): {L.t2_last_error().decode()}")
+
+
+def call_value(name: str, *args):
+    """Call a function whose return value is data (the *_plan functions return a byte count, -1 on error)."""
+    L = lib()
+    fn = getattr(L, name)
+    conv = [(_addr(a) if at is C.c_void_p else a) for a, at in zip(args, fn.argtypes)]
+    return fn(*conv)
 
 
 def make(struct_name: str, **kw):

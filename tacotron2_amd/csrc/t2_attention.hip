@@ -22,6 +22,8 @@ int t2_lstm_step_fwd_launch(const T2LstmStep* steps, int n, hipStream_t st);
 int t2_lstm_step_bwd_launch(const T2LstmBwdStep* steps, int n, hipStream_t st);
 void t2_lstm_fwd_advance(T2LstmStep& c, const T2LstmStride& inc);
 void t2_lstm_bwd_advance(T2LstmBwdStep& c, const T2LstmBwdStride& inc);
+int t2_lstm_step_fwd_tab(const T2LstmStep* steps, int n, hipStream_t st, LstmK2* fill, const LstmK2* tab, int idx);
+int t2_lstm_step_bwd_tab(const T2LstmBwdStep* steps, int n, hipStream_t st, BwdK2* fill, const BwdK2* tab, int idx);
 
 namespace {
 
@@ -37,7 +39,9 @@ struct AttnK {
     float* w_out; long ldwo; float* cum_out; long ldco;
     float* ctx_out; long ldctx; float* ctx_out2; long ldctx2;
     float* ctxt_out; int ctxt_col0; long ctxt_cs;
+    unsigned long long* clk;   // diagnostic: shader-clock stamps of workgroup (0,0) (T2AttnStep.clk), or null
 };
+#define T2_STAMP(p, cond, i) do { if ((p).clk && (cond)) (p).clk[i] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // Load discipline for these one-workgroup-per-CU kernels: every global load of a phase is ISSUED (unconditionally, from a
 // clamped in-range address) before anything waits on one; out-of-range lanes are zeroed by a select afterwards.  A
@@ -46,22 +50,57 @@ struct AttnK {
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
-// Stage the haloed location inputs (w_prev, cum_prev) and this slice's folded filter rows into LDS (NTH threads).
+// Stage the haloed location inputs (w_prev, cum_prev) and this slice's folded filter rows into LDS (NTH threads), split
+// into an ISSUE half (global loads into registers) and a COMMIT half (LDS writes) so that a kernel can put its other
+// loads between the two: everything is in flight before anything is waited for.
 template <int NTH>
-__device__ __forceinline__ void stage_inp_U(float* inp, float* Us, const float* w_prev, long ldw, const float* cum_prev,
-                                            long ldcum, const float* U, const float* dummy, int b, int j, int L, int Lp,
-                                            int tid) {
+struct StageRegs { float uv[1024 / NTH]; float iv[1024 / NTH]; };
+
+template <int NTH>
+__device__ __forceinline__ void stage_issue(StageRegs<NTH>& r, const float* w_prev, long ldw, const float* cum_prev, long ldcum,
+                                            const float* U, const float* dummy, int b, int j, int L, int Lp, int tid) {
+    constexpr int PER = 1024 / NTH;
+    const float* wsrc = w_prev ? w_prev + (long)b * ldw : dummy;
+    const float* csrc = cum_prev ? cum_prev + (long)b * ldcum : dummy;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {   // Us[al][c][32]: taps 0..30 of channel c, tap 31 = 0 (rows padded for aligned 16-byte reads)
+        const int idx = tid + NTH * i, al = idx >> 6, c = (idx >> 5) & 1, k = idx & 31;
+        r.uv[i] = U[(long)(j * 16 + al) * 2 * KL + c * KL + imin(k, KL - 1)];
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int idx = tid + NTH * i;
+        const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
+        const int lc = imin(imax(l, 0), L - 1);
+        r.iv[i] = (c ? csrc : wsrc)[lc];
+    }
+}
+
+// inpO (optional): the same two rows shifted by one float (inpO[c][x] = inp[c][x + 1]), so that the odd-aligned pairs of a
+// sliding window can be fetched with aligned 16-byte LDS reads too (the convolutions run on v_pk_fma_f32 pairs).
+template <int NTH>
+__device__ __forceinline__ void stage_commit(const StageRegs<NTH>& r, float* inp, float* Us, const float* w_prev, long ldw,
+                                             const float* cum_prev, long ldcum, const float* dummy, int b, int L, int Lp, int tid,
+                                             float* inpO = nullptr) {
     constexpr int PER = 1024 / NTH;
     const float* wsrc = w_prev ? w_prev + (long)b * ldw : dummy;
     const float* csrc = cum_prev ? cum_prev + (long)b * ldcum : dummy;
     const bool wz = w_prev == nullptr, cz = cum_prev == nullptr;
-    float uv[PER];   // Us[al][c][32]: taps 0..30 of channel c, tap 31 = 0 (rows padded for aligned 16-byte reads)
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const int idx = tid + NTH * i, al = idx >> 6, c = (idx >> 5) & 1, k = idx & 31;
-        uv[i] = U[(long)(j * 16 + al) * 2 * KL + c * KL + imin(k, KL - 1)];
+        const int idx = tid + NTH * i;
+        const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
+        const bool ok = l >= 0 && l < L && !(c ? cz : wz);
+        if (idx < 2 * Lp) {
+            const float v = ok ? r.iv[i] : 0.f;
+            inp[idx] = v;
+            if (inpO) {
+                if (idx != c * Lp) inpO[idx - 1] = v;
+                if (idx == c * Lp + Lp - 1) inpO[idx] = 0.f;
+            }
+        }
     }
-    for (int base = 0; base < 2 * Lp; base += 1024) {
+    for (int base = 1024; base < 2 * Lp; base += 1024) {   // long texts (2*Lp > 1024): further rounds, load then store
         float iv[PER];
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
@@ -75,14 +114,30 @@ __device__ __forceinline__ void stage_inp_U(float* inp, float* Us, const float* 
             const int idx = base + tid + NTH * i;
             const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
             const bool ok = l >= 0 && l < L && !(c ? cz : wz);
-            if (idx < 2 * Lp) inp[idx] = ok ? iv[i] : 0.f;
+            if (idx < 2 * Lp) {
+                const float v = ok ? iv[i] : 0.f;
+                inp[idx] = v;
+                if (inpO) {
+                    if (idx != c * Lp) inpO[idx - 1] = v;
+                    if (idx == c * Lp + Lp - 1) inpO[idx] = 0.f;
+                }
+            }
         }
     }
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int idx = tid + NTH * i;
-        Us[idx] = (idx & 31) < KL ? uv[i] : 0.f;
+        Us[idx] = (idx & 31) < KL ? r.uv[i] : 0.f;
     }
+}
+
+template <int NTH>
+__device__ __forceinline__ void stage_inp_U(float* inp, float* Us, const float* w_prev, long ldw, const float* cum_prev,
+                                            long ldcum, const float* U, const float* dummy, int b, int j, int L, int Lp,
+                                            int tid) {
+    StageRegs<NTH> r;
+    stage_issue<NTH>(r, w_prev, ldw, cum_prev, ldcum, U, dummy, b, j, L, Lp, tid);
+    stage_commit<NTH>(r, inp, Us, w_prev, ldw, cum_prev, ldcum, dummy, b, L, Lp, tid);
 }
 
 constexpr int ENT = 512;   // threads of the energy / ds kernels: two waves per SIMD double the VALU issue rate
@@ -105,91 +160,144 @@ __device__ __forceinline__ void load_taps(const float* Us, int al, float (&uk)[2
 
 __device__ __forceinline__ void attn_energy_body(const AttnK& p, const int b, const int j, float* sm) {
     const int tid = threadIdx.x, lane = tid & 63;
+    const bool stamp = b == 0 && j == 0 && tid == 0;
+    T2_STAMP(p, stamp, 0);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
     const int al = tid >> 5, sub = tid & 31, a = j * 16 + al;
     const int L = p.L, NG = (L + 3) >> 2, Lp = 4 * NG + 36;
     float* inp = sm;             // [2][Lp]   zero-haloed (w_prev, cum_prev), index l + 15
-    float* Us = inp + 2 * Lp;    // [16][2][32] folded location filter rows of this slice
+    float* inpO = inp + 2 * Lp;  // [2][Lp]   the same rows shifted by one float (odd-aligned window pairs)
+    float* Us = inpO + 2 * Lp;   // [16][2][32] folded location filter rows of this slice
     float* qs = Us + 16 * 64;    // [16]
     float* ec = qs + 16;         // [16][4*NG] per-dim energy contributions
     const long rowoff = ((long)b * p.Ad + a) * L;
 
+    // ---- issue first: the haloed location inputs and filter rows (the only loads the convolution waits for) ----
+    StageRegs<ENT> sr;
+    stage_issue<ENT>(sr, p.w_prev, p.ldw, p.cum_prev, p.ldcum, p.U, p.pmT, b, j, L, Lp, tid);
     // ---- issue: first round of processed-memory values + v ----
     float pmv[EMAXI][4];
     const float va = p.v[a];
 #pragma unroll
     for (int it = 0; it < EMAXI; ++it) {
-        const int lg = imin(sub + 32 * it, NG - 1);
+        const int lg = imin(2 * sub + it, NG - 1);   // a thread owns two ADJACENT 4-position groups (8 positions)
 #pragma unroll
         for (int i = 0; i < 4; ++i) pmv[it][i] = p.pmT[rowoff + imin(4 * lg + i, L - 1)];
     }
-    // ---- issue + accumulate: query projection (2 dims per wave, 16-byte loads) ----
-    float qacc[2] = {0.f, 0.f};
+    // ---- issue: query-projection operands of the first 1024 columns (2 dims per wave, 16-byte loads).  They are consumed
+    //      AFTER the location convolution, which does not depend on the query: the 64 KB of Wq rows arrive while the
+    //      convolution runs, and only the small staging loads sit in front of it ----
     const float* h = p.att_h + (long)b * p.ldh;
     const float* wq0 = p.Wq + (long)(j * 16 + w * 2) * p.A;
-    for (int k0 = lane * 4; k0 < p.A; k0 += 1024) {
-        f32x4 hv[4], wv[2][4];
+    f32x4 hv[4], wv[2][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = imin(k0 + 256 * i, p.A - 4);
-            hv[i] = *reinterpret_cast<const f32x4*>(h + k);
+    for (int i = 0; i < 4; ++i) {
+        const int k = imin(lane * 4 + 256 * i, p.A - 4);
+        hv[i] = *reinterpret_cast<const f32x4*>(h + k);
 #pragma unroll
-            for (int aa = 0; aa < 2; ++aa) wv[aa][i] = *reinterpret_cast<const f32x4*>(wq0 + (long)aa * p.A + k);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float okf = (k0 + 256 * i) < p.A ? 1.f : 0.f;
-#pragma unroll
-            for (int aa = 0; aa < 2; ++aa)
-                qacc[aa] += okf * (hv[i][0] * wv[aa][i][0] + hv[i][1] * wv[aa][i][1] + hv[i][2] * wv[aa][i][2] +
-                                   hv[i][3] * wv[aa][i][3]);
-        }
+        for (int aa = 0; aa < 2; ++aa) wv[aa][i] = *reinterpret_cast<const f32x4*>(wq0 + (long)aa * p.A + k);
     }
-    stage_inp_U<ENT>(inp, Us, p.w_prev, p.ldw, p.cum_prev, p.ldcum, p.U, p.pmT, b, j, L, Lp, tid);
-#pragma unroll
-    for (int aa = 0; aa < 2; ++aa) {
-        const float sq = t2_wave_sum(qacc[aa]);
-        if (lane == 0) qs[w * 2 + aa] = sq;
-    }
-    __syncthreads();
+    stage_commit<ENT>(sr, inp, Us, p.w_prev, p.ldw, p.cum_prev, p.ldcum, p.pmT, b, L, Lp, tid, inpO);
+    __syncthreads();   // staging visible
+    T2_STAMP(p, stamp, 1);
 
-    float uk[2][32];
-    load_taps(Us, al, uk);
-    const float qa = qs[al];
+    float qa = 0.f;
     for (int base = 0; base < NG; base += 32 * EMAXI) {
         if (base > 0) {   // later rounds (L > 256)
 #pragma unroll
             for (int it = 0; it < EMAXI; ++it) {
-                const int lg = imin(base + sub + 32 * it, NG - 1);
+                const int lg = imin(base + 2 * sub + it, NG - 1);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) pmv[it][i] = p.pmT[rowoff + imin(4 * lg + i, L - 1)];
             }
         }
-#pragma unroll
-        for (int it = 0; it < EMAXI; ++it) {
-            const int lg = base + sub + 32 * it;
-            if (lg >= NG) continue;
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+        // 8 adjacent positions x 31 taps x 2 channels on packed FMAs.  Position pairs (0,1) (2,3) (4,5) (6,7) are the halves
+        // of four v_pk_fma_f32 accumulators; the window pairs (win[k], win[k+1]) are register pairs of the aligned LDS read
+        // for even k and of the shifted copy for odd k (no repacking moves), the tap is broadcast through op_sel.  The two
+        // groups share one 40-float window: 20 x 16-byte LDS reads per channel instead of 36 (the loop is LDS-read bound).
+        float acc[EMAXI][4];
+        {
+            const int lg0 = imin(base + 2 * sub, NG - 1);
+            f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f}, a45 = {0.f, 0.f}, a67 = {0.f, 0.f};
+#pragma nounroll
             for (int c = 0; c < 2; ++c) {
-                float win[36];
-                const f32x4* wp = reinterpret_cast<const f32x4*>(inp + c * Lp + 4 * lg);
+                float ukc[32];   // this channel's taps (read per channel: both channels' taps at once spill registers)
+                {
+                    const f32x4* up = reinterpret_cast<const f32x4*>(Us + al * 64 + c * 32);
 #pragma unroll
-                for (int i = 0; i < 9; ++i) {
-                    const f32x4 t = wp[i];
-                    win[4 * i] = t[0]; win[4 * i + 1] = t[1]; win[4 * i + 2] = t[2]; win[4 * i + 3] = t[3];
+                    for (int i = 0; i < 8; ++i) {
+                        const f32x4 t = up[i];
+                        ukc[4 * i] = t[0]; ukc[4 * i + 1] = t[1]; ukc[4 * i + 2] = t[2]; ukc[4 * i + 3] = t[3];
+                    }
+                }
+                // even taps against the aligned window pairs, then odd taps against the shifted copy (one window live at a time)
+#pragma nounroll
+                for (int par = 0; par < 2; ++par) {
+                    f32x2 wp2[20];
+                    const f32x4* wp = reinterpret_cast<const f32x4*>((par ? inpO : inp) + c * Lp + 4 * lg0);
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) {
+                        const f32x4 t = wp[i];
+                        wp2[2 * i] = (f32x2){t[0], t[1]}; wp2[2 * i + 1] = (f32x2){t[2], t[3]};
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk) {       // taps par, par + 2, ...: compile-time register indices
+                        const float uv = par ? ukc[(2 * kk + 1) & 31] : ukc[2 * kk];   // tap 31 is the zero pad
+                        const f32x2 u = {uv, uv};
+                        a01 = __builtin_elementwise_fma(u, wp2[kk], a01);
+                        a23 = __builtin_elementwise_fma(u, wp2[kk + 1], a23);
+                        a45 = __builtin_elementwise_fma(u, wp2[kk + 2], a45);
+                        a67 = __builtin_elementwise_fma(u, wp2[kk + 3], a67);
+                    }
+                }
+            }
+            acc[0][0] = a01[0]; acc[0][1] = a01[1]; acc[0][2] = a23[0]; acc[0][3] = a23[1];
+            acc[1][0] = a45[0]; acc[1][1] = a45[1]; acc[1][2] = a67[0]; acc[1][3] = a67[1];
+        }
+        T2_STAMP(p, stamp && base == 0, 4);
+        if (base == 0) {   // query projection: dot products of the hoisted operands (+ the columns past 1024), wave sums
+            float qacc[2] = {0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float okf = (lane * 4 + 256 * i) < p.A ? 1.f : 0.f;
+#pragma unroll
+                for (int aa = 0; aa < 2; ++aa)
+                    qacc[aa] += okf * (hv[i][0] * wv[aa][i][0] + hv[i][1] * wv[aa][i][1] + hv[i][2] * wv[aa][i][2] +
+                                       hv[i][3] * wv[aa][i][3]);
+            }
+            for (int k0 = lane * 4 + 1024; k0 < p.A; k0 += 1024) {
+                f32x4 hv2[4], wv2[2][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = imin(k0 + 256 * i, p.A - 4);
+                    hv2[i] = *reinterpret_cast<const f32x4*>(h + k);
+#pragma unroll
+                    for (int aa = 0; aa < 2; ++aa) wv2[aa][i] = *reinterpret_cast<const f32x4*>(wq0 + (long)aa * p.A + k);
                 }
 #pragma unroll
-                for (int k = 0; k < KL; ++k)
+                for (int i = 0; i < 4; ++i) {
+                    const float okf = (k0 + 256 * i) < p.A ? 1.f : 0.f;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(uk[c][k], win[i + k], acc[i]);
+                    for (int aa = 0; aa < 2; ++aa)
+                        qacc[aa] += okf * (hv2[i][0] * wv2[aa][i][0] + hv2[i][1] * wv2[aa][i][1] + hv2[i][2] * wv2[aa][i][2] +
+                                           hv2[i][3] * wv2[aa][i][3]);
+                }
             }
+            // wave w computed dims 2w and 2w+1 - exactly the dims of its own lanes (al = tid >> 5): no exchange, no barrier
+            const float sq0 = t2_wave_sum(qacc[0]), sq1 = t2_wave_sum(qacc[1]);
+            qa = lane < 32 ? sq0 : sq1;
+            T2_STAMP(p, stamp, 5);
+        }
+#pragma unroll
+        for (int it = 0; it < EMAXI; ++it) {
+            const int lg = base + 2 * sub + it;
+            if (lg >= NG) continue;
             f32x4 th4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int l = 4 * lg + i;
                 if (l < L) {
-                    th4[i] = t2_tanh(qa + acc[i] + pmv[it][i]);
+                    th4[i] = t2_tanh(qa + acc[it][i] + pmv[it][i]);
                     ec[al * 4 * NG + l] = va * th4[i];
                 }
             }
@@ -197,6 +305,7 @@ __device__ __forceinline__ void attn_energy_body(const AttnK& p, const int b, co
             if (p.th_out) *reinterpret_cast<f32x4*>(p.th_out + ((long)b * p.Ad + a) * (4 * NG) + 4 * lg) = th4;
         }
     }
+    T2_STAMP(p, stamp, 2);
     __syncthreads();
     for (int l = tid; l < L; l += ENT) {
         float s = 0.f;
@@ -204,6 +313,7 @@ __device__ __forceinline__ void attn_energy_body(const AttnK& p, const int b, co
         for (int al2 = 0; al2 < 16; ++al2) s += ec[al2 * 4 * NG + l];
         p.e_part[((long)b * (p.Ad >> 4) + j) * L + l] = s;
     }
+    T2_STAMP(p, stamp, 3);
 }
 
 __global__ __launch_bounds__(ENT, 2) void attn_energy_kernel(AttnK p) {
@@ -214,27 +324,44 @@ __global__ __launch_bounds__(ENT, 2) void attn_energy_kernel(AttnK p) {
 
 __device__ __forceinline__ void attn_context_body(const AttnK& p, const int b, const int es0, float* sm) {
     const int tid = threadIdx.x;
+    const bool stamp = b == 0 && es0 == 0 && tid == 0;
+    T2_STAMP(p, stamp, 8);
     const int L = p.L, NA = p.Ad >> 4;
-    float* ws = sm;                       // [L rounded to 4]
-    float* red = ws + ((L + 3) & ~3);     // [8]
-    float* part = red + 8;                // [8][32]
-    // ---- issue: encoder-memory slice of the first 192 positions (independent of the softmax) ----
     constexpr int NR = 24;
+    const int WS = imax((L + 3) & ~3, 8 * NR);
+    float* ws = sm;                       // [max(L rounded to 4, 8*NR)] softmax weights, zero past L
+    float* red = ws + WS;                 // [8]
+    float* part = red + 8;                // [8][32]
     const int el = tid & 31, lg = tid >> 5;
+    if (L + tid < 8 * NR) ws[L + tid] = 0.f;   // zero weights for the register rows past L: the product loop is branch-free
+    // ---- issue FIRST what the softmax waits for: the partial energies of position tid (first 8 slices) and the length;
+    //      loads return in order, so the 24 memory rows below must not sit in front of them ----
+    const int len = p.len[b];
+    float ev0[8];
+    {
+        const int lc = imin(tid, L - 1);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) ev0[jj] = p.e_part[((long)b * NA + imin(jj, NA - 1)) * L + lc];
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep these loads in front (the scheduler otherwise sinks them behind the rows below)
+    // ---- issue: encoder-memory slice of the first 192 positions (independent of the softmax, consumed after it) ----
     const float* mp = p.memory + (long)b * L * p.Ef + es0 + el;
     float mv[NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) mv[i] = mp[(long)imin(lg + 8 * i, L - 1) * p.Ef];
-    // ---- issue: partial energies of this thread's position(s), previous cumulative weights, length ----
-    const int len = p.len[b];
     float mx = -INFINITY;
     for (int l0 = 0; l0 < L; l0 += 256) {
         const int l = l0 + tid, lc = imin(l, L - 1);
         float ev[8];
         float e = 0.f;
         for (int j0 = 0; j0 < NA; j0 += 8) {
+            if (l0 == 0 && j0 == 0) {
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) ev[jj] = p.e_part[((long)b * NA + imin(j0 + jj, NA - 1)) * L + lc];
+                for (int jj = 0; jj < 8; ++jj) ev[jj] = ev0[jj];
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) ev[jj] = p.e_part[((long)b * NA + imin(j0 + jj, NA - 1)) * L + lc];
+            }
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) e += (j0 + jj) < NA ? ev[jj] : 0.f;
         }
@@ -249,6 +376,7 @@ __device__ __forceinline__ void attn_context_body(const AttnK& p, const int b, c
 #pragma unroll
         for (int r = 0; r < 2; ++r) cprev[r] = p.cum_prev[(long)b * p.ldcum + imin(tid + 256 * r, L - 1)];
     }
+    T2_STAMP(p, stamp, 9);
     mx = t2_block_max(mx, red);
     float sum = 0.f;
     for (int l = tid; l < L; l += 256) {
@@ -257,6 +385,7 @@ __device__ __forceinline__ void attn_context_body(const AttnK& p, const int b, c
         sum += pe;
     }
     sum = t2_block_sum(sum, red);
+    T2_STAMP(p, stamp, 10);
     for (int l = tid, r = 0; l < L; l += 256, ++r) {
         const float wv = ws[l] / sum;
         ws[l] = wv;
@@ -269,15 +398,18 @@ __device__ __forceinline__ void attn_context_body(const AttnK& p, const int b, c
         }
     }
     __syncthreads();
+    T2_STAMP(p, stamp, 11);
+    // all 24 weights are read from LDS before the first use (a guarded `load -> wait -> fma` chain costs 24 LDS latencies)
+    float wv24[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) wv24[i] = ws[lg + 8 * i];
     float acc = 0.f;
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const int l = lg + 8 * i;
-        if (l < L) acc = fmaf(ws[l], mv[i], acc);
-    }
+    for (int i = 0; i < NR; ++i) acc = fmaf(wv24[i], mv[i], acc);
 #pragma unroll 8
     for (int l = lg + 8 * NR; l < L; l += 8) acc = fmaf(ws[l], mp[(long)l * p.Ef], acc);
     part[lg * 32 + el] = acc;
+    T2_STAMP(p, stamp, 12);
     __syncthreads();
     if (tid < 32) {
         float s2 = 0.f;
@@ -287,6 +419,7 @@ __device__ __forceinline__ void attn_context_body(const AttnK& p, const int b, c
         if (p.ctx_out2) p.ctx_out2[(long)b * p.ldctx2 + es0 + tid] = s2;
         if (p.ctxt_out) { const int col = p.ctxt_col0 + es0 + tid; p.ctxt_out[(long)(col >> 4) * p.ctxt_cs + b * 16 + (col & 15)] = s2; }
     }
+    T2_STAMP(p, stamp, 13);
 }
 
 __global__ __launch_bounds__(256, 1) void attn_context_kernel(AttnK p) {
@@ -333,24 +466,90 @@ void to_ak(const T2AttnStep& s, AttnK& k) {
     k.w_out = s.w_out; k.ldwo = s.ldwo; k.cum_out = s.cum_out; k.ldco = s.ldco;
     k.ctx_out = s.ctx_out; k.ldctx = s.ldctx; k.ctx_out2 = s.ctx_out2; k.ldctx2 = s.ldctx2;
     k.ctxt_out = s.ctxt_out; k.ctxt_col0 = s.ctxt_col0; k.ctxt_cs = (long)((s.B + 15) / 16 * 16) * 16;
+    k.clk = (unsigned long long*)s.clk;
 }
+
+// Table variants: the operand block comes from a device-resident table entry (16-byte kernel-argument block; see
+// lstm_step_fwd_fast_tab_kernel).
+__global__ __launch_bounds__(ENT, 2) void attn_energy_tab_kernel(const T2_CONST_AS AttnK* tab, int idx) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const AttnK p = t2_tab_entry(&tab[idx]);
+    attn_energy_body(p, blockIdx.x, blockIdx.y, sm);
+}
+__global__ __launch_bounds__(256, 1) void attn_context_tab_kernel(const T2_CONST_AS AttnK* tab, int idx) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const AttnK p = t2_tab_entry(&tab[idx]);
+    attn_context_body(p, blockIdx.x, blockIdx.y * 32, sm);
+}
+template <int MT>
+__global__ __launch_bounds__(256, 3) void attn_context_co_tab_kernel(const T2_CONST_AS AttnK* tab, const T2_CONST_AS LstmK* ctab, int idx,
+                                                                     int nC) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int bid = blockIdx.x;
+    if (bid < nC) {
+        const AttnK p = t2_tab_entry(&tab[idx]);
+        attn_context_body(p, bid % p.B, (bid / p.B) * 32, sm);
+    } else {
+        const LstmK c = t2_tab_entry(&ctab[idx]);
+        t2_lstm_fwd_fast_body<MT, 4>(c, bid - nC, sm);
+    }
+}
+
+// Per-frame parameter tables of one teacher-forced attention chain (t2_attn_seq_fwd_plan): [T x cell][T x attention][T x co]
+struct FwdTabs { LstmK2* cell; AttnK* attn; LstmK* co; };
+inline int64_t fwd_tab_bytes(int T) { return (int64_t)T * (sizeof(LstmK2) + sizeof(AttnK) + sizeof(LstmK)); }
+inline FwdTabs fwd_tabs(const void* base, int T) {
+    char* p = (char*)base;
+    FwdTabs v;
+    v.cell = (LstmK2*)p; p += (size_t)T * sizeof(LstmK2);
+    v.attn = (AttnK*)p; p += (size_t)T * sizeof(AttnK);
+    v.co = (LstmK*)p;
+    return v;
+}
+enum { T2_BY_VALUE = 0, T2_FILL = 1, T2_TABLE = 2 };
 
 // A cell step can ride in the context launch if it takes the packed single-segment path with <= 32 batch rows.
 bool co_eligible(const T2LstmStep& c) { return c.wpacked && c.nseg == 1 && c.B <= 32 && c.H % 4 == 0; }
 
-int launch_attn(const T2AttnStep& s, hipStream_t st, const T2LstmStep* co = nullptr) {
+int launch_attn(const T2AttnStep& s, hipStream_t st, const T2LstmStep* co = nullptr, int mode = T2_BY_VALUE,
+                const FwdTabs* tabs = nullptr, int idx = 0) {
     AttnK k;
     to_ak(s, k);
     const int NG = (s.L + 3) >> 2, Lp = 4 * NG + 36;
-    const size_t sm_e = (size_t)(2 * Lp + 16 * 64 + 16 + 16 * 4 * NG) * sizeof(float);
-    const size_t sm_c = (size_t)(((s.L + 3) & ~3) + 8 + 256) * sizeof(float);
-    hipLaunchKernelGGL(attn_energy_kernel, dim3(s.B, s.Ad / 16), dim3(ENT), sm_e, st, k);
+    const size_t sm_e = (size_t)(4 * Lp + 16 * 64 + 16 + 16 * 4 * NG) * sizeof(float);
+    const int wsn = ((s.L + 3) & ~3) > 192 ? ((s.L + 3) & ~3) : 192;
+    const size_t sm_c = (size_t)(wsn + 8 + 256) * sizeof(float);
+    LstmK ck;
+    int MT = 1;
+    size_t smx = sm_c;
     if (co) {
         T2_TRY(t2_lstm_check_step(*co));
-        LstmK ck;
         t2_lstm_to_k(*co, ck, 0, co->B);
-        const int MT = co->B <= 16 ? 1 : 2, nC = s.B * (s.Ef / 32);
-        const size_t sm_co = (size_t)4 * MT * 256 * sizeof(float), smx = sm_c > sm_co ? sm_c : sm_co;
+        MT = co->B <= 16 ? 1 : 2;
+        const size_t sm_co = (size_t)4 * MT * 256 * sizeof(float);
+        smx = sm_c > sm_co ? sm_c : sm_co;
+    }
+    const int nC = s.B * (s.Ef / 32);
+    if (mode == T2_FILL) {
+        tabs->attn[idx] = k;
+        if (co) tabs->co[idx] = ck;
+        return T2_OK;
+    }
+    if (mode == T2_TABLE) {
+        const T2_CONST_AS AttnK* at = (const T2_CONST_AS AttnK*)tabs->attn;
+        const T2_CONST_AS LstmK* ct = (const T2_CONST_AS LstmK*)tabs->co;
+        hipLaunchKernelGGL(attn_energy_tab_kernel, dim3(s.B, s.Ad / 16), dim3(ENT), sm_e, st, at, idx);
+        if (co) {
+            if (MT == 1) hipLaunchKernelGGL(attn_context_co_tab_kernel<1>, dim3(nC + co->H / 4), dim3(256), smx, st, at, ct, idx, nC);
+            else hipLaunchKernelGGL(attn_context_co_tab_kernel<2>, dim3(nC + co->H / 4), dim3(256), smx, st, at, ct, idx, nC);
+        } else {
+            hipLaunchKernelGGL(attn_context_tab_kernel, dim3(s.B, s.Ef / 32), dim3(256), sm_c, st, at, idx);
+        }
+        T2_CHECK_LAUNCH();
+        return T2_OK;
+    }
+    hipLaunchKernelGGL(attn_energy_kernel, dim3(s.B, s.Ad / 16), dim3(ENT), sm_e, st, k);
+    if (co) {
         if (MT == 1) hipLaunchKernelGGL(attn_context_co_kernel<1>, dim3(nC + co->H / 4), dim3(256), smx, st, k, ck, nC);
         else hipLaunchKernelGGL(attn_context_co_kernel<2>, dim3(nC + co->H / 4), dim3(256), smx, st, k, ck, nC);
     } else {
@@ -382,20 +581,27 @@ extern "C" int t2_attn_step_fwd(const T2AttnStep* s, void* stream) {
 }
 
 // Teacher-forced attention chain over all T frames: per frame  attention-LSTMCell -> energies -> softmax/context.
-extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
-    T2_REQUIRE(a != nullptr, "t2_attn_seq_fwd: null");
-    hipStream_t st = (hipStream_t)stream;
+// mode T2_BY_VALUE: launch frames [t_begin, t_end) with by-value operand blocks (co step i rides frame t_begin + i);
+// mode T2_FILL: write the tables of ALL T frames (co step i rides frame co_first + i);  mode T2_TABLE: launch frames
+// [t_begin, t_end) from the device tables.
+static int attn_seq_fwd_core(const T2AttnSeq* a, hipStream_t st, int mode, const FwdTabs* tabs) {
     const int B = a->B, L = a->L, T = a->T, A = a->A, Ef = a->Ef, Ad = a->Ad;
     const long ldx = A + Ef;
-    const int tb = (a->t_begin == 0 && a->t_end == 0) ? 0 : a->t_begin, te = (a->t_begin == 0 && a->t_end == 0) ? T : a->t_end;
+    int tb = (a->t_begin == 0 && a->t_end == 0) ? 0 : a->t_begin, te = (a->t_begin == 0 && a->t_end == 0) ? T : a->t_end;
     T2_REQUIRE(tb >= 0 && te <= T && tb <= te, "t2_attn_seq_fwd: bad frame range");
     T2_REQUIRE(!a->xdec_t || (a->wpacked && (A + Ef) % 16 == 0 && A % 16 == 0), "t2_attn_seq_fwd: xdec_t needs wpacked and A, Ef multiples of 16");
+    if (mode == T2_FILL) { tb = 0; te = T; }
     T2LstmStep co;
-    int co_left = 0;
+    int co_left = 0, co_at = tb;     // co step rides frames co_at, co_at + 1, ... while co_left > 0
     bool co_ride = false;
     if (a->co_step && a->co_steps > 0) {
         T2_REQUIRE(a->co_inc != nullptr, "t2_attn_seq_fwd: co_inc required with co_step");
         co = *a->co_step; co_left = a->co_steps; co_ride = co_eligible(co);
+        if (mode != T2_BY_VALUE) {
+            T2_REQUIRE(co_ride && a->co_first >= 0, "t2_attn_seq_fwd: planned co-scheduling needs an eligible cell and co_first >= 0");
+            co_at = a->co_first;
+            for (; co_at < tb && co_left > 0; ++co_at, --co_left) t2_lstm_fwd_advance(co, *a->co_inc);   // skip to the range
+        }
     }
     for (int t = tb; t < te; ++t) {
         T2LstmStep s;
@@ -420,7 +626,8 @@ extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
         s.h_out = slot1; s.ldh = ldx;
         s.c_out = a->att_c + (long)(t + 1) * B * A; s.ldc_out = A;
         if (a->gates) { s.gates_out = a->gates + (long)t * B * 4 * A; s.ldg = 4 * A; }
-        T2_TRY(t2_lstm_step_fwd_launch(&s, 1, st));
+        if (mode == T2_BY_VALUE) T2_TRY(t2_lstm_step_fwd_launch(&s, 1, st));
+        else T2_TRY(t2_lstm_step_fwd_tab(&s, 1, st, mode == T2_FILL ? &tabs->cell[t] : nullptr, mode == T2_TABLE ? tabs->cell : nullptr, t));
 
         T2AttnStep q;
         memset(&q, 0, sizeof(q));
@@ -435,19 +642,41 @@ extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
         q.ctx_out = slot1 + A; q.ldctx = ldx;
         if (a->xproj_ctx) { q.ctx_out2 = a->xproj_ctx + (long)t * B * a->ld_xproj; q.ldctx2 = a->ld_xproj; }
         if (a->xdec_t) { q.ctxt_out = a->xdec_t + (long)(t + 1) * xts; q.ctxt_col0 = A; }
+        q.clk = a->clk;
         if (t == tb) T2_TRY(check_attn(q));
-        if (co_left > 0 && co_ride) {
-            T2_TRY(launch_attn(q, st, &co));
+        if (co_left > 0 && co_ride && t >= co_at) {
+            T2_TRY(launch_attn(q, st, &co, mode, tabs, t));
             t2_lstm_fwd_advance(co, *a->co_inc); --co_left;
         } else {
-            T2_TRY(launch_attn(q, st));
+            T2_TRY(launch_attn(q, st, nullptr, mode, tabs, t));
         }
     }
-    for (; co_left > 0; --co_left) {   // co-scheduled steps that did not ride in an energy launch
-        T2_TRY(t2_lstm_step_fwd_launch(&co, 1, st));
-        t2_lstm_fwd_advance(co, *a->co_inc);
+    if (mode == T2_BY_VALUE) {
+        for (; co_left > 0; --co_left) {   // co-scheduled steps that did not ride in a context launch
+            T2_TRY(t2_lstm_step_fwd_launch(&co, 1, st));
+            t2_lstm_fwd_advance(co, *a->co_inc);
+        }
     }
     return T2_OK;
+}
+
+extern "C" int64_t t2_attn_seq_fwd_plan(const T2AttnSeq* a, void* host_tab, int64_t bytes) {
+    if (!a) return -1;
+    const int64_t need = fwd_tab_bytes(a->T);
+    if (!host_tab) return need;
+    if (bytes < need) return -1;
+    memset(host_tab, 0, (size_t)need);
+    const FwdTabs tabs = fwd_tabs(host_tab, a->T);
+    return attn_seq_fwd_core(a, nullptr, T2_FILL, &tabs) == T2_OK ? need : -1;
+}
+
+extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
+    T2_REQUIRE(a != nullptr, "t2_attn_seq_fwd: null");
+    if (a->plan) {
+        const FwdTabs tabs = fwd_tabs(a->plan, a->T);
+        return attn_seq_fwd_core(a, (hipStream_t)stream, T2_TABLE, &tabs);
+    }
+    return attn_seq_fwd_core(a, (hipStream_t)stream, T2_BY_VALUE, nullptr);
 }
 
 // =================================================================================================
@@ -475,6 +704,7 @@ struct AttnBwdK {
     const float* th; const float* v; const float* U;
     const float* w_prev; long ldwp; const float* cum_prev; long ldcp;
     float* dpmT; float* dq; long lddq; float* dv_part; float* dU_part; float* din_part_out;
+    unsigned long long* clk;   // diagnostic stamps (T2AttnSeqBwd.clk) or null
 };
 
 namespace {
@@ -483,19 +713,53 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dw_kernel(AttnBwdK p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x, l0 = blockIdx.y * 32, tid = threadIdx.x;
     const int L = p.L, Ef = p.Ef, NA = p.Ad >> 4;
-    float* dctx_s = sm;                    // [Ef]
-    float* dwx_s = dctx_s + Ef;            // [L rounded]
+    constexpr int NEV = 20;                // memory-row items per thread held in registers (covers Ef <= 640)
+    const int DS = imax(Ef, 32 * NEV);
+    float* dctx_s = sm;                    // [max(Ef, 640)] zero past Ef: the product loop below is branch-free
+    float* dwx_s = dctx_s + DS;            // [L rounded]
     float* red = dwx_s + ((L + 3) & ~3);   // [8]
-    // ---- issue: this thread's share of its memory row (8 lanes per position, 16 B each, stride 128 B) ----
-    constexpr int NEV = 20;                // covers Ef <= 640 in registers
+    const bool stamp = b == 0 && blockIdx.y == 0 && tid == 0;
+    T2_STAMP(p, stamp, 16);
     const int l = l0 + (tid >> 3), sub = tid & 7;
+    // ---- issue FIRST the small loads that depend on the previous launches (upstream context gradient, location-path
+    //      partials of frame t+1, weights): loads return in order, so the 80 KB of memory rows must not sit in front ----
+    float dv0[4], cv0[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = imin(tid + 256 * i, Ef - 1);
+        dv0[i] = p.dctx[(long)b * p.lddctx + e];
+        cv0[i] = p.ctx[(long)b * p.ldctx + e];
+    }
+    const int lc0 = imin(tid, L - 1);
+    float a0[8], a1[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) { a0[jj] = 0.f; a1[jj] = 0.f; }
+    if (p.din_part) {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const long o = (((long)b * NA + imin(jj, NA - 1)) * 2) * L + lc0;
+            a0[jj] = p.din_part[o];
+            a1[jj] = p.din_part[o + L];
+        }
+    }
+    const float gin0 = p.G_in ? p.G_in[(long)b * L + lc0] : 0.f;
+    const float wl0 = p.w[(long)b * p.ldw + lc0];
+    const float wme = p.w[(long)b * p.ldw + imin(l, L - 1)];
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- issue: this thread's share of its memory row (8 lanes per position, 16 B each, stride 128 B) ----
     const float* mp = p.memory + ((long)b * L + imin(l, L - 1)) * Ef;
     f32x4 mv[NEV];
 #pragma unroll
     for (int i = 0; i < NEV; ++i) mv[i] = *reinterpret_cast<const f32x4*>(mp + imin(sub * 4 + 32 * i, Ef - 4));
-    // ---- issue: dctx / ctx (<= 4 per thread per pass) ----
+    for (int e = Ef + tid; e < DS; e += 256) dctx_s[e] = 0.f;
+    // ---- dctx -> LDS, dctx . ctx ----
     float part = 0.f;
-    for (int e0 = 0; e0 < Ef; e0 += 1024) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + 256 * i;
+        if (e < Ef) { dctx_s[e] = dv0[i]; part = fmaf(dv0[i], cv0[i], part); }
+    }
+    for (int e0 = 1024; e0 < Ef; e0 += 1024) {
         float dv[4], cv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -515,20 +779,21 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dw_kernel(AttnBwdK p) {
         float g0 = 0.f, g1 = 0.f;
         if (p.din_part) {
             for (int j0 = 0; j0 < NA; j0 += 8) {
-                float a0[8], a1[8];
+                if (ll0 > 0 || j0 > 0) {
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    const long o = (((long)b * NA + imin(j0 + jj, NA - 1)) * 2) * L + lc;
-                    a0[jj] = p.din_part[o];
-                    a1[jj] = p.din_part[o + L];
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const long o = (((long)b * NA + imin(j0 + jj, NA - 1)) * 2) * L + lc;
+                        a0[jj] = p.din_part[o];
+                        a1[jj] = p.din_part[o + L];
+                    }
                 }
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj)
                     if (j0 + jj < NA) { g0 += a0[jj]; g1 += a1[jj]; }
             }
         }
-        const float gin = p.G_in ? p.G_in[(long)b * L + lc] : 0.f;
-        const float wl = p.w[(long)b * p.ldw + lc];
+        const float gin = ll0 == 0 ? gin0 : (p.G_in ? p.G_in[(long)b * L + lc] : 0.f);
+        const float wl = ll0 == 0 ? wl0 : p.w[(long)b * p.ldw + lc];
         if (ll < L) {
             const float Gn = g1 + gin;
             const float dx = g0 + Gn;
@@ -537,13 +802,21 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dw_kernel(AttnBwdK p) {
             part = fmaf(wl, dx, part);
         }
     }
-    const float wme = p.w[(long)b * p.ldw + imin(l, L - 1)];
+    T2_STAMP(p, stamp, 17);
     const float sigma = t2_block_sum(part, red);
+    T2_STAMP(p, stamp, 18);
+    // dw[l] = memory[l] . dctx: all LDS reads of a half are issued before their FMAs (no guard: dctx_s is zero-padded)
     float acc = 0.f;
 #pragma unroll
-    for (int i = 0; i < NEV; ++i) {
-        const int e = sub * 4 + 32 * i;
-        if (e < Ef) acc += mv[i][0] * dctx_s[e] + mv[i][1] * dctx_s[e + 1] + mv[i][2] * dctx_s[e + 2] + mv[i][3] * dctx_s[e + 3];
+    for (int h = 0; h < 2; ++h) {
+        f32x4 dq4[NEV / 2];
+#pragma unroll
+        for (int i = 0; i < NEV / 2; ++i) dq4[i] = *reinterpret_cast<const f32x4*>(dctx_s + sub * 4 + 32 * (h * (NEV / 2) + i));
+#pragma unroll
+        for (int i = 0; i < NEV / 2; ++i) {
+            const f32x4 m = mv[h * (NEV / 2) + i];
+            acc += m[0] * dq4[i][0] + m[1] * dq4[i][1] + m[2] * dq4[i][2] + m[3] * dq4[i][3];
+        }
     }
     if (l < L) {
         for (int e = sub * 4 + 32 * NEV; e < Ef; e += 32) {
@@ -551,14 +824,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dw_kernel(AttnBwdK p) {
             acc += m[0] * dctx_s[e] + m[1] * dctx_s[e + 1] + m[2] * dctx_s[e + 2] + m[3] * dctx_s[e + 3];
         }
     }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    acc += __shfl_xor(acc, 4, 64);
+    acc = t2_oct_sum(acc);
     if (sub == 0 && l < L) p.de[(long)b * L + l] = wme * (acc + dwx_s[l] - sigma);
+    T2_STAMP(p, stamp, 19);
 }
 
 __device__ __forceinline__ void attn_bwd_ds_body(const AttnBwdK& p, const int b, const int j, float* sm) {
     const int tid = threadIdx.x;
+    const bool stamp = b == 0 && j == 0 && tid == 0;
+    T2_STAMP(p, stamp, 24);
     const int al = tid >> 5, sub = tid & 31, a = j * 16 + al;
     const int L = p.L, NG = (L + 3) >> 2, Lp = 4 * NG + 36, L4 = 4 * NG;
     constexpr int DH = 16;         // halo of the ds rows (16, not 15: keeps every 4-position read 16-byte aligned)
@@ -603,6 +877,7 @@ __device__ __forceinline__ void attn_bwd_ds_body(const AttnBwdK& p, const int b,
     }
     for (int l = tid + 1024; l < L4; l += ENT) des[l] = l < L ? p.de[(long)b * L + l] : 0.f;
     __syncthreads();
+    T2_STAMP(p, stamp, 25);
 
     // phase A: ds, dpmT accumulation (32 threads per dim)
     for (int base = 0; base < NG; base += 32 * EMAXI) {
@@ -636,6 +911,7 @@ __device__ __forceinline__ void attn_bwd_ds_body(const AttnBwdK& p, const int b,
         }
     }
     __syncthreads();
+    T2_STAMP(p, stamp, 26);
 
     {   // phase B: dq[a], dv[a]: 32 lanes per attention dim, 16-byte reads
         float sq = 0.f, sv = 0.f;
@@ -645,14 +921,14 @@ __device__ __forceinline__ void attn_bwd_ds_body(const AttnBwdK& p, const int b,
             sq += (d4[0] + d4[1]) + (d4[2] + d4[3]);
             sv += (t4[0] + t4[1]) + (t4[2] + t4[3]);
         }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) { sq += __shfl_xor(sq, o, 64); sv += __shfl_xor(sv, o, 64); }
-        if (sub == 0) {
+        sq = t2_half_sum_hi(sq); sv = t2_half_sum_hi(sv);   // totals of the dim's 32 lanes land in its upper 16 lanes
+        if (sub == 31) {
             p.dq[(long)b * p.lddq + a] = sq;
             p.dv_part[(long)b * p.Ad + a] = dv_old + sv;
         }
     }
 
+    T2_STAMP(p, stamp, 27);
     {   // phase C: dU[a][c][k0..k0+7] += sum_l ds[l] * in[c][l + k - 15]; 8 taps x 4 positions per register tile,
         // a quarter of the position groups per thread, quarters combined by two shuffles
         float out[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -673,8 +949,7 @@ __device__ __forceinline__ void attn_bwd_ds_body(const AttnBwdK& p, const int b,
         }
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
-            out[kk] += __shfl_xor(out[kk], 1, 64);
-            out[kk] += __shfl_xor(out[kk], 2, 64);
+            out[kk] = t2_quad_sum(out[kk]);
         }
         if (c_lq == 0) {
 #pragma unroll
@@ -682,6 +957,7 @@ __device__ __forceinline__ void attn_bwd_ds_body(const AttnBwdK& p, const int b,
                 if (c_k0 + kk < KL) dU_dst[kk] = dU_old[kk] + out[kk];
         }
     }
+    T2_STAMP(p, stamp, 28);
     __syncthreads();   // tvs (and the tail of dsp's region is NOT touched) is reused below
 
     // phase D: d_in partial of THIS dim: dinq[al][c][l'] = sum_k ds[l' + 15 - k] * U[al][c][k]; items (c, lg) per dim
@@ -715,6 +991,7 @@ __device__ __forceinline__ void attn_bwd_ds_body(const AttnBwdK& p, const int b,
         }
     }
     __syncthreads();
+    T2_STAMP(p, stamp, 29);
     for (int idx = tid; idx < 2 * L; idx += ENT) {
         const int c = idx >= L ? 1 : 0, l = idx - c * L;
         float s2 = 0.f;
@@ -722,6 +999,7 @@ __device__ __forceinline__ void attn_bwd_ds_body(const AttnBwdK& p, const int b,
         for (int al2 = 0; al2 < 16; ++al2) s2 += dinq[(al2 * 2 + c) * L4 + l];
         p.din_part_out[(((long)b * (p.Ad >> 4) + j) * 2 + c) * L + l] = s2;
     }
+    T2_STAMP(p, stamp, 30);
 }
 
 __global__ __launch_bounds__(ENT, 2) void attn_bwd_ds_kernel(AttnBwdK p) {
@@ -749,7 +1027,7 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
     const int B = a->B, L = a->L, T = a->T, A = a->A, Ef = a->Ef, Ad = a->Ad, NA = Ad / 16;
     const long ldx = A + Ef;
     const int NG = (L + 3) >> 2, Lp = 4 * NG + 36, L4 = 4 * NG;
-    const size_t sm_dw = (size_t)(Ef + ((L + 3) & ~3) + 8) * sizeof(float);
+    const size_t sm_dw = (size_t)((Ef > 640 ? Ef : 640) + ((L + 3) & ~3) + 8) * sizeof(float);
     const size_t sm_ds = (size_t)(18 * Lp + 16 * 64 + 32 * L4) * sizeof(float);
     T2_REQUIRE(sm_ds <= 64 * 1024, "t2_attn_seq_bwd: LDS budget exceeded");
     T2_REQUIRE(a->wtp_ctx && a->wtp_h, "t2_attn_seq_bwd: packed weight streams (t2_lstm_pack_bwd) are required");
@@ -808,6 +1086,7 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         k.cum_prev = a->cum + (long)t * B * L; k.ldcp = L;
         k.dpmT = a->dpmT; k.dq = Z + (long)(t + 1) * B * ldz + 4 * A; k.lddq = ldz;
         k.dv_part = a->dv_part; k.dU_part = a->dU_part; k.din_part_out = a->din_part;
+        k.clk = (unsigned long long*)a->clk;
         hipLaunchKernelGGL(attn_bwd_dw_kernel, dim3(B, t2_cdiv(L, 32)), dim3(256), sm_dw, st, k);
         if (co_left > 0 && co_ride) {   // ds workgroups + one BPTT step of the co-scheduled recurrence in one launch
             T2_TRY(t2_lstm_check_bwd(co));

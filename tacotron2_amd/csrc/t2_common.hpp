@@ -10,6 +10,18 @@
 #include "../../include/tacotron2_amd.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Kernel-parameter tables live in device memory that no kernel writes: typing the kernel argument as a constant-address-
+// space pointer lets the compiler fetch entries with scalar loads and keeps the pointers loaded from them in the global
+// address space (generic/flat accesses would break the counted vmcnt pipelines).
+#define T2_CONST_AS __attribute__((address_space(4)))
+// copy of one table entry (the compiler turns it into lazy scalar loads of the fields that are used)
+template <typename T>
+__device__ __forceinline__ T t2_tab_entry(const T2_CONST_AS T* p) {
+    T v;
+    __builtin_memcpy(&v, p, sizeof(T));
+    return v;
+}
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define T2_WAVE 64
@@ -51,14 +63,53 @@ static inline bool t2_aligned16(const void* p) { return (((uintptr_t)p) & 15) ==
 __device__ __forceinline__ float t2_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float t2_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
 
+// Wave-wide reductions with DPP moves (quad_perm, row_ror, row_bcast15/31: ~50 cycles) instead of six dependent
+// ds_bpermute shuffles through the LDS crossbar (~600 cycles); every lane receives the result.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float t2_dpp(float ident, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident), __builtin_bit_cast(int, v), CTRL,
+                                                                 ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float t2_wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += t2_dpp<0xB1, 0xf>(0.f, v);     // quad_perm [1,0,3,2]
+    v += t2_dpp<0x4E, 0xf>(0.f, v);     // quad_perm [2,3,0,1]
+    v += t2_dpp<0x124, 0xf>(0.f, v);    // row_ror:4
+    v += t2_dpp<0x128, 0xf>(0.f, v);    // row_ror:8   -> every lane holds the sum of its row of 16
+    v += t2_dpp<0x142, 0xa>(0.f, v);    // row_bcast15 into rows 1 and 3
+    v += t2_dpp<0x143, 0xc>(0.f, v);    // row_bcast31 into rows 2 and 3 -> lane 63 holds the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float t2_wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    const float ni = -__builtin_inff();
+    v = fmaxf(v, t2_dpp<0xB1, 0xf>(ni, v));
+    v = fmaxf(v, t2_dpp<0x4E, 0xf>(ni, v));
+    v = fmaxf(v, t2_dpp<0x124, 0xf>(ni, v));
+    v = fmaxf(v, t2_dpp<0x128, 0xf>(ni, v));
+    v = fmaxf(v, t2_dpp<0x142, 0xa>(ni, v));
+    v = fmaxf(v, t2_dpp<0x143, 0xc>(ni, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// sums over aligned groups of 4 / 8 / 16 lanes (every lane of the group gets the result) and of 32 lanes (the UPPER 16
+// lanes of each half-wave get the result)
+__device__ __forceinline__ float t2_quad_sum(float v) {
+    v += t2_dpp<0xB1, 0xf>(0.f, v);
+    v += t2_dpp<0x4E, 0xf>(0.f, v);
+    return v;
+}
+__device__ __forceinline__ float t2_oct_sum(float v) {
+    v = t2_quad_sum(v);
+    v += t2_dpp<0x141, 0xf>(0.f, v);    // row_half_mirror: the other quad of the aligned group of 8
+    return v;
+}
+__device__ __forceinline__ float t2_row_sum(float v) {
+    v = t2_quad_sum(v);
+    v += t2_dpp<0x124, 0xf>(0.f, v);
+    v += t2_dpp<0x128, 0xf>(0.f, v);
+    return v;
+}
+__device__ __forceinline__ float t2_half_sum_hi(float v) {
+    v = t2_row_sum(v);
+    v += t2_dpp<0x142, 0xa>(0.f, v);    // lanes 16..31 / 48..63 now hold the sum of their 32 lanes
     return v;
 }
 __device__ __forceinline__ double t2_wave_sum_d(double v) {

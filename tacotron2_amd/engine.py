@@ -66,6 +66,8 @@ class Engine:
         self.dev = ps.device
         self._ws: Dict[str, torch.Tensor] = {}
         self._side = None
+        self._plans: Dict[str, dict] = {}
+        self.use_plans = True         # kernel-parameter tables for the frame loops (16-byte kernel arguments)
         self.chunk = 64               # frames per pipeline chunk (two-stream overlap of the two recurrences)
         self.chunk_bwd = 80           # frames per chunk of the backward pipeline (80*32 rows = 240 tiles of the dxdec GEMM)
         self.co_schedule = True       # forward: decoder-LSTM steps ride in the attention-context launches (T2AttnSeq.co_step)
@@ -76,8 +78,33 @@ class Engine:
         self.chunk_bwd = int(_os.environ.get("T2_CHUNK_BWD", self.chunk_bwd))
         self.co_schedule = _os.environ.get("T2_CO_SCHEDULE", "1") != "0"
         self.co_schedule_bwd = _os.environ.get("T2_CO_SCHEDULE_BWD", "0") != "0"
+        self.use_plans = _os.environ.get("T2_USE_PLANS", "1") != "0"
         self.profile = False          # when True, mark() records HIP events at segment boundaries
         self.marks = []               # [(name, event)] of the current step
+
+    # ---- kernel-parameter tables ("plans", include/tacotron2_amd.h T2AttnSeq.plan) ---------------------------------
+    def plan_upload(self, name: str, plan_fn, *args):
+        """Build a table with the C plan function into pinned host memory (ring of 3 slots, so the host may run ahead of
+        the device) and copy it to its device buffer on the current stream.  Returns the device pointer."""
+        from ._lib import call_value
+        nbytes = int(call_value(plan_fn, *args, None, 0))
+        if nbytes < 0:
+            raise _lib.T2Error(f"{plan_fn} failed: {_lib.lib().t2_last_error().decode()}")
+        slot = self._plans.setdefault(name, dict(dev=None, host=[None] * 3, ev=[None] * 3, i=0))
+        i = slot["i"]; slot["i"] = (i + 1) % 3
+        if slot["host"][i] is None or slot["host"][i].numel() < nbytes:
+            slot["host"][i] = torch.empty(max(nbytes, 1), dtype=torch.uint8, pin_memory=True)
+        if slot["ev"][i] is not None:
+            slot["ev"][i].synchronize()                 # the copy that last read this pinned slot has run
+        host = slot["host"][i]
+        if int(call_value(plan_fn, *args, host.data_ptr(), nbytes)) != nbytes:
+            raise _lib.T2Error(f"{plan_fn} failed: {_lib.lib().t2_last_error().decode()}")
+        if slot["dev"] is None or slot["dev"].numel() < nbytes:
+            slot["dev"] = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.dev)
+        slot["dev"][:nbytes].copy_(host[:nbytes], non_blocking=True)
+        ev = torch.cuda.Event(); ev.record()
+        slot["ev"][i] = ev
+        return slot["dev"].data_ptr()
 
     def side_stream(self):
         if self._side is None:
@@ -365,14 +392,30 @@ class Engine:
         import ctypes as _C
         chunks = [(c0, min(T, c0 + CH)) for c0 in range(0, T, CH)]
         co = B <= 32 and self.co_schedule     # co-scheduling needs <= 32 batch rows; otherwise plain two-stream pipeline
+        plans = self.use_plans and B <= 64
+        drain_from = T
+        if plans:
+            # one table for the whole chain: per-frame operand blocks of the attention cell, the attention kernels and the
+            # co-scheduled decoder cell (decoder frame j rides attention frame j + CH)
+            if co and T > CH:
+                stp_all, inc_all = dec_chunk(0, T)
+                seq.co_step, seq.co_inc = _C.pointer(stp_all), _C.pointer(inc_all)
+                seq.co_steps, seq.co_first = T - CH, CH
+                drain_from = T - CH
+            else:
+                seq.co_step, seq.co_inc, seq.co_steps, seq.co_first = None, None, 0, 0
+                drain_from = 0
+            seq.t_begin, seq.t_end = 0, 0
+            seq.plan = self.plan_upload("fwd.attn", "t2_attn_seq_fwd_plan", seq)
         for i, (c0, c1) in enumerate(chunks):
             seq.t_begin, seq.t_end = c0, c1
-            if co and i >= 1:
-                stp, inc = dec_chunk(*chunks[i - 1])
-                seq.co_step, seq.co_inc = _C.pointer(stp), _C.pointer(inc)
-                seq.co_steps = chunks[i - 1][1] - chunks[i - 1][0]
-            else:
-                seq.co_step, seq.co_inc, seq.co_steps = None, None, 0
+            if not plans:
+                if co and i >= 1:
+                    stp, inc = dec_chunk(*chunks[i - 1])
+                    seq.co_step, seq.co_inc = _C.pointer(stp), _C.pointer(inc)
+                    seq.co_steps = chunks[i - 1][1] - chunks[i - 1][0]
+                else:
+                    seq.co_step, seq.co_inc, seq.co_steps = None, None, 0
             call("t2_attn_seq_fwd", seq, st)
             if co:
                 pre_dec_gemm(c0, c1)
@@ -385,9 +428,10 @@ class Engine:
                     call("t2_lstm_seq_fwd", stp, inc, 1, c1 - c0, side.cuda_stream)
         self.mark("fwd.dec.attn_chain")
         main.wait_stream(side)
-        if co:                                  # drain: the last decoder-LSTM chunk
-            stp, inc = dec_chunk(*chunks[-1])
-            call("t2_lstm_seq_fwd", stp, inc, 1, chunks[-1][1] - chunks[-1][0], st)
+        if co:                                  # drain: the decoder-LSTM frames that found no attention frame to ride in
+            d0 = drain_from if plans else chunks[-1][0]
+            stp, inc = dec_chunk(d0, T)
+            call("t2_lstm_seq_fwd", stp, inc, 1, T - d0, st)
         self.mark("fwd.dec.lstm_chain_tail")
 
         # mel + stop projection over all frames: [mel_out.weight ; gate.weight] is one (M+1, D+Ef) matrix
@@ -533,7 +577,7 @@ class Engine:
                   cum=ctx["cum"], th=ctx["th"], att_drop=masks.get("att_drop"),
                   dh_ext=dxdec, ld_dh=ldx, dctx_ext1=_ptr(dxdec, A), ld_dc1=ldx, dctx_ext2=_ptr(dxproj, D), ld_dc2=ldp,
                   dgates=Z, dctx_tot=dctx_tot, dq=None, dpmT=dpmT, dv_part=dv_part, dU_part=dU_part,
-                  dc=dc_att, G=Gc, de=de, din_part=din_part, dgates_t=Zt)
+                  dc=dc_att, G=Gc, de=de, din_part=din_part, dgates_t=Zt, clk=getattr(self, "clk_bwd", None))
         self.mark("bwd.dec.proj")
         main, side = torch.cuda.current_stream(), self.side_stream()
         side.wait_stream(main)

@@ -1,0 +1,27 @@
+"""Phase stamps of the backward attention kernels inside a real training step (diagnostic, GPU box only)."""
+import sys, os, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from tacotron2_amd.params import ParamStore
+from tacotron2_amd.trainer import Trainer
+from tacotron2_amd.synthetic import ljspeech_batch
+
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+from tacotron2_amd.init import init_parameters
+ps = ParamStore(bench.VANILLA, dev)
+init_parameters(ps, seed=0)
+tr = Trainer(ps, lr=1e-3, weight_decay=1e-6, scheduler_milestones=(50000, 75000))
+batch = {k: v.to(dev) for k, v in ljspeech_batch(32, seed=1234, num_speakers=4).items()}
+clk = torch.zeros(32, dtype=torch.int64, device=dev)
+for i in range(3):
+    if i == 2:
+        tr.engine.clk_bwd = clk
+    tr.train_step(batch)
+torch.cuda.synchronize()
+c = clk.cpu().tolist()
+GHZ = 2.38
+f = lambda a, b0: (c[a] - c[b0]) / GHZ / 1e3
+print("dw kernel, workgroup (0,0), us from entry: small loads consumed %.2f | sigma %.2f | exit %.2f" % (f(17, 16), f(18, 16), f(19, 16)))
+print("ds kernel, workgroup (0,0), us from entry: staged %.2f | phase A (ds, dpmT) %.2f | phase B (dq, dv) %.2f | phase C (dU) %.2f | "
+      "phase D (d_in) %.2f | exit %.2f" % (f(25, 24), f(26, 24), f(27, 24), f(28, 24), f(29, 24), f(30, 24)))

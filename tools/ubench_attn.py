@@ -40,11 +40,14 @@ xproj = torch.zeros(T + 1, B, 1024 + Ef, device=dev)
 e_part = torch.empty(B, Ad // 16, L, device=dev)
 
 
-def run(use_th, use_gates):
+clk = torch.zeros(32, dtype=torch.int64, device=dev)
+
+
+def run(use_th, use_gates, stamps=False):
     seq = make("T2AttnSeq", B=B, L=L, T=T, A=A, Ad=Ad, Ef=Ef, Kl=KL, wpacked=wp, W_ih_ctx=W, ld_wih=A + Ef, W_hh=W, Wq=Wq, U=U, v=v,
                pre=pre, pmT=pmT, memory=memory, len=lens, xdec=xdec, att_c=att_c, gates=gates if use_gates else None,
                align=align, cum=cum, th=th if use_th else None, xproj_ctx=xproj[1:, :, 1024:].data_ptr(), ld_xproj=1024 + Ef,
-               e_part=e_part, xdec_t=xdec_t)
+               e_part=e_part, xdec_t=xdec_t, clk=clk if stamps else None)
     call("t2_attn_seq_fwd", seq, st); torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record(); call("t2_attn_seq_fwd", seq, st); e1.record(); torch.cuda.synchronize()
@@ -53,3 +56,13 @@ def run(use_th, use_gates):
 
 for use_th, use_gates in [(True, True), (False, True), (True, False), (False, False)]:
     print(f"th stash {use_th}, gates stash {use_gates}: {run(use_th, use_gates):.2f} us per frame (cell + energies + context)", flush=True)
+
+run(True, True, stamps=True)
+c = clk.cpu().tolist()
+GHZ = 2.38   # shader clock during the loop (s_memtime ticks / s_memrealtime), DESIGN.md section 4.1
+e = [(c[i] - c[0]) / GHZ / 1e3 for i in range(6)]
+k = [(c[i] - c[8]) / GHZ / 1e3 for i in range(8, 14)]
+print("energies  kernel, workgroup (0,0), us from entry: staging done %.2f | conv done %.2f | query ready %.2f | tanh done %.2f | exit %.2f"
+      % (e[1], e[4], e[5], e[2], e[3]))
+print("context   kernel, workgroup (0,0), us from entry: e_part summed %.2f | softmax sums %.2f | weights written %.2f | "
+      "context partial %.2f | exit %.2f" % (k[1], k[2], k[3], k[4], k[5]))
