@@ -67,7 +67,9 @@ class Engine:
         self._ws: Dict[str, torch.Tensor] = {}
         self._side = None
         self._plans: Dict[str, dict] = {}
-        self.use_plans = True         # kernel-parameter tables for the frame loops (16-byte kernel arguments)
+        self.use_plans = False        # kernel-parameter tables for the forward frame loop (16-byte kernel arguments): cuts the
+                                      # HOST cost per launch (2.8 vs 3.7 us enqueue rate); GPU-side a dependent launch costs
+                                      # 1.7 us whatever the argument size (tools/ubench_gpu_launch.hip), so off by default
         self.chunk = 64               # frames per pipeline chunk (two-stream overlap of the two recurrences)
         self.chunk_bwd = 80           # frames per chunk of the backward pipeline (80*32 rows = 240 tiles of the dxdec GEMM)
         self.co_schedule = True       # forward: decoder-LSTM steps ride in the attention-context launches (T2AttnSeq.co_step)
@@ -78,7 +80,7 @@ class Engine:
         self.chunk_bwd = int(_os.environ.get("T2_CHUNK_BWD", self.chunk_bwd))
         self.co_schedule = _os.environ.get("T2_CO_SCHEDULE", "1") != "0"
         self.co_schedule_bwd = _os.environ.get("T2_CO_SCHEDULE_BWD", "0") != "0"
-        self.use_plans = _os.environ.get("T2_USE_PLANS", "1") != "0"
+        self.use_plans = _os.environ.get("T2_USE_PLANS", "0") != "0"
         self.profile = False          # when True, mark() records HIP events at segment boundaries
         self.marks = []               # [(name, event)] of the current step
 
