@@ -530,6 +530,8 @@ int launch_attn(const T2AttnStep& s, hipStream_t st, const T2LstmStep* co = null
         smx = sm_c > sm_co ? sm_c : sm_co;
     }
     const int nC = s.B * (s.Ef / 32);
+    T2_REQUIRE(t2_allow_lds(attn_energy_kernel, sm_e) && t2_allow_lds(attn_energy_tab_kernel, sm_e),
+               "attention: LDS budget exceeded (energies kernel)");
     if (mode == T2_FILL) {
         tabs->attn[idx] = k;
         if (co) tabs->co[idx] = ck;
@@ -1022,14 +1024,15 @@ __global__ __launch_bounds__(ENT, 4) void attn_bwd_ds_co_kernel(AttnBwdK p, BwdK
 extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
     T2_REQUIRE(a != nullptr, "t2_attn_seq_bwd: null");
     T2_REQUIRE(a->Kl == KL && a->Ad % 16 == 0 && a->Ef % 32 == 0, "t2_attn_seq_bwd: unsupported dims");
-    T2_REQUIRE(a->L >= 1 && a->L <= 256, "t2_attn_seq_bwd: need 1 <= L <= 256 (LDS budget of the backward attention kernel)");
+    T2_REQUIRE(a->L >= 1 && a->L <= 768, "t2_attn_seq_bwd: need 1 <= L <= 768 (LDS budget of the attention kernels)");
     hipStream_t st = (hipStream_t)stream;
     const int B = a->B, L = a->L, T = a->T, A = a->A, Ef = a->Ef, Ad = a->Ad, NA = Ad / 16;
     const long ldx = A + Ef;
     const int NG = (L + 3) >> 2, Lp = 4 * NG + 36, L4 = 4 * NG;
     const size_t sm_dw = (size_t)((Ef > 640 ? Ef : 640) + ((L + 3) & ~3) + 8) * sizeof(float);
     const size_t sm_ds = (size_t)(18 * Lp + 16 * 64 + 32 * L4) * sizeof(float);
-    T2_REQUIRE(sm_ds <= 64 * 1024, "t2_attn_seq_bwd: LDS budget exceeded");
+    T2_REQUIRE(t2_allow_lds(attn_bwd_ds_kernel, sm_ds) && t2_allow_lds(attn_bwd_ds_co_kernel, sm_ds),
+               "t2_attn_seq_bwd: LDS budget exceeded");
     T2_REQUIRE(a->wtp_ctx && a->wtp_h, "t2_attn_seq_bwd: packed weight streams (t2_lstm_pack_bwd) are required");
     // Z[s][b] = [ dgates_s (4A) | dq_{s-1} (Ad) ], s = 0..T; slot T's dgates part is zero-filled by the caller, so the
     // backward step of frame t always reads ONE contiguous row Z[t+1] (no special case for the last frame).

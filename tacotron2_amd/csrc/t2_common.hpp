@@ -2,6 +2,8 @@
 // fp32-input MFMA (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32), no other targets.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
+#include <unordered_map>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -138,6 +140,23 @@ __device__ __forceinline__ float t2_block_max(float v, float* red) {
     float s = red[0];
     for (int i = 1; i < nw; ++i) s = fmaxf(s, red[i]);
     return s;
+}
+
+// Dynamic LDS above 64 KB (gfx950 has 160 KB per CU) must be enabled per kernel; the call is remembered per function.
+template <typename K>
+inline bool t2_allow_lds(K kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return true;
+    if (bytes > 160 * 1024) return false;
+    static std::unordered_map<const void*, size_t> granted;     // per kernel function
+    static std::mutex mu;
+    const void* f = reinterpret_cast<const void*>(kernel);
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& g = granted[f];
+    if (bytes > g) {
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+        g = bytes;
+    }
+    return true;
 }
 
 // Philox4x32-10 counter RNG (Salmon et al. 2011); one call -> 4 x 32 random bits.

@@ -373,6 +373,33 @@ def test_edge_shapes_match_oracle(B, L, T, lens, tls):
     assert torch.isfinite(ps.grad).all() and torch.isfinite(loss3).all()
 
 
+@pytest.mark.parametrize("L", [300, 700])
+def test_long_text_forward_backward_match_oracle(L):
+    """Texts longer than one 256-position round of the attention kernels (and, at 700, dynamic LDS above 64 KB): outputs
+    and every parameter gradient against the CPU oracle."""
+    dev = _dev()
+    d = R.default_dims(num_chars=39, encoded_dim=64, prenet_dim=32, att_rnn_dim=64, att_dim=32, rnn_hidden_dim=64,
+                       postnet_dim=64, num_mels=16, dropout=0.5)
+    P = R.init_params(d, seed=L)
+    eng, ps = build_engine(d, P, dev)
+    ci, lens, mel, tl, gate, masks = random_case(d, 2, L, 4, 900 + L, dev)
+    lens = torch.tensor([L, L - 37])
+    ci[1, L - 37:] = 0
+    Pc = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not R.is_buffer(k)) else v.clone()) for k, v in P.items()}
+    o = R.tacotron2_fwd(Pc, d, ci, lens, True, mel, tl, training=True, masks=masks, new_stats={})
+    loss = R.tts_loss(o[0], o[1], o[2], mel, gate)[0]
+    names = [k for k, v in Pc.items() if v.requires_grad]
+    grads = torch.autograd.grad(loss, [Pc[k] for k in names])
+    outs, ctx = eng.forward_tf(ci.to(dev), lens.to(dev), mel.to(dev), tl.to(dev), training=True, masks=masks_to_device(masks, dev))
+    ps.grad.zero_()
+    loss3 = eng.loss_and_grads(outs, ctx, mel.to(dev), gate.to(dev))
+    torch.cuda.synchronize()
+    assert l1(outs[0], o[0].detach()) < MEL_L1_TOL and l1(outs[1], o[1].detach()) < MEL_L1_TOL
+    assert mx(outs[3], o[3].detach()) < 2e-5
+    assert abs(float(loss3.sum()) - float(loss)) < 2e-5 * max(1.0, abs(float(loss)))
+    _grad_check(ps, {k: g for k, g in zip(names, grads)})
+
+
 def test_unsupported_shapes_fail_loudly():
     from tacotron2_amd._lib import T2Error
     dev = _dev()
