@@ -76,12 +76,9 @@ __device__ __forceinline__ void stage_issue(StageRegs<NTH>& r, const float* w_pr
     }
 }
 
-// inpO (optional): the same two rows shifted by one float (inpO[c][x] = inp[c][x + 1]), so that the odd-aligned pairs of a
-// sliding window can be fetched with aligned 16-byte LDS reads too (the convolutions run on v_pk_fma_f32 pairs).
 template <int NTH>
 __device__ __forceinline__ void stage_commit(const StageRegs<NTH>& r, float* inp, float* Us, const float* w_prev, long ldw,
-                                             const float* cum_prev, long ldcum, const float* dummy, int b, int L, int Lp, int tid,
-                                             float* inpO = nullptr) {
+                                             const float* cum_prev, long ldcum, const float* dummy, int b, int L, int Lp, int tid) {
     constexpr int PER = 1024 / NTH;
     const float* wsrc = w_prev ? w_prev + (long)b * ldw : dummy;
     const float* csrc = cum_prev ? cum_prev + (long)b * ldcum : dummy;
@@ -91,14 +88,7 @@ __device__ __forceinline__ void stage_commit(const StageRegs<NTH>& r, float* inp
         const int idx = tid + NTH * i;
         const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
         const bool ok = l >= 0 && l < L && !(c ? cz : wz);
-        if (idx < 2 * Lp) {
-            const float v = ok ? r.iv[i] : 0.f;
-            inp[idx] = v;
-            if (inpO) {
-                if (idx != c * Lp) inpO[idx - 1] = v;
-                if (idx == c * Lp + Lp - 1) inpO[idx] = 0.f;
-            }
-        }
+        if (idx < 2 * Lp) inp[idx] = ok ? r.iv[i] : 0.f;
     }
     for (int base = 1024; base < 2 * Lp; base += 1024) {   // long texts (2*Lp > 1024): further rounds, load then store
         float iv[PER];
@@ -114,14 +104,7 @@ __device__ __forceinline__ void stage_commit(const StageRegs<NTH>& r, float* inp
             const int idx = base + tid + NTH * i;
             const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
             const bool ok = l >= 0 && l < L && !(c ? cz : wz);
-            if (idx < 2 * Lp) {
-                const float v = ok ? iv[i] : 0.f;
-                inp[idx] = v;
-                if (inpO) {
-                    if (idx != c * Lp) inpO[idx - 1] = v;
-                    if (idx == c * Lp + Lp - 1) inpO[idx] = 0.f;
-                }
-            }
+            if (idx < 2 * Lp) inp[idx] = ok ? iv[i] : 0.f;
         }
     }
 #pragma unroll
@@ -166,8 +149,7 @@ __device__ __forceinline__ void attn_energy_body(const AttnK& p, const int b, co
     const int al = tid >> 5, sub = tid & 31, a = j * 16 + al;
     const int L = p.L, NG = (L + 3) >> 2, Lp = 4 * NG + 36;
     float* inp = sm;             // [2][Lp]   zero-haloed (w_prev, cum_prev), index l + 15
-    float* inpO = inp + 2 * Lp;  // [2][Lp]   the same rows shifted by one float (odd-aligned window pairs)
-    float* Us = inpO + 2 * Lp;   // [16][2][32] folded location filter rows of this slice
+    float* Us = inp + 2 * Lp;    // [16][2][32] folded location filter rows of this slice
     float* qs = Us + 16 * 64;    // [16]
     float* ec = qs + 16;         // [16][4*NG] per-dim energy contributions
     const long rowoff = ((long)b * p.Ad + a) * L;
@@ -197,7 +179,7 @@ __device__ __forceinline__ void attn_energy_body(const AttnK& p, const int b, co
 #pragma unroll
         for (int aa = 0; aa < 2; ++aa) wv[aa][i] = *reinterpret_cast<const f32x4*>(wq0 + (long)aa * p.A + k);
     }
-    stage_commit<ENT>(sr, inp, Us, p.w_prev, p.ldw, p.cum_prev, p.ldcum, p.pmT, b, L, Lp, tid, inpO);
+    stage_commit<ENT>(sr, inp, Us, p.w_prev, p.ldw, p.cum_prev, p.ldcum, p.pmT, b, L, Lp, tid);
     __syncthreads();   // staging visible
     T2_STAMP(p, stamp, 1);
 
@@ -212,9 +194,9 @@ __device__ __forceinline__ void attn_energy_body(const AttnK& p, const int b, co
             }
         }
         // 8 adjacent positions x 31 taps x 2 channels on packed FMAs.  Position pairs (0,1) (2,3) (4,5) (6,7) are the halves
-        // of four v_pk_fma_f32 accumulators; the window pairs (win[k], win[k+1]) are register pairs of the aligned LDS read
-        // for even k and of the shifted copy for odd k (no repacking moves), the tap is broadcast through op_sel.  The two
-        // groups share one 40-float window: 20 x 16-byte LDS reads per channel instead of 36 (the loop is LDS-read bound).
+        // of four v_pk_fma_f32 accumulators; the window pairs (win[k], win[k+1]) are the register pairs of the aligned LDS
+        // read for even k and pairs built with one v_pk_mov_b32 each for odd k, the tap is broadcast through op_sel.  The
+        // two groups share one 40-float window: 10 x 16-byte LDS reads per channel instead of 18.
         float acc[EMAXI][4];
         {
             const int lg0 = imin(base + 2 * sub, NG - 1);
@@ -230,24 +212,30 @@ __device__ __forceinline__ void attn_energy_body(const AttnK& p, const int b, co
                         ukc[4 * i] = t[0]; ukc[4 * i + 1] = t[1]; ukc[4 * i + 2] = t[2]; ukc[4 * i + 3] = t[3];
                     }
                 }
-                // even taps against the aligned window pairs, then odd taps against the shifted copy (one window live at a time)
-#pragma nounroll
-                for (int par = 0; par < 2; ++par) {
-                    f32x2 wp2[20];
-                    const f32x4* wp = reinterpret_cast<const f32x4*>((par ? inpO : inp) + c * Lp + 4 * lg0);
+                // aligned window pairs from one 40-float LDS read; the odd-aligned pairs are built in registers
+                // (one v_pk_mov_b32 each), so even and odd taps both run on v_pk_fma_f32 without repacking
+                f32x2 we[20], wo[19];
+                const f32x4* wp = reinterpret_cast<const f32x4*>(inp + c * Lp + 4 * lg0);
 #pragma unroll
-                    for (int i = 0; i < 10; ++i) {
-                        const f32x4 t = wp[i];
-                        wp2[2 * i] = (f32x2){t[0], t[1]}; wp2[2 * i + 1] = (f32x2){t[2], t[3]};
-                    }
+                for (int i = 0; i < 10; ++i) {
+                    const f32x4 t = wp[i];
+                    we[2 * i] = (f32x2){t[0], t[1]}; we[2 * i + 1] = (f32x2){t[2], t[3]};
+                }
 #pragma unroll
-                    for (int kk = 0; kk < 16; ++kk) {       // taps par, par + 2, ...: compile-time register indices
-                        const float uv = par ? ukc[(2 * kk + 1) & 31] : ukc[2 * kk];   // tap 31 is the zero pad
-                        const f32x2 u = {uv, uv};
-                        a01 = __builtin_elementwise_fma(u, wp2[kk], a01);
-                        a23 = __builtin_elementwise_fma(u, wp2[kk + 1], a23);
-                        a45 = __builtin_elementwise_fma(u, wp2[kk + 2], a45);
-                        a67 = __builtin_elementwise_fma(u, wp2[kk + 3], a67);
+                for (int m = 0; m < 19; ++m) wo[m] = (f32x2){we[m][1], we[m + 1][0]};
+#pragma unroll
+                for (int k = 0; k < KL; ++k) {
+                    const f32x2 u = {ukc[k], ukc[k]};
+                    if ((k & 1) == 0) {
+                        a01 = __builtin_elementwise_fma(u, we[k / 2], a01);
+                        a23 = __builtin_elementwise_fma(u, we[k / 2 + 1], a23);
+                        a45 = __builtin_elementwise_fma(u, we[k / 2 + 2], a45);
+                        a67 = __builtin_elementwise_fma(u, we[k / 2 + 3], a67);
+                    } else {
+                        a01 = __builtin_elementwise_fma(u, wo[k / 2], a01);
+                        a23 = __builtin_elementwise_fma(u, wo[k / 2 + 1], a23);
+                        a45 = __builtin_elementwise_fma(u, wo[k / 2 + 2], a45);
+                        a67 = __builtin_elementwise_fma(u, wo[k / 2 + 3], a67);
                     }
                 }
             }
@@ -516,7 +504,7 @@ int launch_attn(const T2AttnStep& s, hipStream_t st, const T2LstmStep* co = null
     AttnK k;
     to_ak(s, k);
     const int NG = (s.L + 3) >> 2, Lp = 4 * NG + 36;
-    const size_t sm_e = (size_t)(4 * Lp + 16 * 64 + 16 + 16 * 4 * NG) * sizeof(float);
+    const size_t sm_e = (size_t)(2 * Lp + 16 * 64 + 16 + 16 * 4 * NG) * sizeof(float);
     const int wsn = ((s.L + 3) & ~3) > 192 ? ((s.L + 3) & ~3) : 192;
     const size_t sm_c = (size_t)(wsn + 8 + 256) * sizeof(float);
     LstmK ck;
