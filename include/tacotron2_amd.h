@@ -210,6 +210,8 @@ typedef struct {
      * stream) next to the latency-bound context kernel uses otherwise idle pipes.  Needs the packed single-segment path and
      * co_step->B <= 32 (else, and for steps beyond the frame range, the steps run as plain launches). */
     const T2LstmStep* co_step; const T2LstmStride* co_inc; int co_steps;
+    int co_host;                     /* where the co-scheduled step rides: 0 = context launch, 1 = energies launch, 2 = its
+                                        workgroups split between the two (by-value launches only) */
     /* Optional kernel-parameter tables ("plan").  Every launch of the chain otherwise carries a 230-600 byte by-value
      * operand block; a dependent launch costs 2.8 us with a 16-byte block and 3.4-3.7 us with 260-520 bytes
      * (tools/ubench_kernarg.hip), so the blocks of all T frames are written ONCE into a table:

@@ -419,11 +419,11 @@ __global__ __launch_bounds__(256, 1) void attn_context_kernel(AttnK p) {
 // [nC, nC + H/4) run one step of a co-scheduled LSTM cell (t2_lstm_step.hpp).  3 waves per SIMD (<= 168 VGPRs) so that two
 // context workgroups and one cell workgroup fit on a CU.
 template <int MT>
-__global__ __launch_bounds__(256, 3) void attn_context_co_kernel(AttnK p, LstmK c, int nC) {
+__global__ __launch_bounds__(256, 3) void attn_context_co_kernel(AttnK p, LstmK c, int nC, int bx0) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int bid = blockIdx.x;
     if (bid < nC) attn_context_body(p, bid % p.B, (bid / p.B) * 32, sm);
-    else t2_lstm_fwd_fast_body<MT, 4>(c, bid - nC, sm);
+    else t2_lstm_fwd_fast_body<MT, 4>(c, bx0 + bid - nC, sm);
 }
 
 // U[a][c][k] = sum_f Wd[a][f] * Wc[f][c][k]
@@ -455,6 +455,19 @@ void to_ak(const T2AttnStep& s, AttnK& k) {
     k.ctx_out = s.ctx_out; k.ldctx = s.ldctx; k.ctx_out2 = s.ctx_out2; k.ldctx2 = s.ldctx2;
     k.ctxt_out = s.ctxt_out; k.ctxt_col0 = s.ctxt_col0; k.ctxt_cs = (long)((s.B + 15) / 16 * 16) * 16;
     k.clk = (unsigned long long*)s.clk;
+}
+
+// The same co-scheduling with the ENERGIES launch as the host (T2AttnSeq.co_host = 1): 512-thread workgroups; the cell
+// body uses 256 threads, the upper four waves of a cell workgroup end at once (finished waves do not count at s_barrier
+// and release their registers), so an energies workgroup (2 waves per SIMD) and a cell workgroup (1 wave per SIMD) share a
+// CU at <= 168 VGPRs.
+template <int MT>
+__global__ __launch_bounds__(ENT, 3) void attn_energy_co_kernel(AttnK p, LstmK c, int nE, int bx0) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int bid = blockIdx.x;
+    if (bid < nE) { attn_energy_body(p, bid % p.B, bid / p.B, sm); return; }
+    if (threadIdx.x >= 256) return;
+    t2_lstm_fwd_fast_body<MT, 4>(c, bx0 + bid - nE, sm);
 }
 
 // Table variants: the operand block comes from a device-resident table entry (16-byte kernel-argument block; see
@@ -500,7 +513,7 @@ enum { T2_BY_VALUE = 0, T2_FILL = 1, T2_TABLE = 2 };
 bool co_eligible(const T2LstmStep& c) { return c.wpacked && c.nseg == 1 && c.B <= 32 && c.H % 4 == 0; }
 
 int launch_attn(const T2AttnStep& s, hipStream_t st, const T2LstmStep* co = nullptr, int mode = T2_BY_VALUE,
-                const FwdTabs* tabs = nullptr, int idx = 0) {
+                const FwdTabs* tabs = nullptr, int idx = 0, int co_host = 0) {
     AttnK k;
     to_ak(s, k);
     const int NG = (s.L + 3) >> 2, Lp = 4 * NG + 36;
@@ -538,10 +551,22 @@ int launch_attn(const T2AttnStep& s, hipStream_t st, const T2LstmStep* co = null
         T2_CHECK_LAUNCH();
         return T2_OK;
     }
-    hipLaunchKernelGGL(attn_energy_kernel, dim3(s.B, s.Ad / 16), dim3(ENT), sm_e, st, k);
-    if (co) {
-        if (MT == 1) hipLaunchKernelGGL(attn_context_co_kernel<1>, dim3(nC + co->H / 4), dim3(256), smx, st, k, ck, nC);
-        else hipLaunchKernelGGL(attn_context_co_kernel<2>, dim3(nC + co->H / 4), dim3(256), smx, st, k, ck, nC);
+    // co_host 0: the whole cell step rides in the context launch; 1: in the energies launch; 2: its workgroups are split
+    // between the two (first half in the energies launch)
+    const int ncell = co ? co->H / 4 : 0;
+    const int ne_cell = !co ? 0 : (co_host == 1 ? ncell : (co_host == 2 ? ncell / 2 : 0)), nc_cell = ncell - ne_cell;
+    if (ne_cell > 0) {
+        const int nE = s.B * (s.Ad / 16);
+        const size_t sm_co = (size_t)4 * MT * 256 * sizeof(float), sme = sm_e > sm_co ? sm_e : sm_co;
+        T2_REQUIRE(t2_allow_lds(attn_energy_co_kernel<1>, sme) && t2_allow_lds(attn_energy_co_kernel<2>, sme), "attention: LDS budget exceeded");
+        if (MT == 1) hipLaunchKernelGGL(attn_energy_co_kernel<1>, dim3(nE + ne_cell), dim3(ENT), sme, st, k, ck, nE, 0);
+        else hipLaunchKernelGGL(attn_energy_co_kernel<2>, dim3(nE + ne_cell), dim3(ENT), sme, st, k, ck, nE, 0);
+    } else {
+        hipLaunchKernelGGL(attn_energy_kernel, dim3(s.B, s.Ad / 16), dim3(ENT), sm_e, st, k);
+    }
+    if (nc_cell > 0) {
+        if (MT == 1) hipLaunchKernelGGL(attn_context_co_kernel<1>, dim3(nC + nc_cell), dim3(256), smx, st, k, ck, nC, ne_cell);
+        else hipLaunchKernelGGL(attn_context_co_kernel<2>, dim3(nC + nc_cell), dim3(256), smx, st, k, ck, nC, ne_cell);
     } else {
         hipLaunchKernelGGL(attn_context_kernel, dim3(s.B, s.Ef / 32), dim3(256), sm_c, st, k);
     }
@@ -635,7 +660,7 @@ static int attn_seq_fwd_core(const T2AttnSeq* a, hipStream_t st, int mode, const
         q.clk = a->clk;
         if (t == tb) T2_TRY(check_attn(q));
         if (co_left > 0 && co_ride && t >= co_at) {
-            T2_TRY(launch_attn(q, st, &co, mode, tabs, t));
+            T2_TRY(launch_attn(q, st, &co, mode, tabs, t, a->co_host));
             t2_lstm_fwd_advance(co, *a->co_inc); --co_left;
         } else {
             T2_TRY(launch_attn(q, st, nullptr, mode, tabs, t));

@@ -81,6 +81,8 @@ class Engine:
         self.co_schedule = _os.environ.get("T2_CO_SCHEDULE", "1") != "0"
         self.co_schedule_bwd = _os.environ.get("T2_CO_SCHEDULE_BWD", "0") != "0"
         self.use_plans = _os.environ.get("T2_USE_PLANS", "0") != "0"
+        self.co_host = int(_os.environ.get("T2_CO_HOST", "1"))   # where the co-scheduled decoder cell rides: 1 = energies launch (measured best:
+                                                                 # 26.85 ms vs 27.2 ms in the context launch, 29.2 ms split over both)
         self.profile = False          # when True, mark() records HIP events at segment boundaries
         self.marks = []               # [(name, event)] of the current step
 
@@ -353,7 +355,8 @@ class Engine:
                    W_hh=P["decoder.att_rnn.weight_hh"], Wq=P["decoder.attention.query_layer.weight"], U=U,
                    v=P["decoder.attention.v.weight"], pre=pre_att, pmT=pmT, memory=memory, len=len32,
                    att_drop=masks.get("att_drop"), xdec=xdec, att_c=att_c, gates=gates_att, align=align, cum=cum, th=th,
-                   xproj_ctx=_ptr(xproj, B * (D + Ef) + D), ld_xproj=D + Ef, e_part=e_part, xdec_t=xdec_t)
+                   xproj_ctx=_ptr(xproj, B * (D + Ef) + D), ld_xproj=D + Ef, e_part=e_part, xdec_t=xdec_t,
+                   co_host=self.co_host)
         # decoder-LSTM chain operands (prepared before the pipeline below)
         pre_dec = self.buf("pre_dec", T, B, 4 * D)
         dec_c = self.buf("dec_c", T + 1, B, D)

@@ -222,9 +222,10 @@ def test_train_step_midsize_matches_oracle():
         ps.load_state_dict({k: v.detach() for k, v in Pc.items()})
 
 
-@pytest.mark.parametrize("co_fwd,co_bwd,chunk,plans", [(True, True, 8, False), (False, False, 8, True), (True, False, 64, False),
-                                                        (False, True, 5, False), (True, False, 8, True)])
-def test_pipeline_variants_match_oracle(co_fwd, co_bwd, chunk, plans):
+@pytest.mark.parametrize("co_fwd,co_bwd,chunk,plans,co_host", [(True, True, 8, False, 1), (False, False, 8, True, 0),
+                                                                (True, False, 64, False, 0), (False, True, 5, False, 0),
+                                                                (True, False, 8, True, 0), (True, False, 8, False, 2)])
+def test_pipeline_variants_match_oracle(co_fwd, co_bwd, chunk, plans, co_host):
     """The frame loop's schedule (chunk size, decoder-LSTM steps co-scheduled inside attention launches or on the side
     stream) must not change results: every variant against the CPU oracle on the same inputs."""
     dev = _dev()
@@ -233,6 +234,7 @@ def test_pipeline_variants_match_oracle(co_fwd, co_bwd, chunk, plans):
     P = R.init_params(d, seed=11)
     eng, ps = build_engine(d, P, dev)
     eng.co_schedule, eng.co_schedule_bwd, eng.chunk, eng.chunk_bwd, eng.use_plans = co_fwd, co_bwd, chunk, chunk, plans
+    eng.co_host = co_host
     ci, lens, mel, tl, gate, masks = random_case(d, 5, 17, 23, 77, dev)
     Pc = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not R.is_buffer(k)) else v.clone()) for k, v in P.items()}
     o = R.tacotron2_fwd(Pc, d, ci, lens, True, mel, tl, training=True, masks=masks, new_stats={})
