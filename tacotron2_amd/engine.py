@@ -84,7 +84,7 @@ class Engine:
         self.co_host = int(_os.environ.get("T2_CO_HOST", "1"))   # where the co-scheduled decoder cell rides: 1 = energies launch (measured best:
                                                                  # 26.85 ms vs 27.2 ms in the context launch, 29.2 ms split over both)
         self.profile = False          # when True, mark() records HIP events at segment boundaries
-        self.marks = []               # [(name, event)] of the current step
+        self.marks = []; self.spans = []               # [(name, event)] of the current step
 
     # ---- kernel-parameter tables ("plans", include/tacotron2_amd.h T2AttnSeq.plan) ---------------------------------
     def plan_upload(self, name: str, plan_fn, *args):
@@ -122,11 +122,27 @@ class Engine:
             self.marks.append((name, ev))
 
     def segment_times_ms(self):
-        """Durations between consecutive marks of the last profiled step: {segment: ms} (summed per name)."""
+        """Durations between consecutive marks of the last profiled step: {segment: ms} (summed per name), plus the
+        side-stream spans recorded with mark_span (work that runs concurrently with main-stream segments)."""
         out: Dict[str, float] = {}
         for (n0, e0), (n1, e1) in zip(self.marks[:-1], self.marks[1:]):
             out[n1] = out.get(n1, 0.0) + e0.elapsed_time(e1)
+        for name, e0, e1 in self.spans:
+            out[name] = out.get(name, 0.0) + e0.elapsed_time(e1)
         return out
+
+    def span_begin(self):
+        if not self.profile:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def span_end(self, name: str, e0):
+        if e0 is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream())
+            self.spans.append((name, e0, ev))
 
     def make_masks(self, B: int, L: int, T: int, training: bool, seed: int, step: int) -> dict:
         """Dropout scale masks for one step from the device Philox generator (t2_philox_mask).  Sites and rates as
@@ -287,6 +303,25 @@ class Engine:
         ctx["len32"], ctx["mlen32"], ctx["chars_idx"] = len32, mlen32, chars_idx
 
         self.mark("start")
+        # The prenet and the hoisted prenet part of the attention-RNN input projection depend only on the mel input: they run
+        # on the side stream next to the encoder, whose BiLSTM recurrence is a chain of small latency-bound launches.
+        main0, side0 = torch.cuda.current_stream(), self.side_stream()
+        side0.wait_stream(main0)
+        with torch.cuda.stream(side0):
+            mel_tm = self.buf("mel_tm", T + 1, B, M)
+            call("t2_mel_to_tm", mel, mel_tm, B, T, M, _stream())
+            pd = masks.get("prenet_drop")
+            p1 = self.buf("p1", T + 1, B, Pd)
+            p2 = self.buf("p2", T + 1, B, Pd)
+            R1 = (T + 1) * B
+            gemm(mel_tm, P["prenet.0.weight"], p1, R1, Pd, M, M, M, Pd, relu=1, mulmask=pd[0] if pd else None, ldmask=Pd)
+            gemm(p1, P["prenet.3.weight"], p2, R1, Pd, Pd, Pd, Pd, Pd, relu=1, mulmask=pd[1] if pd else None, ldmask=Pd)
+            R = T * B
+            pre_att = self.buf("pre_att", T, B, 4 * A)
+            sp0 = self.span_begin()
+            gemm(p2, P["decoder.att_rnn.weight_ih"], pre_att, R, 4 * A, Pd, Pd, Pd + Ef, 4 * A,
+                 bias=P["decoder.att_rnn.bias_ih"], bias2=P["decoder.att_rnn.bias_hh"])
+            self.span_end("fwd.dec.pre_att_gemm.side_stream", sp0)   # part of the decoder step; runs next to the encoder
         enc = self.encoder_fwd(chars_idx, len32, training, masks, ctx)
         self.mark("fwd.encoder")
 
@@ -306,23 +341,7 @@ class Engine:
         gemm(P["att_encoder.weight"], memory, pmT, Ad, L, Ef, Ef, Ef, L, batch=B, sA=0, sB=L * Ef, sC=Ad * L)
 
         self.mark("fwd.condition")
-        # prenet on all frames, time-major (model/tacotron2.py:255-258)
-        mel_tm = self.buf("mel_tm", T + 1, B, M)
-        call("t2_mel_to_tm", mel, mel_tm, B, T, M, st)
-        pd = masks.get("prenet_drop")
-        p1 = self.buf("p1", T + 1, B, Pd)
-        p2 = self.buf("p2", T + 1, B, Pd)
-        R1 = (T + 1) * B
-        gemm(mel_tm, P["prenet.0.weight"], p1, R1, Pd, M, M, M, Pd, relu=1, mulmask=pd[0] if pd else None, ldmask=Pd)
-        gemm(p1, P["prenet.3.weight"], p2, R1, Pd, Pd, Pd, Pd, Pd, relu=1, mulmask=pd[1] if pd else None, ldmask=Pd)
-
-        self.mark("fwd.prenet")
-        # hoisted prenet part of the attention-RNN input projection + both biases
-        R = T * B
-        pre_att = self.buf("pre_att", T, B, 4 * A)
-        gemm(p2, P["decoder.att_rnn.weight_ih"], pre_att, R, 4 * A, Pd, Pd, Pd + Ef, 4 * A,
-             bias=P["decoder.att_rnn.bias_ih"], bias2=P["decoder.att_rnn.bias_hh"])
-
+        main0.wait_stream(side0)      # prenet (model/tacotron2.py:255-258) and pre_att (side stream, above) are ready
         self.mark("fwd.dec.pre_att_gemm")
         # attention chain
         U = self.buf("U", Ad, 2, KL)
@@ -648,47 +667,51 @@ class Engine:
             dec_wgrads()
         self.mark("bwd.dec.chains")
 
-        # weight gradients of the attention chain (large GEMMs over all frames)
-        gWih = G["decoder.att_rnn.weight_ih"]
-        self._wgrad(dga, ldz, ctx["p2"], Pd, gWih, Pd + Ef, 4 * A, Pd, R)
-        self._wgrad(dga, ldz, _ptr(xdec, A), ldx, _ptr(gWih, Pd), Pd + Ef, 4 * A, Ef, R)
-        self._wgrad(dga, ldz, xdec, ldx, G["decoder.att_rnn.weight_hh"], A, 4 * A, A, R)
-        db = self.buf("db_att", 4 * A, zero=True)
-        call("t2_colsum", dga, ldz, R, 4 * A, db, st)
-        G["decoder.att_rnn.bias_ih"].add_(db); G["decoder.att_rnn.bias_hh"].add_(db)
-        self._wgrad(dq, ldz, _ptr(xdec, B * ldx), ldx, G["decoder.attention.query_layer.weight"], A, Ad, A, R)
-        call("t2_colsum", dv_part, Ad, B, Ad, G["decoder.attention.v.weight"], st)
-        dU = self.buf("dU", Ad, 2 * KL, zero=True)
-        call("t2_colsum", dU_part, Ad * 2 * KL, B, Ad * 2 * KL, dU, st)
-        Wd, Wc = P["decoder.attention.location_dense.weight"], P["decoder.attention.location_conv.weight"]
-        gemm(dU, Wc, G["decoder.attention.location_dense.weight"], Ad, F, 2 * KL, 2 * KL, 2 * KL, F, accumulate=1)
-        gemm(Wd, dU, G["decoder.attention.location_conv.weight"], F, 2 * KL, Ad, F, 2 * KL, 2 * KL, a_k=0, b_k=0,
-             accumulate=1)
-
-        # gradient w.r.t. the encoder memory: context path (batched over samples) + processed-memory path
+        # gradient w.r.t. the encoder memory: context path (batched over samples) + processed-memory path.  It heads the
+        # critical branch (conditioning -> encoder BiLSTM recurrence -> encoder convolutions), so it goes first.
         dmem = self.buf("dmem", B, L, Ef)
         gemm(ctx["align"], dctx_tot, dmem, L, Ef, T, L, B * Ef, Ef, a_k=0, b_k=0, batch=B, sA=T * L, sB=Ef, sC=L * Ef)
         Watt = P["att_encoder.weight"]
         gemm(dpmT, Watt, dmem, L, Ef, Ad, L, Ef, Ef, a_k=0, b_k=0, accumulate=1, batch=B, sA=Ad * L, sB=0, sC=L * Ef)
-        gemm(dpmT, ctx["memory"], G["att_encoder.weight"], Ad, Ef, L, L, Ef, Ef, a_k=1, b_k=0, accumulate=2, batch=B,
-             sA=Ad * L, sB=L * Ef, sC=0)
 
+        # Independent branch on the side stream: weight gradients of the attention chain (large GEMMs over all frames) and the
+        # prenet backward.  The main stream meanwhile walks the encoder BiLSTM backward recurrence, a chain of small
+        # latency-bound launches that fits next to the GEMM workgroups.
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            sst = side.cuda_stream
+            gWih = G["decoder.att_rnn.weight_ih"]
+            self._wgrad(dga, ldz, ctx["p2"], Pd, gWih, Pd + Ef, 4 * A, Pd, R)
+            self._wgrad(dga, ldz, _ptr(xdec, A), ldx, _ptr(gWih, Pd), Pd + Ef, 4 * A, Ef, R)
+            self._wgrad(dga, ldz, xdec, ldx, G["decoder.att_rnn.weight_hh"], A, 4 * A, A, R)
+            db = self.buf("db_att", 4 * A, zero=True)
+            call("t2_colsum", dga, ldz, R, 4 * A, db, sst)
+            G["decoder.att_rnn.bias_ih"].add_(db); G["decoder.att_rnn.bias_hh"].add_(db)
+            self._wgrad(dq, ldz, _ptr(xdec, B * ldx), ldx, G["decoder.attention.query_layer.weight"], A, Ad, A, R)
+            call("t2_colsum", dv_part, Ad, B, Ad, G["decoder.attention.v.weight"], sst)
+            dU = self.buf("dU", Ad, 2 * KL, zero=True)
+            call("t2_colsum", dU_part, Ad * 2 * KL, B, Ad * 2 * KL, dU, sst)
+            Wd, Wc = P["decoder.attention.location_dense.weight"], P["decoder.attention.location_conv.weight"]
+            gemm(dU, Wc, G["decoder.attention.location_dense.weight"], Ad, F, 2 * KL, 2 * KL, 2 * KL, F, accumulate=1)
+            gemm(Wd, dU, G["decoder.attention.location_conv.weight"], F, 2 * KL, Ad, F, 2 * KL, 2 * KL, a_k=0, b_k=0,
+                 accumulate=1)
+            gemm(dpmT, ctx["memory"], G["att_encoder.weight"], Ad, Ef, L, L, Ef, Ef, a_k=1, b_k=0, accumulate=2, batch=B,
+                 sA=Ad * L, sB=L * Ef, sC=0)
+            # ---- prenet ----
+            dp2 = self.buf("dp2", T + 1, B, Pd)
+            dp2[T].zero_()
+            gemm(dga, P["decoder.att_rnn.weight_ih"], dp2, R, Pd, 4 * A, ldz, Pd + Ef, Pd, a_k=1, b_k=0)
+            pd = ctx["pd"]
+            g2 = self.buf("g2", T + 1, B, Pd)
+            call("t2_relu_mask_bwd", dp2, ctx["p2"], pd[1] if pd else None, g2, R1 * Pd, sst)
+            self._wgrad(g2, Pd, ctx["p1"], Pd, G["prenet.3.weight"], Pd, Pd, Pd, R1)
+            dp1 = self.buf("dp1", T + 1, B, Pd)
+            gemm(g2, P["prenet.3.weight"], dp1, R1, Pd, Pd, Pd, Pd, Pd, a_k=1, b_k=0)
+            g1 = self.buf("g1", T + 1, B, Pd)
+            call("t2_relu_mask_bwd", dp1, ctx["p1"], pd[0] if pd else None, g1, R1 * Pd, sst)
+            self._wgrad(g1, Pd, ctx["mel_tm"], M, G["prenet.0.weight"], M, Pd, M, R1)
         self.mark("bwd.dec.attn_gemms")
-        # ---- prenet -----------------------------------------------------------------------------------------
-        dp2 = self.buf("dp2", T + 1, B, Pd)
-        dp2[T].zero_()
-        gemm(dga, P["decoder.att_rnn.weight_ih"], dp2, R, Pd, 4 * A, ldz, Pd + Ef, Pd, a_k=1, b_k=0)
-        pd = ctx["pd"]
-        g2 = self.buf("g2", T + 1, B, Pd)
-        call("t2_relu_mask_bwd", dp2, ctx["p2"], pd[1] if pd else None, g2, R1 * Pd, st)
-        self._wgrad(g2, Pd, ctx["p1"], Pd, G["prenet.3.weight"], Pd, Pd, Pd, R1)
-        dp1 = self.buf("dp1", T + 1, B, Pd)
-        gemm(g2, P["prenet.3.weight"], dp1, R1, Pd, Pd, Pd, Pd, Pd, a_k=1, b_k=0)
-        g1 = self.buf("g1", T + 1, B, Pd)
-        call("t2_relu_mask_bwd", dp1, ctx["p1"], pd[0] if pd else None, g1, R1 * Pd, st)
-        self._wgrad(g1, Pd, ctx["mel_tm"], M, G["prenet.0.weight"], M, Pd, M, R1)
 
-        self.mark("bwd.prenet")
         # ---- conditioning ---------------------------------------------------------------------------------------
         denc = self.buf("denc", B, L, E)
         ddesc = self.buf("ddesc", B, 128) if d.get("description_embeddings") else None

@@ -62,7 +62,7 @@ class Trainer:
         ci, mel = batch["chars_idx"], batch["mel_spectrogram"]
         B, L = ci.shape
         T = mel.shape[1]
-        eng.marks = []
+        eng.marks = []; eng.spans = []
         if masks is None:
             masks = eng.make_masks(B, L, T, True, self.seed + 7919 * self.rank, self.global_step)
         eng.mark("masks")
