@@ -83,7 +83,8 @@ typedef struct {
     float* h_out; int64_t ldh;       /* post-dropout h */
     float* h_out2; int64_t ldh2;     /* optional second copy (NULL to skip) */
     float* c_out; int64_t ldc_out;
-    float* gates_out; int64_t ldg;   /* optional stash of activated gates [b][4H] for backward */
+    float* gates_out; int64_t ldg;   /* optional stash of the activated gates for backward, gate-interleaved: row b holds
+                                        [u][4] = (i, f, g, o) of unit u (16-byte items; ldg >= 4H, 16-byte aligned rows) */
     const int32_t* len; int t;       /* optional activity predicate */
     /* x16-tiled operands (packed path only).  A (B x K) matrix in x16 layout is stored [K/16][Bp][16] with
      * Bp = round_up(B,16): one 16-row x 16-column MFMA operand tile is ONE contiguous 1 KB block, so a wave-load reads
@@ -135,7 +136,7 @@ typedef struct {
     const float* ext1; int64_t ldx1; const float* ext2; int64_t ldx2;
     float* dx_out; int64_t lddx;
     const float* drop; int64_t lddrop;
-    const float* gates; int64_t ldgs;
+    const float* gates; int64_t ldgs;       /* the forward stash, gate-interleaved [b][u][4] (T2LstmStep.gates_out) */
     const float* c_prev; int64_t ldcp; const float* c_cur; int64_t ldcc;
     float* dc; int64_t lddc;
     float* dg_out; int64_t ldgo;

@@ -138,8 +138,8 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmK2 pp) {
             if (p.h_out2) p.h_out2[(long)b * p.ldh2 + u] = hn;
             if (p.c_out) p.c_out[(long)b * p.ldc_out + u] = cn;
             if (p.gates_out) {
-                float* go_ = p.gates_out + (long)b * p.ldg + u;
-                go_[0] = gi; go_[H] = gf; go_[2 * H] = gg; go_[3 * H] = go;
+                // gate-interleaved stash [b][u][4] = (i, f, g, o): one 16-byte store per thread, 64 contiguous bytes per 4 units
+                *reinterpret_cast<f32x4*>(p.gates_out + (long)b * p.ldg + 4 * u) = (f32x4){gi, gf, gg, go};
             }
         }
     }
@@ -238,8 +238,8 @@ __device__ __forceinline__ void bwd_epilogue(const BwdK& p, const float* red, in
                 const bool active = (p.len == nullptr) || (p.t < p.len[b]);
                 float dh = dx;
                 if (p.drop) dh *= p.drop[(long)b * p.lddrop + u];
-                const float* gs = p.gates + (long)b * p.ldgs + u;
-                const float gi = gs[0], gf = gs[H], gg = gs[2 * H], go = gs[3 * H];
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gates + (long)b * p.ldgs + 4 * u);
+                const float gi = g4[0], gf = g4[1], gg = g4[2], go = g4[3];
                 const float cp = p.c_prev ? p.c_prev[(long)b * p.ldcp + u] : 0.f;
                 const float tc = t2_tanh(p.c_cur[(long)b * p.ldcc + u]);
                 float dcv = p.dc[(long)b * p.lddc + u] + dh * go * (1.f - tc * tc);

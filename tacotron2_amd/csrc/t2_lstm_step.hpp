@@ -182,10 +182,8 @@ __device__ __forceinline__ void t2_lstm_fwd_fast_body(const LstmK& p, const int 
             if (p.ht_out) { const int col = p.ht_col0 + u; p.ht_out[(long)(col >> 4) * p.xt_cs + b * 16 + (col & 15)] = hn; }
             if (p.c_out) p.c_out[(long)b * p.ldc_out + u] = cn;
             if (p.gates_out) {
-                float* go_ = p.gates_out + (long)b * p.ldg + u;
-                // stash for the backward pass: read once, much later -> non-temporal (does not stay dirty in L2)
-                __builtin_nontemporal_store(gi, go_); __builtin_nontemporal_store(gf, go_ + H);
-                __builtin_nontemporal_store(gg, go_ + 2 * H); __builtin_nontemporal_store(go, go_ + 3 * H);
+                // gate-interleaved stash [b][u][4] = (i, f, g, o): one 16-byte store per thread, 64 contiguous bytes per 4 units
+                *reinterpret_cast<f32x4*>(p.gates_out + (long)b * p.ldg + 4 * u) = (f32x4){gi, gf, gg, go};
             }
         }
     }
@@ -258,8 +256,8 @@ __device__ __forceinline__ BwdEpi bwd_epi_load(const BwdK& p, int tid, int u0, i
     if (p.epi == 1) {
         const int H = p.H;
         if (p.drop) e.drop = p.drop[b * p.lddrop + u];
-        const float* gs = p.gates + b * p.ldgs + u;
-        e.gi = gs[0]; e.gf = gs[H]; e.gg = gs[2 * H]; e.go = gs[3 * H];
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gates + b * p.ldgs + 4 * u);   // gate-interleaved stash [b][u][4]
+        e.gi = g4[0]; e.gf = g4[1]; e.gg = g4[2]; e.go = g4[3];
         if (p.c_prev) e.cp = p.c_prev[b * p.ldcp + u];
         e.cc = p.c_cur[b * p.ldcc + u];
         e.dc = p.dc[b * p.lddc + u];

@@ -112,7 +112,7 @@ def test_lstm_step_fwd(dev, B, H, Ks):
     torch.cuda.synchronize()
     assert _rel(h, h_ref) < 5e-6 and _rel(c, c_ref) < 5e-6
     i_ref = 1 / (1 + torch.exp(-gates[:, :H]))
-    assert _rel(gs[:, :H], i_ref) < 5e-6
+    assert _rel(gs.view(B, H, 4)[:, :, 0], i_ref) < 5e-6      # gate-interleaved stash [b][u][4] = (i, f, g, o)
 
 
 def _tile16(x, Bp):
@@ -203,7 +203,7 @@ def test_lstm_step_bwd_packed_tiled(dev, B, H, N4):
         dc = dc0.clone().to(dev)
         dgo = torch.empty(B, 4 * H, device=dev)
         dgo_t = torch.zeros(4 * H // 16, Bp, 16, device=dev) if tiled else None
-        keep = [dg.to(dev), ext.to(dev), gates.to(dev), cp.to(dev), cc.to(dev)]
+        keep = [dg.to(dev), ext.to(dev), gates.view(B, 4, H).transpose(1, 2).contiguous().view(B, 4 * H).to(dev), cp.to(dev), cc.to(dev)]
         s = _lib.make("T2LstmBwdStep", B=B, H=H, N4=N4, dg_next=keep[0], lddg=N4, W=Wd, ldw=H, wtpacked=wtp, ncols=H, epi=1,
                       ext1=keep[1], ldx1=H, gates=keep[2], ldgs=4 * H, c_prev=keep[3], ldcp=H, c_cur=keep[4], ldcc=H,
                       dc=dc, lddc=H, dg_out=dgo, ldgo=4 * H, dgt_next=dgt if tiled else None, dgt_out=dgo_t)
@@ -240,7 +240,7 @@ def test_lstm_step_bwd_matches_autograd(dev):
     f = lambda t: t.detach().float().to(dev).contiguous()
     dc = f(dc1); dg = torch.empty(B, 4 * H, device=dev)
     s = _lib.make("T2LstmBwdStep", B=B, H=H, N4=4 * H, ncols=H, epi=1, ext1=f(dh1), ldx1=H, drop=f(drop), lddrop=H,
-                  gates=f(acts), ldgs=4 * H, c_prev=f(c0), ldcp=H, c_cur=f(c1), ldcc=H, dc=dc, lddc=H, dg_out=dg, ldgo=4 * H)
+                  gates=f(acts.view(B, 4, H).transpose(1, 2).contiguous().view(B, 4 * H)), ldgs=4 * H, c_prev=f(c0), ldcp=H, c_cur=f(c1), ldcc=H, dc=dc, lddc=H, dg_out=dg, ldgo=4 * H)
     _lib.call("t2_lstm_step_bwd", s, 1, torch.cuda.current_stream().cuda_stream)
     assert _rel(dg, gpre) < 1e-5 and _rel(dc, gc0) < 1e-5
     # recurrent hop: dh0 = dg @ W  (epi=0)
