@@ -319,6 +319,7 @@ int t2_loss_fwd_bwd(const float* mels, const float* post, const float* gates, co
 int t2_relu_mask_bwd(const float* g, const float* y, const float* mask, float* out, int64_t n, void* stream);
 int t2_condition_fwd(const float* enc, const float* spk_table, const int32_t* spk, const float* desc, float* memory, int B,
                      int L, int E, int Ef, void* stream);
+/* dspk_table and ddesc are ACCUMULATED into (atomics): the caller zero-fills ddesc */
 int t2_condition_bwd(const float* dmem, const float* memory, const int32_t* spk, float* denc, float* dspk_table, float* ddesc,
                      int B, int L, int E, int Ef, void* stream);
 int t2_tanh_bias(float* x, const float* bias, int64_t rows, int C, void* stream);

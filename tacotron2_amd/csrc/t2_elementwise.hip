@@ -416,20 +416,31 @@ __global__ void condition_fwd_kernel(const float* enc, const float* spk_table, c
 // ddesc[b][:] += sum_l dmem[b][l][E:]
 __global__ void condition_bwd_kernel(const float* dmem, const float* memory, const int32_t* spk, int has_spk, float* denc,
                                      float* dspk_table, float* ddesc, int B, int L, int E, int Ef) {
-    const int b = blockIdx.x;
+    // grid (B, ceil(L/16)): 16 rows per workgroup with all their loads independent (a single workgroup per sample walking
+    // L rows with a dependent accumulation took 0.67 ms); the row sums are combined with atomics
+    const int b = blockIdx.x, l0 = blockIdx.y * 16;
     for (int e = threadIdx.x; e < Ef; e += blockDim.x) {
-        float acc = 0.f;
-        for (int l = 0; l < L; ++l) {
+        float g[16], m[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int l = l0 + r < L ? l0 + r : L - 1;
             const long i = ((long)b * L + l) * Ef + e;
-            float g = dmem[i];
+            g[r] = dmem[i];
+            m[r] = (e < E && has_spk) ? memory[i] : 0.f;
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (l0 + r >= L) continue;
+            float v = g[r];
             if (e < E) {
-                if (has_spk) { const float m = memory[i]; g *= (1.f - m * m); }
-                denc[((long)b * L + l) * E + e] = g;
+                if (has_spk) v *= (1.f - m[r] * m[r]);
+                denc[((long)b * L + l0 + r) * E + e] = v;
             }
-            acc += g;
+            acc += v;
         }
         if (e < E) { if (has_spk) atomicAdd(&dspk_table[(long)spk[b] * E + e], acc); }
-        else if (ddesc) ddesc[(long)b * (Ef - E) + (e - E)] = acc;
+        else if (ddesc) atomicAdd(&ddesc[(long)b * (Ef - E) + (e - E)], acc);
     }
 }
 
@@ -615,8 +626,8 @@ extern "C" int t2_condition_fwd(const float* enc, const float* spk_table, const 
 extern "C" int t2_condition_bwd(const float* dmem, const float* memory, const int32_t* spk, float* denc, float* dspk_table,
                                 float* ddesc, int B, int L, int E, int Ef, void* stream) {
     T2_REQUIRE(dmem && memory && denc, "t2_condition_bwd: null");
-    hipLaunchKernelGGL(condition_bwd_kernel, dim3(B), dim3(256), 0, ST, dmem, memory, spk, dspk_table != nullptr, denc, dspk_table,
-                       ddesc, B, L, E, Ef);
+    hipLaunchKernelGGL(condition_bwd_kernel, dim3(B, t2_cdiv(L, 16)), dim3(256), 0, ST, dmem, memory, spk, dspk_table != nullptr, denc,
+                       dspk_table, ddesc, B, L, E, Ef);
     T2_CHECK_LAUNCH(); return T2_OK;
 }
 extern "C" int t2_tanh_bias(float* x, const float* bias, int64_t rows, int C, void* stream) {

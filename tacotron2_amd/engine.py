@@ -714,7 +714,7 @@ class Engine:
 
         # ---- conditioning ---------------------------------------------------------------------------------------
         denc = self.buf("denc", B, L, E)
-        ddesc = self.buf("ddesc", B, 128) if d.get("description_embeddings") else None
+        ddesc = self.buf("ddesc", B, 128, zero=True) if d.get("description_embeddings") else None
         call("t2_condition_bwd", dmem, ctx["memory"], ctx["spk32"], denc,
              G["speaker_embedding.weight"] if d.get("speaker_tokens") else None, ddesc, B, L, E, Ef, st)
         if ddesc is not None:
