@@ -28,13 +28,41 @@ struct LinK {
     float* out_t; int out_col0; long out_cs;   // optional x16-tiled copy of the output (chunk stride out_cs floats)
     int ksplit;                                // > 1: blockIdx.y owns a K slice, partial sums are atomically added into a
                                                // ZERO-FILLED out (bias by slice 0; no relu/mask/out_t)
+    // optional stop logic of the PREVIOUS frame, run by one extra workgroup next to the linear (saves one dependent launch per frame)
+    const float* stop_proj; long stop_ldp; int stop_M, stop_t;
+    int32_t* stop_done; int64_t* stop_lengths; int32_t* stop_state;
 };
+
+// model/tacotron2.py:319-322: done[gate < 0] = True; lengths[gate >= 0] += 1; if done.all(): break  (the frame that
+// completes `done` is still emitted).  state = {all_done, n_frames}; nothing changes once all_done is set.  One workgroup.
+__device__ __forceinline__ void stop_logic(const float* proj, long ldp, int M, int B, int t, int32_t* done, int64_t* lengths,
+                                           int32_t* state, int* notdone /* LDS */) {
+    if (threadIdx.x == 0) *notdone = 0;
+    __syncthreads();
+    if (state[0] == 0) {
+        for (int b = threadIdx.x; b < B; b += blockDim.x) {
+            const float g = proj[(long)b * ldp + M];
+            if (g < 0.f) done[b] = 1; else lengths[b] += 1;
+            if (!done[b]) atomicAdd(notdone, 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && state[0] == 0) {
+        state[1] = t + 1;
+        if (*notdone == 0) state[0] = 1;
+    }
+}
 
 // out[b][n] = act(sum_k x[b][k] w[n][k] + bias[n]) * mask[b][n]; M = batch rows on the MFMA M axis (<= 64), one
 // 16-column tile per workgroup, K split over the 4 waves (K % 16 == 0), all loads issued before the first MFMA wait.
 template <int MT>
 __global__ __launch_bounds__(256, 1) void linear_rows_kernel(LinK p) {
     __shared__ float red[4 * MT * 256];
+    __shared__ int notdone;
+    if (p.stop_proj && blockIdx.x == gridDim.x - 1) {   // one extra workgroup: the stop logic runs next to the linear, not in front
+        stop_logic(p.stop_proj, p.stop_ldp, p.stop_M, p.B, p.stop_t, p.stop_done, p.stop_lengths, p.stop_state, &notdone);
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
@@ -102,7 +130,8 @@ int launch_linear(const LinK& k, hipStream_t st) {
                "linear rows: K % 16 == 0 and 16-byte aligned operands required");
     T2_REQUIRE(k.B >= 1 && k.B <= 64, "linear rows: 1 <= B <= 64");
     T2_REQUIRE(k.ksplit >= 1 && (k.ksplit == 1 || (!k.relu && !k.mask && !k.out_t)), "linear rows: K split needs a plain linear");
-    dim3 grid(t2_cdiv(k.N, 16), k.ksplit), block(256);
+    T2_REQUIRE(!k.stop_proj || k.ksplit == 1, "linear rows: stop logic rides only in unsplit launches");
+    dim3 grid(t2_cdiv(k.N, 16) + (k.stop_proj ? 1 : 0), k.ksplit), block(256);
     if (k.B <= 16) hipLaunchKernelGGL((linear_rows_kernel<1>), grid, block, 0, st, k);
     else if (k.B <= 32) hipLaunchKernelGGL((linear_rows_kernel<2>), grid, block, 0, st, k);
     else hipLaunchKernelGGL((linear_rows_kernel<4>), grid, block, 0, st, k);
@@ -110,23 +139,9 @@ int launch_linear(const LinK& k, hipStream_t st) {
     return T2_OK;
 }
 
-// model/tacotron2.py:319-322: done[gate < 0] = True; lengths[gate >= 0] += 1; if done.all(): break  (the frame that
-// completes `done` is still emitted).  state = {all_done, n_frames}; nothing changes once all_done is set.
 __global__ void stop_kernel(const float* proj, long ldp, int M, int B, int t, int32_t* done, int64_t* lengths, int32_t* state) {
     __shared__ int notdone;
-    if (threadIdx.x == 0) notdone = 0;
-    __syncthreads();
-    if (state[0]) return;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        const float g = proj[(long)b * ldp + M];
-        if (g < 0.f) done[b] = 1; else lengths[b] += 1;
-        if (!done[b]) atomicAdd(&notdone, 1);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        state[1] = t + 1;
-        if (notdone == 0) state[0] = 1;
-    }
+    stop_logic(proj, ldp, M, B, t, done, lengths, state, &notdone);
 }
 
 }  // namespace
@@ -142,6 +157,7 @@ extern "C" int t2_linear_rows(const float* x, int64_t ldx, const float* w, int64
         k.mask = mask ? mask + (long)b0 * ldmask : nullptr; k.ldmask = ldmask; k.relu = relu;
         k.out = out + (long)b0 * ldo; k.ldo = ldo;
         k.out_t = nullptr; k.out_col0 = 0; k.out_cs = 0; k.ksplit = 1;
+        k.stop_proj = nullptr;
         T2_TRY(launch_linear(k, st));
     }
     return T2_OK;
@@ -166,9 +182,20 @@ extern "C" int t2_decoder_infer(const T2Infer* a, int t0, int t1, void* stream) 
         const long ldprev = t == 0 ? 0 : ldo;
         const float* m1 = a->prenet_mask ? a->prenet_mask + ((long)t * 2 + 0) * B * P : nullptr;
         const float* m2 = a->prenet_mask ? a->prenet_mask + ((long)t * 2 + 1) * B * P : nullptr;
-        T2_TRY(t2_linear_rows(prev, ldprev, a->W_pre1, M, nullptr, m1, P, 1, a->p1, P, B, P, M, stream));
+        {   // first prenet layer; one extra workgroup of the launch runs the stop logic of frame t-1 (frames of this call only)
+            LinK k;
+            memset(&k, 0, sizeof(k));
+            k.B = B; k.N = P; k.K = M; k.x = prev; k.ldx = ldprev; k.w = a->W_pre1; k.ldw = M; k.mask = m1; k.ldmask = P;
+            k.relu = 1; k.out = a->p1; k.ldo = P; k.ksplit = 1;
+            if (t > t0) {
+                k.stop_proj = prev; k.stop_ldp = ldo; k.stop_M = M; k.stop_t = t - 1;
+                k.stop_done = a->done; k.stop_lengths = a->lengths; k.stop_state = a->state;
+            }
+            T2_TRY(launch_linear(k, st));
+        }
         {
             LinK k;
+            memset(&k, 0, sizeof(k));
             k.B = B; k.N = P; k.K = P; k.x = a->p1; k.ldx = P; k.w = a->W_pre2; k.ldw = P; k.bias = nullptr;
             k.mask = m2; k.ldmask = P; k.relu = 1; k.out = a->p2; k.ldo = P;
             k.out_t = xs_cur; k.out_col0 = 0; k.out_cs = cs; k.ksplit = 1;
@@ -215,12 +242,14 @@ extern "C" int t2_decoder_infer(const T2Infer* a, int t0, int t1, void* stream) 
         float* out = a->proj + (long)t * B * ldo;
         {
             LinK k;
+            memset(&k, 0, sizeof(k));
             k.B = B; k.N = M + 1; k.K = (int)ldp; k.x = a->xproj; k.ldx = ldp; k.w = a->W_proj; k.ldw = ldp; k.bias = a->b_proj;
             k.mask = nullptr; k.ldmask = 0; k.relu = 0; k.out = out; k.ldo = ldo;
             k.out_t = nullptr; k.out_col0 = 0; k.out_cs = 0; k.ksplit = ksplit;
             T2_TRY(launch_linear(k, st));
         }
-        hipLaunchKernelGGL(stop_kernel, dim3(1), dim3(256), 0, st, out, ldo, M, B, t, a->done, a->lengths, a->state);
+        if (t == t1 - 1)   // the last frame of the call: nobody else will run its stop logic before the host looks
+            hipLaunchKernelGGL(stop_kernel, dim3(1), dim3(256), 0, st, out, ldo, M, B, t, a->done, a->lengths, a->state);
     }
     T2_CHECK_LAUNCH();
     return T2_OK;
