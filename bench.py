@@ -77,9 +77,19 @@ def cpu_baseline(dims, batch, t_cap, b_cap):
             R.adam_l2_step(P[k], gr * coef, torch.zeros_like(gr), torch.zeros_like(gr), 1, 1e-3, 1e-6)
     dt = time.perf_counter() - t0
     frames = int(tl.sum())
+    # secondary metric on the CPU too: autoregressive inference steps of the same oracle, eval mode, the
+    # same utterances, a bounded number of frames (random weights never emit a stop)
+    n_inf = 40
+    with torch.no_grad():
+        Pi = {k: v.detach() for k, v in P.items()}
+        t1 = time.perf_counter()
+        R.tacotron2_fwd(Pi, d, ci, cl, False, speaker_id=spk, max_len_override=n_inf, training=False, masks={})
+        dti = time.perf_counter() - t1
     return dict(value=frames / dt, unit="mel-frames/s", cores=cores, kind="port",
                 sample=f"oracle/tacotron2_ref.py, 1 train step (fwd+loss+bwd+clip+Adam), first {b_cap} utterances of the "
-                       f"bench batch, frames capped at {t_cap} (L={L}, T={T}, {frames} valid frames), {dt:.1f} s")
+                       f"bench batch, frames capped at {t_cap} (L={L}, T={T}, {frames} valid frames), {dt:.1f} s",
+                decode_steps_per_s=n_inf / dti,
+                decode_sample=f"{n_inf} autoregressive steps, batch {b_cap}, includes encoder and postnet of the call, {dti:.1f} s")
 
 
 def main():
