@@ -94,6 +94,10 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise T2Error(f"{LIB_PATH} not found: build it with `python -m tacotron2_amd.build` "
                       "(hipcc --offload-arch=gfx950). There is no fallback path.")
+    # torch first: its wheel bundles its own libamdhip64 (torch/lib), and the dynamic loader only shares ONE HIP runtime
+    # between torch and this library when torch's copy is already loaded (same SONAME); loaded the other way round the
+    # process ends up with two runtimes and launches on torch's streams fail with "no ROCm-capable device"
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     for name, (ret, alist) in _funcs.items():
         fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol

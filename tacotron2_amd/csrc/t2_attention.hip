@@ -582,6 +582,7 @@ int t2_attn_step_launch(const T2AttnStep* s, hipStream_t st) {
 }
 
 extern "C" int t2_attn_fold_location(const float* Wd, const float* Wc, float* U, int Ad, int F, int Kl, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(Wd && Wc && U && Ad > 0 && F > 0 && Kl > 0, "t2_attn_fold_location: bad arguments");
     const int n = Ad * 2 * Kl;
     hipLaunchKernelGGL(fold_location_kernel, dim3(t2_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, Wd, Wc, U, Ad, F,
@@ -591,6 +592,7 @@ extern "C" int t2_attn_fold_location(const float* Wd, const float* Wc, float* U,
 }
 
 extern "C" int t2_attn_step_fwd(const T2AttnStep* s, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(s != nullptr, "t2_attn_step_fwd: null");
     return t2_attn_step_launch(s, (hipStream_t)stream);
 }
@@ -676,6 +678,7 @@ static int attn_seq_fwd_core(const T2AttnSeq* a, hipStream_t st, int mode, const
 }
 
 extern "C" int64_t t2_attn_seq_fwd_plan(const T2AttnSeq* a, void* host_tab, int64_t bytes) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     if (!a) return -1;
     const int64_t need = fwd_tab_bytes(a->T);
     if (!host_tab) return need;
@@ -686,6 +689,7 @@ extern "C" int64_t t2_attn_seq_fwd_plan(const T2AttnSeq* a, void* host_tab, int6
 }
 
 extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(a != nullptr, "t2_attn_seq_fwd: null");
     if (a->plan) {
         const FwdTabs tabs = fwd_tabs(a->plan, a->T);
@@ -1035,6 +1039,7 @@ __global__ __launch_bounds__(ENT, 4) void attn_bwd_ds_co_kernel(AttnBwdK p, BwdK
 }  // namespace
 
 extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(a != nullptr, "t2_attn_seq_bwd: null");
     T2_REQUIRE(a->Kl == KL && a->Ad % 16 == 0 && a->Ef % 32 == 0, "t2_attn_seq_bwd: unsupported dims");
     T2_REQUIRE(a->L >= 1 && a->L <= 768, "t2_attn_seq_bwd: need 1 <= L <= 768 (LDS budget of the attention kernels)");

@@ -513,27 +513,32 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n
 #define ST ((hipStream_t)stream)
 
 extern "C" int t2_embedding_fwd(const int64_t* idx, const float* table, float* out, int B, int L, int E, int pad, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(idx && table && out, "t2_embedding_fwd: null");
     hipLaunchKernelGGL(embedding_fwd_kernel, dim3(ew_grid((long)B * (L + 2 * pad) * E)), dim3(256), 0, ST, idx, table, out, B, L, E, pad);
     T2_CHECK_LAUNCH(); return T2_OK;
 }
 extern "C" int t2_embedding_bwd(const int64_t* idx, const float* dout, float* dtable, int B, int L, int E, int Lp, int pad, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(idx && dout && dtable, "t2_embedding_bwd: null");
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3(ew_grid((long)B * L * E)), dim3(256), 0, ST, idx, dout, dtable, B, L, E, Lp, pad);
     T2_CHECK_LAUNCH(); return T2_OK;
 }
 extern "C" int t2_pack_conv_weight(const float* w, float* wp, int Co, int Ci, int K, int flip, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(w && wp, "t2_pack_conv_weight: null");
     hipLaunchKernelGGL(pack_conv_w_kernel, dim3(ew_grid((long)Co * Ci * K)), dim3(256), 0, ST, w, wp, Co, Ci, K, flip);
     T2_CHECK_LAUNCH(); return T2_OK;
 }
 extern "C" int t2_unpack_conv_wgrad(const float* gp, float* g, int Co, int Ci, int K, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(gp && g, "t2_unpack_conv_wgrad: null");
     hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(ew_grid((long)Co * Ci * K)), dim3(256), 0, ST, gp, g, Co, Ci, K);
     T2_CHECK_LAUNCH(); return T2_OK;
 }
 
 extern "C" int t2_bn_fwd(const T2Bn* s, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(s && s->x && s->gamma && s->beta && s->mean && s->invstd && s->y, "t2_bn_fwd: null operand");
     T2_REQUIRE(s->training ? (s->sums != nullptr) : (s->running_mean && s->running_var), "t2_bn_fwd: stats operands");
     BnK k; to_bnk(s, k);
@@ -549,6 +554,7 @@ extern "C" int t2_bn_fwd(const T2Bn* s, void* stream) {
 }
 
 extern "C" int t2_bn_bwd(const T2Bn* s, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(s && s->x && s->gamma && s->beta && s->mean && s->invstd && s->dy && s->dx && s->sums && s->dgamma && s->dbeta,
                "t2_bn_bwd: null operand");
     BnK k; to_bnk(s, k);
@@ -561,6 +567,7 @@ extern "C" int t2_bn_bwd(const T2Bn* s, void* stream) {
 }
 
 extern "C" int t2_colsum(const float* x, int64_t ld, int64_t R, int C, float* out, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(x && out && R > 0 && C > 0, "t2_colsum: bad arguments");
     if (C % 4 == 0 && ld % 4 == 0 && t2_aligned16(x) && C >= 256) {
         // enough row blocks for ~4 workgroups per CU
@@ -574,17 +581,20 @@ extern "C" int t2_colsum(const float* x, int64_t ld, int64_t R, int C, float* ou
     T2_CHECK_LAUNCH(); return T2_OK;
 }
 extern "C" int t2_mel_to_tm(const float* mel, float* out, int B, int T, int M, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(mel && out, "t2_mel_to_tm: null");
     hipLaunchKernelGGL(mel_to_tm_kernel, dim3(ew_grid((long)(T + 1) * B * M)), dim3(256), 0, ST, mel, out, B, T, M);
     T2_CHECK_LAUNCH(); return T2_OK;
 }
 extern "C" int t2_swap01(const float* in, float* out, int D0, int D1, int C, int accumulate, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(in && out, "t2_swap01: null");
     hipLaunchKernelGGL(swap01_kernel, dim3(ew_grid((long)D0 * D1 * C)), dim3(256), 0, ST, in, out, D0, D1, C, accumulate);
     T2_CHECK_LAUNCH(); return T2_OK;
 }
 extern "C" int t2_finalize_fwd(const float* proj, int64_t ld_proj, const int32_t* len, float* mels, float* gates, float* post_in,
                                int B, int T, int M, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(proj && len && mels && gates, "t2_finalize_fwd: null");
     hipLaunchKernelGGL(finalize_fwd_kernel, dim3(ew_grid((long)B * (T + 4) * (M + 1))), dim3(256), 0, ST, proj, (long)ld_proj, len, mels, gates,
                        post_in, B, T, M);
@@ -593,6 +603,7 @@ extern "C" int t2_finalize_fwd(const float* proj, int64_t ld_proj, const int32_t
 extern "C" int t2_loss_fwd_bwd(const float* mels, const float* post, const float* gates, const float* mel_tgt,
                                const float* gate_tgt, const int32_t* len, int B, int T, int M, double* loss3, float* d_post,
                                float* dproj, float grad_scale, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(mels && post && gates && mel_tgt && gate_tgt && len && loss3, "t2_loss_fwd_bwd: null");
     (void)hipMemsetAsync(loss3, 0, 3 * sizeof(double), ST);
     hipLaunchKernelGGL(loss_kernel, dim3(ew_grid((long)B * T * (M + 1))), dim3(256), 0, ST, mels, post, gates, mel_tgt, gate_tgt,
@@ -601,23 +612,27 @@ extern "C" int t2_loss_fwd_bwd(const float* mels, const float* post, const float
 }
 extern "C" int t2_outgrad_pack(const float* d_mels, const float* d_post, const float* d_gates, const int32_t* len,
                                float* d_post_out, float* dproj, int B, int T, int M, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(len && d_post_out && dproj, "t2_outgrad_pack: null");
     hipLaunchKernelGGL(outgrad_pack_kernel, dim3(ew_grid((long)B * T * (M + 1))), dim3(256), 0, ST, d_mels, d_post, d_gates, len,
                        d_post_out, dproj, B, T, M);
     T2_CHECK_LAUNCH(); return T2_OK;
 }
 extern "C" int t2_finalize_bwd(const float* dpost_in, float* dproj, int B, int T, int M, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(dpost_in && dproj, "t2_finalize_bwd: null");
     hipLaunchKernelGGL(finalize_bwd_kernel, dim3(ew_grid((long)B * T * M)), dim3(256), 0, ST, dpost_in, dproj, B, T, M);
     T2_CHECK_LAUNCH(); return T2_OK;
 }
 extern "C" int t2_relu_mask_bwd(const float* g, const float* y, const float* mask, float* out, int64_t n, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(g && y && out, "t2_relu_mask_bwd: null");
     hipLaunchKernelGGL(relu_mask_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, g, y, mask, out, (long)n);
     T2_CHECK_LAUNCH(); return T2_OK;
 }
 extern "C" int t2_condition_fwd(const float* enc, const float* spk_table, const int32_t* spk, const float* desc, float* memory,
                                 int B, int L, int E, int Ef, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(enc && memory && (Ef == E || desc), "t2_condition_fwd: bad arguments");
     hipLaunchKernelGGL(condition_fwd_kernel, dim3(ew_grid((long)B * L * Ef)), dim3(256), 0, ST, enc, spk_table, spk, desc, memory, B,
                        L, E, Ef);
@@ -625,28 +640,33 @@ extern "C" int t2_condition_fwd(const float* enc, const float* spk_table, const 
 }
 extern "C" int t2_condition_bwd(const float* dmem, const float* memory, const int32_t* spk, float* denc, float* dspk_table,
                                 float* ddesc, int B, int L, int E, int Ef, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(dmem && memory && denc, "t2_condition_bwd: null");
     hipLaunchKernelGGL(condition_bwd_kernel, dim3(B, t2_cdiv(L, 16)), dim3(256), 0, ST, dmem, memory, spk, dspk_table != nullptr, denc,
                        dspk_table, ddesc, B, L, E, Ef);
     T2_CHECK_LAUNCH(); return T2_OK;
 }
 extern "C" int t2_tanh_bias(float* x, const float* bias, int64_t rows, int C, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(x, "t2_tanh_bias: null");
     hipLaunchKernelGGL(tanh_bias_kernel, dim3(ew_grid(rows * C)), dim3(256), 0, ST, x, bias, (long)rows, C);
     T2_CHECK_LAUNCH(); return T2_OK;
 }
 extern "C" int t2_tanh_bwd(const float* g, const float* y, float* out, int64_t n, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(g && y && out, "t2_tanh_bwd: null");
     hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, g, y, out, (long)n);
     T2_CHECK_LAUNCH(); return T2_OK;
 }
 extern "C" int t2_philox_mask(float* out, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(out && n >= 0 && p >= 0.f && p < 1.f, "t2_philox_mask: bad arguments");
     if (n == 0) return T2_OK;
     hipLaunchKernelGGL(philox_mask_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, ST, out, (long)n, p, seed, stream_id);
     T2_CHECK_LAUNCH(); return T2_OK;
 }
 extern "C" int t2_sumsq(const float* g, int64_t n, double* out, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(g && out, "t2_sumsq: null");
     (void)hipMemsetAsync(out, 0, sizeof(double), ST);
     hipLaunchKernelGGL(sumsq_kernel, dim3(ew_grid(n) > 1024 ? 1024 : ew_grid(n)), dim3(256), 0, ST, g, (long)n, out);
@@ -654,6 +674,7 @@ extern "C" int t2_sumsq(const float* g, int64_t n, double* out, void* stream) {
 }
 extern "C" int t2_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq, float max_norm, float lr,
                             float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(p && g && m && v && step >= 1, "t2_adam_step: bad arguments");
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, p, g, m, v, (long)n, sumsq, max_norm, lr, beta1, beta2, eps,

@@ -148,6 +148,7 @@ __global__ void stop_kernel(const float* proj, long ldp, int M, int B, int t, in
 
 extern "C" int t2_linear_rows(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* mask,
                               int64_t ldmask, int relu, float* out, int64_t ldo, int B, int N, int K, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(x && w && out, "t2_linear_rows: null operand");
     hipStream_t st = (hipStream_t)stream;
     for (int b0 = 0; b0 < B; b0 += 64) {
@@ -164,6 +165,7 @@ extern "C" int t2_linear_rows(const float* x, int64_t ldx, const float* w, int64
 }
 
 extern "C" int t2_decoder_infer(const T2Infer* a, int t0, int t1, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(a != nullptr && t0 >= 0 && t1 >= t0, "t2_decoder_infer: bad arguments");
     T2_REQUIRE(a->B <= 64, "t2_decoder_infer: B <= 64 per call (split larger batches)");
     hipStream_t st = (hipStream_t)stream;

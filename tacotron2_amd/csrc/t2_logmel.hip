@@ -48,6 +48,7 @@ extern "C" int t2_logmel_frames(int64_t n_samples, int hop) { return (int)(1 + n
 
 extern "C" int t2_logmel_fwd(const float* wav, int64_t n, const float* basis, const float* fb, float* padded, float* spec,
                              float* mag, float* out, int n_fft, int hop, int n_mels, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(wav && basis && fb && padded && spec && mag && out, "t2_logmel_fwd: null operand");
     T2_REQUIRE(n > n_fft / 2 && n_fft % 4 == 0 && hop % 4 == 0, "t2_logmel_fwd: need n > n_fft/2 (reflect padding), n_fft,hop % 4 == 0");
     hipStream_t st = (hipStream_t)stream;

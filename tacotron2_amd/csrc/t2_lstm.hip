@@ -450,16 +450,19 @@ int t2_lstm_step_bwd_tab(const T2LstmBwdStep* steps, int n, hipStream_t st, BwdK
 }
 
 extern "C" int t2_lstm_step_fwd(const T2LstmStep* steps, int n, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(steps != nullptr, "t2_lstm_step_fwd: null");
     return launch_fwd(steps, n, (hipStream_t)stream);
 }
 
 extern "C" int t2_lstm_step_bwd(const T2LstmBwdStep* steps, int n, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(steps != nullptr, "t2_lstm_step_bwd: null");
     return launch_bwd(steps, n, (hipStream_t)stream);
 }
 
 extern "C" int t2_lstm_seq_fwd(const T2LstmStep* base, const T2LstmStride* inc, int n, int S, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(base && inc && (n == 1 || n == 2) && S >= 0, "t2_lstm_seq_fwd: bad arguments");
     T2LstmStep cur[2];
     for (int i = 0; i < n; ++i) cur[i] = base[i];
@@ -473,6 +476,7 @@ extern "C" int t2_lstm_seq_fwd(const T2LstmStep* base, const T2LstmStride* inc, 
 // Planned variants: the operand blocks of all S steps are written once into a table (host side), the caller uploads it,
 // and every launch then carries a 16-byte argument block (table pointer + step index).
 extern "C" int64_t t2_lstm_seq_fwd_plan(const T2LstmStep* base, const T2LstmStride* inc, int n, int S, void* host_tab, int64_t bytes) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     const int64_t need = (int64_t)S * sizeof(LstmK2);
     if (!host_tab) return need;
     if (!base || !inc || (n != 1 && n != 2) || S < 0 || bytes < need) return -1;
@@ -487,6 +491,7 @@ extern "C" int64_t t2_lstm_seq_fwd_plan(const T2LstmStep* base, const T2LstmStri
 }
 
 extern "C" int t2_lstm_seq_fwd_run(const void* dev_tab, const T2LstmStep* base, int n, int s_begin, int s_end, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(dev_tab && base && (n == 1 || n == 2) && s_begin >= 0 && s_end >= s_begin, "t2_lstm_seq_fwd_run: bad arguments");
     for (int s = s_begin; s < s_end; ++s) T2_TRY(launch_fwd(base, n, (hipStream_t)stream, nullptr, (const LstmK2*)dev_tab, s));
     return T2_OK;
@@ -494,6 +499,7 @@ extern "C" int t2_lstm_seq_fwd_run(const void* dev_tab, const T2LstmStep* base, 
 
 extern "C" int64_t t2_lstm_seq_bwd_plan(const T2LstmBwdStep* base, const T2LstmBwdStride* inc, int n, int S, void* host_tab,
                                         int64_t bytes) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     const int64_t need = (int64_t)S * sizeof(BwdK2);
     if (!host_tab) return need;
     if (!base || !inc || (n != 1 && n != 2) || S < 0 || bytes < need) return -1;
@@ -508,12 +514,14 @@ extern "C" int64_t t2_lstm_seq_bwd_plan(const T2LstmBwdStep* base, const T2LstmB
 }
 
 extern "C" int t2_lstm_seq_bwd_run(const void* dev_tab, const T2LstmBwdStep* base, int n, int s_begin, int s_end, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(dev_tab && base && (n == 1 || n == 2) && s_begin >= 0 && s_end >= s_begin, "t2_lstm_seq_bwd_run: bad arguments");
     for (int s = s_begin; s < s_end; ++s) T2_TRY(launch_bwd(base, n, (hipStream_t)stream, nullptr, (const BwdK2*)dev_tab, s));
     return T2_OK;
 }
 
 extern "C" int t2_lstm_seq_bwd(const T2LstmBwdStep* base, const T2LstmBwdStride* inc, int n, int S, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(base && inc && (n == 1 || n == 2) && S >= 0, "t2_lstm_seq_bwd: bad arguments");
     T2LstmBwdStep cur[2];
     for (int i = 0; i < n; ++i) cur[i] = base[i];
@@ -525,6 +533,7 @@ extern "C" int t2_lstm_seq_bwd(const T2LstmBwdStep* base, const T2LstmBwdStride*
 }
 
 extern "C" int t2_lstm_pack_fwd(const T2Seg* segs, int nseg, int H, float* out, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(segs && out && nseg >= 1 && nseg <= 3 && H % 4 == 0, "t2_lstm_pack_fwd: bad arguments");
     PackSegs s; s.nseg = nseg;
     int NT = 0;
@@ -541,6 +550,7 @@ extern "C" int t2_lstm_pack_fwd(const T2Seg* segs, int nseg, int H, float* out, 
 
 extern "C" int t2_lstm_pack_bwd(const float* W, int64_t ldw, int N4, const float* W2, int64_t ldw2, int N2, int ncols,
                                 float* out, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(W && out && N4 % 16 == 0 && (!W2 || N2 % 16 == 0) && ncols >= 1, "t2_lstm_pack_bwd: bad arguments");
     const long total = (long)t2_cdiv(ncols, 16) * ((((N4 >> 4) + (W2 ? (N2 >> 4) : 0)) + 31) & ~31) * 64;
     hipLaunchKernelGGL(lstm_pack_bwd_kernel, dim3(t2_cdiv(total, 256) > 2048 ? 2048 : t2_cdiv(total, 256)), dim3(256), 0,
@@ -551,6 +561,7 @@ extern "C" int t2_lstm_pack_bwd(const float* W, int64_t ldw, int N4, const float
 
 // Diagnostic: enable/disable the clock stamps of the forward fast kernel and read the last 8 stamped words.
 extern "C" int t2_debug_clock(int enable, uint64_t* out8) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_t2_clk_enable), &enable, sizeof(int)) != hipSuccess) return T2_ERR_LAUNCH;
     if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_t2_clk), 8 * sizeof(unsigned long long)) != hipSuccess) return T2_ERR_LAUNCH;
     return T2_OK;
