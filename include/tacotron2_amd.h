@@ -59,6 +59,8 @@ typedef struct {
     int accumulate;
     int splitk;
     int batch; int64_t sA, sB, sC;
+    int share_cu;                    /* hint: 1 = keep ONE workgroup per CU (extra dynamic LDS), leaving LDS for the small kernels
+                                        of a concurrent stream; two 73 KB workgroups per CU otherwise lock them out */
 } T2Gemm;
 int t2_gemm(const T2Gemm* g, void* stream);
 

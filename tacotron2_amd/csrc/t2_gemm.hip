@@ -238,9 +238,11 @@ extern "C" int t2_gemm(const T2Gemm* g, void* stream) {
     p.ntm = t2_cdiv(g->M, BM); p.ntn = t2_cdiv(g->N, BN);
     dim3 grid(p.ntm * p.ntn, 1, batch * splitk), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (g->a_kmajor && g->b_kmajor) hipLaunchKernelGGL((gemm_f32_mfma<true, true>), grid, block, 0, s, p);
-    else if (g->a_kmajor && !g->b_kmajor) hipLaunchKernelGGL((gemm_f32_mfma<true, false>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm_f32_mfma<false, false>), grid, block, 0, s, p);
+    // share_cu: 24 KB of (unused) dynamic LDS on top of the 73.7 KB static tile buffers -> a second workgroup no longer fits
+    const size_t pad = g->share_cu ? 24 * 1024 : 0;
+    if (g->a_kmajor && g->b_kmajor) hipLaunchKernelGGL((gemm_f32_mfma<true, true>), grid, block, pad, s, p);
+    else if (g->a_kmajor && !g->b_kmajor) hipLaunchKernelGGL((gemm_f32_mfma<true, false>), grid, block, pad, s, p);
+    else hipLaunchKernelGGL((gemm_f32_mfma<false, false>), grid, block, pad, s, p);
     T2_CHECK_LAUNCH();
     return T2_OK;
 }

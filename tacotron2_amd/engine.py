@@ -28,12 +28,15 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+SHARE_CU = [0]     # set to [1] while enqueuing GEMMs that run next to a latency-bound chain on another stream
+
+
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_k=1, b_k=1, alpha=1.0, bias=None, bias2=None, mulmask=None, ldmask=0,
          relu=0, accumulate=0, splitk=1, batch=1, sA=0, sB=0, sC=0):
     """C-ABI t2_gemm on raw pointers (ints) or tensors."""
     g = make("T2Gemm", A=A, B=B, C=C, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, a_kmajor=a_k, b_kmajor=b_k,
              alpha=alpha, bias=bias, bias2=bias2, mulmask=mulmask, ldmask=ldmask, relu=relu, accumulate=accumulate,
-             splitk=splitk, batch=batch, sA=sA, sB=sB, sC=sC)
+             splitk=splitk, batch=batch, sA=sA, sB=sB, sC=sC, share_cu=SHARE_CU[0])
     call("t2_gemm", g, _stream())
 
 
@@ -81,6 +84,9 @@ class Engine:
         self.co_schedule = _os.environ.get("T2_CO_SCHEDULE", "1") != "0"
         self.co_schedule_bwd = _os.environ.get("T2_CO_SCHEDULE_BWD", "0") != "0"
         self.use_plans = _os.environ.get("T2_USE_PLANS", "0") != "0"
+        self.fwd_lag = int(_os.environ.get("T2_FWD_LAG", "1"))     # 1: chunk GEMMs on the main stream between chunks; 2: on the side stream
+        self.share_cu = int(_os.environ.get("T2_SHARE_CU", "1"))   # side-stream GEMMs next to the chains at ONE workgroup per CU: two
+                                                                   # 73 KB-LDS workgroups per CU lock the attention kernels out (84.3 -> 83.2 ms)
         self.co_host = int(_os.environ.get("T2_CO_HOST", "1"))   # where the co-scheduled decoder cell rides: 1 = energies launch (measured best:
                                                                  # 26.85 ms vs 27.2 ms in the context launch, 29.2 ms split over both)
         self.profile = False          # when True, mark() records HIP events at segment boundaries
@@ -431,17 +437,29 @@ class Engine:
                 drain_from = 0
             seq.t_begin, seq.t_end = 0, 0
             seq.plan = self.plan_upload("fwd.attn", "t2_attn_seq_fwd_plan", seq)
+        lag = self.fwd_lag if (co and not plans) else 1      # 2: the chunk GEMMs run on the side stream, one chunk behind
+        gemm_done = []
         for i, (c0, c1) in enumerate(chunks):
             seq.t_begin, seq.t_end = c0, c1
             if not plans:
-                if co and i >= 1:
-                    stp, inc = dec_chunk(*chunks[i - 1])
+                if co and i >= lag:
+                    if lag > 1:
+                        main.wait_event(gemm_done[i - lag])
+                    stp, inc = dec_chunk(*chunks[i - lag])
                     seq.co_step, seq.co_inc = _C.pointer(stp), _C.pointer(inc)
-                    seq.co_steps = chunks[i - 1][1] - chunks[i - 1][0]
+                    seq.co_steps = chunks[i - lag][1] - chunks[i - lag][0]
                 else:
                     seq.co_step, seq.co_inc, seq.co_steps = None, None, 0
             call("t2_attn_seq_fwd", seq, st)
-            if co:
+            if co and lag > 1:
+                ev = main.record_event()
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    SHARE_CU[0] = self.share_cu
+                    pre_dec_gemm(c0, c1)
+                    SHARE_CU[0] = 0
+                    gemm_done.append(side.record_event())
+            elif co:
                 pre_dec_gemm(c0, c1)
             else:
                 ev = main.record_event()
@@ -453,7 +471,7 @@ class Engine:
         self.mark("fwd.dec.attn_chain")
         main.wait_stream(side)
         if co:                                  # drain: the decoder-LSTM frames that found no attention frame to ride in
-            d0 = drain_from if plans else chunks[-1][0]
+            d0 = drain_from if plans else chunks[max(0, len(chunks) - lag)][0]
             stp, inc = dec_chunk(d0, T)
             call("t2_lstm_seq_fwd", stp, inc, 1, T - d0, st)
         self.mark("fwd.dec.lstm_chain_tail")
@@ -621,13 +639,17 @@ class Engine:
             return s, inc
 
         def dxdec_gemm(hi, lo):
+            SHARE_CU[0] = self.share_cu
             gemm(_ptr(dgd, lo * B * 4 * D), P["decoder.lstm.weight_ih"], _ptr(dxdec, lo * B * ldx), (hi - lo) * B, ldx, 4 * D,
                  4 * D, ldx, ldx, a_k=1, b_k=0)
+            SHARE_CU[0] = 0
 
         def dec_wgrads():   # decoder-LSTM weight gradients, on the side stream next to the attention chain's tail
             with torch.cuda.stream(side):
+                SHARE_CU[0] = self.share_cu
                 self._wgrad(dgd, 4 * D, _ptr(xdec, B * ldx), ldx, G["decoder.lstm.weight_ih"], ldx, 4 * D, ldx, R)
                 self._wgrad(dgd, 4 * D, xproj, ldp, G["decoder.lstm.weight_hh"], D, 4 * D, D, R)
+                SHARE_CU[0] = 0
                 db = self.buf("db_dec", 4 * D, zero=True)                      # both biases see the same gate gradients
                 call("t2_colsum", dgd, 4 * D, R, 4 * D, db, side.cuda_stream)
                 G["decoder.lstm.bias_ih"].add_(db); G["decoder.lstm.bias_hh"].add_(db)

@@ -224,7 +224,8 @@ def test_train_step_midsize_matches_oracle():
 
 @pytest.mark.parametrize("co_fwd,co_bwd,chunk,plans,co_host", [(True, True, 8, False, 1), (False, False, 8, True, 0),
                                                                 (True, False, 64, False, 0), (False, True, 5, False, 0),
-                                                                (True, False, 8, True, 0), (True, False, 8, False, 2)])
+                                                                (True, False, 8, True, 0), (True, False, 8, False, 2),
+                                                                (True, False, 6, False, 12)])
 def test_pipeline_variants_match_oracle(co_fwd, co_bwd, chunk, plans, co_host):
     """The frame loop's schedule (chunk size, decoder-LSTM steps co-scheduled inside attention launches or on the side
     stream) must not change results: every variant against the CPU oracle on the same inputs."""
@@ -234,7 +235,8 @@ def test_pipeline_variants_match_oracle(co_fwd, co_bwd, chunk, plans, co_host):
     P = R.init_params(d, seed=11)
     eng, ps = build_engine(d, P, dev)
     eng.co_schedule, eng.co_schedule_bwd, eng.chunk, eng.chunk_bwd, eng.use_plans = co_fwd, co_bwd, chunk, chunk, plans
-    eng.co_host = co_host
+    eng.co_host = co_host % 10
+    eng.fwd_lag = 2 if co_host >= 10 else 1      # co_host 12: energies/context split hosting + chunk GEMMs on the side stream
     ci, lens, mel, tl, gate, masks = random_case(d, 5, 17, 23, 77, dev)
     Pc = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not R.is_buffer(k)) else v.clone()) for k, v in P.items()}
     o = R.tacotron2_fwd(Pc, d, ci, lens, True, mel, tl, training=True, masks=masks, new_stats={})
