@@ -84,6 +84,7 @@ class Engine:
         self.co_schedule = _os.environ.get("T2_CO_SCHEDULE", "1") != "0"
         self.co_schedule_bwd = _os.environ.get("T2_CO_SCHEDULE_BWD", "0") != "0"
         self.use_plans = _os.environ.get("T2_USE_PLANS", "0") != "0"
+        self.bwd_lag = int(_os.environ.get("T2_BWD_LAG", "1"))     # co-scheduled backward only: 1 = chunk GEMMs on the main stream, 2 = side stream
         self.fwd_lag = int(_os.environ.get("T2_FWD_LAG", "1"))     # 1: chunk GEMMs on the main stream between chunks; 2: on the side stream
         self.share_cu = int(_os.environ.get("T2_SHARE_CU", "1"))   # side-stream GEMMs next to the chains at ONE workgroup per CU: two
                                                                    # 73 KB-LDS workgroups per CU lock the attention kernels out (84.3 -> 83.2 ms)
@@ -656,26 +657,47 @@ class Engine:
 
         chunks = [(hi, max(0, hi - CH)) for hi in range(T, 0, -CH)]
         if self.co_schedule_bwd:
-            # the decoder-LSTM BPTT of chunk k+1 is co-scheduled inside the attention chain of chunk k (its step rides in
-            # the attention-ds launch, T2AttnSeqBwd.co_step); the GEMM that turns a chunk's decoder gate gradients into
-            # d[att_h, ctx] runs between chunks
+            # software pipeline with lag `bwd_lag`: the decoder-LSTM BPTT of chunk k+lag is co-scheduled inside the attention
+            # chain of chunk k (its step rides in the attention-ds launch, T2AttnSeqBwd.co_step); the GEMM that turns a
+            # chunk's decoder gate gradients into d[att_h, ctx] runs between chunks on the main stream (lag 1) or, one
+            # chunk ahead, on the side stream (lag 2)
             import ctypes as _C
-            s, inc = dec_bwd_chunk(*chunks[0])
-            call("t2_lstm_seq_bwd", s, inc, 1, chunks[0][0] - chunks[0][1], st)
-            dxdec_gemm(*chunks[0])
+            n, lag = len(chunks), self.bwd_lag
+            gemm_done = [None] * n
+
+            def chunk_gemm(i):
+                if lag == 1:
+                    dxdec_gemm(*chunks[i])
+                else:
+                    ev = main.record_event()
+                    with torch.cuda.stream(side):
+                        side.wait_event(ev)
+                        dxdec_gemm(*chunks[i])
+                        gemm_done[i] = side.record_event()
+
+            for i in range(min(lag, n)):                   # prologue: the first `lag` decoder chunks run alone
+                s, inc = dec_bwd_chunk(*chunks[i])
+                call("t2_lstm_seq_bwd", s, inc, 1, chunks[i][0] - chunks[i][1], st)
+                if i == 0:
+                    dxdec_gemm(*chunks[0])
             for k, (hi, lo) in enumerate(chunks):
-                nxt = chunks[k + 1] if k + 1 < len(chunks) else None
+                if lag > 1 and k + 1 < n:
+                    chunk_gemm(k + 1)                      # decoder chunk k+1 is complete on the main stream at this point
                 sb.t_hi, sb.t_lo = hi, lo
-                if nxt is not None:
-                    s, inc = dec_bwd_chunk(*nxt)
-                    sb.co_step, sb.co_inc, sb.co_steps = _C.pointer(s), _C.pointer(inc), nxt[0] - nxt[1]
+                if k + lag < n:
+                    s, inc = dec_bwd_chunk(*chunks[k + lag])
+                    sb.co_step, sb.co_inc = _C.pointer(s), _C.pointer(inc)
+                    sb.co_steps = chunks[k + lag][0] - chunks[k + lag][1]
                 else:
                     sb.co_step, sb.co_inc, sb.co_steps = None, None, 0
-                    side.wait_stream(main)
-                    dec_wgrads()
+                    if k + lag == n or (n <= lag and k == 0):   # all decoder gate gradients are final
+                        side.wait_stream(main)
+                        dec_wgrads()
+                if gemm_done[k] is not None:
+                    main.wait_event(gemm_done[k])
                 call("t2_attn_seq_bwd", sb, st)
-                if nxt is not None:
-                    dxdec_gemm(*nxt)
+                if lag == 1 and k + 1 < n:
+                    chunk_gemm(k + 1)
         else:
             for hi, lo in chunks:
                 with torch.cuda.stream(side):
