@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void lstm_step_fwd_fast_kernel(LstmK2 pp) {
     __shared__ float red[4 * MT * 256];
     const bool stamp = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && g_t2_clk_enable;
     if (stamp) { g_t2_clk[0] = __builtin_amdgcn_s_memtime(); g_t2_clk[1] = __builtin_amdgcn_s_memrealtime(); }
-    t2_lstm_fwd_fast_body<MT, U>(pp.s[blockIdx.y], blockIdx.x, red);
+    t2_lstm_fwd_fast_body<MT, U>(pp.s[blockIdx.y], blockIdx.x, red, stamp ? g_t2_clk : nullptr);
     if (stamp) { g_t2_clk[6] = __builtin_amdgcn_s_memtime(); g_t2_clk[7] = __builtin_amdgcn_s_memrealtime(); }
 }
 
@@ -201,7 +201,11 @@ int launch_fwd(const T2LstmStep* steps, int n, hipStream_t st, LstmK2* fill = nu
         } else if (fast) {
             // 8 chunks per group (24 x 1 KB loads per wave per group, two groups in flight) when the padded chunk count allows
             const int ntpad = ((steps[0].seg[0].K >> 4) + 15) & ~15;
-            const bool u8 = (ntpad % 32 == 0) && (n == 1 || ((((steps[1].seg[0].K >> 4) + 15) & ~15) % 32 == 0));
+            // Pipeline depth: measured in one session on the training step (tools/ab_session.sh), 4 chunks per group beat 8
+            // (82.05 against 82.37 ms), and every deeper variant (two groups requested ahead, all loads of the step issued
+            // at entry) was slower still: past ~24 KB per wave the first operands only arrive later.  T2_CELL_U=8 restores 8.
+            static const int force_u = [] { const char* e = getenv("T2_CELL_U"); return e ? atoi(e) : 4; }();
+            const bool u8 = force_u == 8 && (ntpad % 32 == 0) && (n == 1 || ((((steps[1].seg[0].K >> 4) + 15) & ~15) % 32 == 0));
             if (bn <= 16) { if (u8) hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<1, 8>), grid, block, 0, st, kk);
                             else hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<1, 4>), grid, block, 0, st, kk); }
             else if (bn <= 32) { if (u8) hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<2, 8>), grid, block, 0, st, kk);
@@ -337,13 +341,13 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(BwdK2 pp) {
 // zero-padded transposed weight stream; same branch-free double-buffered structure as the forward fast path.
 __global__ __launch_bounds__(256, 1) void lstm_step_bwd_fast_kernel(BwdK2 pp) {
     __shared__ float red[4 * 256];
-    t2_lstm_bwd_fast_body<4, 8>(pp.s[blockIdx.z], blockIdx.x, blockIdx.y, red);
+    t2_lstm_bwd_fast_body<4, 4>(pp.s[blockIdx.z], blockIdx.x, blockIdx.y, red);
 }
 
 __global__ __launch_bounds__(256, 1) void lstm_step_bwd_fast_tab_kernel(const T2_CONST_AS BwdK2* tab, int idx) {
     __shared__ float red[4 * 256];
     const BwdK p = t2_tab_entry(&tab[idx].s[blockIdx.z]);
-    t2_lstm_bwd_fast_body<4, 8>(p, blockIdx.x, blockIdx.y, red);
+    t2_lstm_bwd_fast_body<4, 4>(p, blockIdx.x, blockIdx.y, red);
 }
 
 int launch_bwd(const T2LstmBwdStep* steps, int n, hipStream_t st, BwdK2* fill = nullptr, const BwdK2* tab = nullptr, int idx = 0) {

@@ -68,7 +68,8 @@ inline void t2_lstm_to_k(const T2LstmStep& s, LstmK& k, int b0, int bn) {
 // this size, and two cells in one launch take the sum of their times (same per-CU miss queue and MFMA pipe) - but a
 // cell step next to a latency-bound attention kernel uses otherwise idle pipes (tools/ubench_cell.hip).
 template <int MT, int U>
-__device__ __forceinline__ void t2_lstm_fwd_fast_body(const LstmK& p, const int bx, float* red /* [4*MT*256] */) {
+__device__ __forceinline__ void t2_lstm_fwd_fast_body(const LstmK& p, const int bx, float* red /* [4*MT*256] */,
+                                                      unsigned long long* clk = nullptr /* diagnostic stamps [2..4] */) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
@@ -94,21 +95,24 @@ __device__ __forceinline__ void t2_lstm_fwd_fast_body(const LstmK& p, const int 
     float e_pre[4] = {0.f, 0.f, 0.f, 0.f}, e_b1[4] = {0.f, 0.f, 0.f, 0.f}, e_b2[4] = {0.f, 0.f, 0.f, 0.f};
     float e_cp = 0.f, e_drop = 1.f;
     int e_len = 0x7fffffff;
-    if (p.pre) {
+    auto load_epilogue_operands = [&]() {
+        if (p.pre) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) e_pre[g] = p.pre[ebc * p.ldpre + g * H + eu];
-    }
-    if (p.bias1) {
+            for (int g = 0; g < 4; ++g) e_pre[g] = p.pre[ebc * p.ldpre + g * H + eu];
+        }
+        if (p.bias1) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) e_b1[g] = p.bias1[g * H + eu];
-    }
-    if (p.bias2) {
+            for (int g = 0; g < 4; ++g) e_b1[g] = p.bias1[g * H + eu];
+        }
+        if (p.bias2) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) e_b2[g] = p.bias2[g * H + eu];
-    }
-    if (p.c_prev) e_cp = p.c_prev[ebc * p.ldc_prev + eu];
-    if (p.drop) e_drop = p.drop[ebc * p.lddrop + eu];
-    if (p.len) e_len = p.len[ebc];
+            for (int g = 0; g < 4; ++g) e_b2[g] = p.bias2[g * H + eu];
+        }
+        if (p.c_prev) e_cp = p.c_prev[ebc * p.ldc_prev + eu];
+        if (p.drop) e_drop = p.drop[ebc * p.lddrop + eu];
+        if (p.len) e_len = p.len[ebc];
+    };
+    load_epilogue_operands();
     auto load_chunk = [&](int g, int j, f32x4& bw, f32x4 (&ax)[MT]) {
         const int c = 4 * U * g + 4 * j + w;
         const int cx = c < NT ? c : NT - 1;     // padding chunks: any finite activations x the zero weight chunk
@@ -144,6 +148,7 @@ __device__ __forceinline__ void t2_lstm_fwd_fast_body(const LstmK& p, const int 
         int g = 0;
         for (; g + 2 < G; g += 2) {
             pipe_group(g + 1, bwB, axB, bwA, axA);
+            if (clk && g == 0) clk[2] = __builtin_amdgcn_s_memtime();     // group 0 consumed, group 1 requested
             pipe_group(g + 2, bwA, axA, bwB, axB);
         }
         if (g + 1 < G) {
@@ -155,11 +160,13 @@ __device__ __forceinline__ void t2_lstm_fwd_fast_body(const LstmK& p, const int 
             for (int j = 0; j < U; ++j) mma_chunk(bwA[j], axA[j]);
         }
     }
+    if (clk) clk[3] = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int g = 0; g < 4; ++g) red[((w * MT + m) * 16 + (q * 4 + g)) * 16 + r] = acc[m][g];
     __syncthreads();
+    if (clk) clk[4] = __builtin_amdgcn_s_memtime();
     if (tid < MT * 64) {
         const int b = eb, uu = euu;
         if (b < p.B) {
@@ -170,8 +177,11 @@ __device__ __forceinline__ void t2_lstm_fwd_fast_body(const LstmK& p, const int 
                 float s = 0.f;
 #pragma unroll
                 for (int ww = 0; ww < 4; ++ww) s += red[((ww * MT + (b >> 4)) * 16 + (b & 15)) * 16 + g * 4 + uu];
-                gsum[g] = s + e_pre[g] + e_b1[g] + e_b2[g];
+                gsum[g] = s + (p.pre ? e_pre[g] : 0.f) + (p.bias1 ? e_b1[g] : 0.f) + (p.bias2 ? e_b2[g] : 0.f);
             }
+            if (!p.c_prev) e_cp = 0.f;
+            if (!p.drop) e_drop = 1.f;
+            if (!p.len) e_len = 0x7fffffff;
             const bool active = p.t < e_len;
             float gi = t2_sigmoid(gsum[0]), gf = t2_sigmoid(gsum[1]), gg = t2_tanh(gsum[2]), go = t2_sigmoid(gsum[3]);
             float cn = gf * e_cp + gi * gg;

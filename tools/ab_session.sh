@@ -1,6 +1,10 @@
+# In-session A/B of two settings of one environment knob (box-to-box spread is +-2 %, so variants are compared on one box).
+# usage: bash tools/ab_session.sh KNOB VALUE_A VALUE_B [pytest-args...]
 set -e
+KNOB=$1; A=$2; B=$3; shift 3
 mkdir -p gpurun_out
-cp build/ab/libB.so tacotron2_amd/libtacotron2_amd.so
-timeout -k 10 300 python -m pytest tests/test_gpu_model.py -m gpu -x -q > gpurun_out/t18.log 2>&1
-timeout -k 10 120 python tools/stamps_bwd.py > gpurun_out/stamps18.log 2>&1
-for v in A B A B; do cp build/ab/lib$v.so tacotron2_amd/libtacotron2_amd.so; echo "variant $v" >> gpurun_out/ab18.log; timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-decode >> gpurun_out/ab18.log 2>&1; done
+if [ $# -gt 0 ]; then timeout -k 10 500 python -m pytest "$@" -m gpu -x -q > gpurun_out/ab_tests.log 2>&1; fi
+for v in $A $B $A $B; do
+  echo "variant $KNOB=$v" >> gpurun_out/ab.log
+  env $KNOB=$v timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-decode >> gpurun_out/ab.log 2>&1
+done

@@ -57,7 +57,12 @@ def run(use_th, use_gates, stamps=False):
 for use_th, use_gates in [(True, True), (False, True), (True, False), (False, False)]:
     print(f"th stash {use_th}, gates stash {use_gates}: {run(use_th, use_gates):.2f} us per frame (cell + energies + context)", flush=True)
 
+import ctypes
+out8 = (ctypes.c_uint64 * 8)()
+_lib.lib().t2_debug_clock(1, out8)
 run(True, True, stamps=True)
+_lib.lib().t2_debug_clock(0, out8)
+cc = list(out8)
 c = clk.cpu().tolist()
 GHZ = 2.38   # shader clock during the loop (s_memtime ticks / s_memrealtime), DESIGN.md section 4.1
 e = [(c[i] - c[0]) / GHZ / 1e3 for i in range(6)]
@@ -66,3 +71,8 @@ print("energies  kernel, workgroup (0,0), us from entry: staging done %.2f | con
       % (e[1], e[4], e[5], e[2], e[3]))
 print("context   kernel, workgroup (0,0), us from entry: e_part summed %.2f | softmax sums %.2f | weights written %.2f | "
       "context partial %.2f | exit %.2f" % (k[1], k[2], k[3], k[4], k[5]))
+
+# attention-cell step kernel of the last frame (stamps of workgroup 0; same s_memtime counter as the attention kernels' stamps)
+print("cell step kernel, us from entry: group 0 consumed %.2f | main loop done %.2f | reduced %.2f | exit %.2f ; "
+      "cell exit -> energies entry %.2f us ; energies exit -> context entry %.2f us"
+      % tuple([(cc[i] - cc[0]) / GHZ / 1e3 for i in (2, 3, 4, 6)] + [(c[0] - cc[6]) / GHZ / 1e3, (c[8] - c[3]) / GHZ / 1e3]))
