@@ -123,6 +123,8 @@ def case_tf_train(name, seed, extra, lens, tlens):
         kw["speaker_id"] = torch.randint(0, extra["num_speakers"], (len(lens),), generator=g, dtype=torch.int32)
     if extra.get("description_embeddings"):
         kw["description_embeddings"] = torch.randn(len(lens), extra["description_embeddings_dim"], generator=g)
+    if extra.get("controls"):
+        kw["controls"] = torch.randn(len(lens), extra["controls_dim"], generator=g)
     _captured.clear()
     F.dropout = _recording_dropout
     torch.nn.functional.dropout = _recording_dropout
@@ -155,8 +157,12 @@ def case_tf_train(name, seed, extra, lens, tlens):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
 
 
-def case_infer():
-    m = build(0.5, 31).eval()
+def case_infer(name="infer", seed=31, extra=None):
+    extra = extra or {}
+    m = build(0.5, seed, **extra).eval()
+    kw = {}
+    if extra.get("controls"):
+        kw["controls"] = torch.randn(3, extra["controls_dim"], generator=torch.Generator().manual_seed(seed + 5))
     # nudge the stop projection so samples stop at different frames (random weights never stop)
     with torch.no_grad():
         m.decoder.gate.bias.fill_(0.05)
@@ -167,7 +173,7 @@ def case_infer():
     torch.nn.functional.dropout = _recording_dropout
     try:
         with torch.no_grad():
-            mels, post, gates, al = m(ci, cl, False, max_len_override=40)
+            mels, post, gates, al = m(ci, cl, False, max_len_override=40, **kw)
     finally:
         F.dropout = _orig_dropout
         torch.nn.functional.dropout = _orig_dropout
@@ -179,7 +185,9 @@ def case_infer():
     d.update(chars_idx=ci.numpy(), chars_len=cl.numpy(), **{"m.prenet_drop": pm.numpy()},
              o_mels=mels.numpy(), o_post=post.numpy(), o_gates=gates.numpy(), o_align=al.numpy(),
              max_len=np.array(40))
-    np.savez_compressed(os.path.join(OUT, "infer.npz"), **d)
+    for k, v in kw.items():
+        d[k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
 
 
 if __name__ == "__main__":
@@ -190,5 +198,8 @@ if __name__ == "__main__":
     case_tf_train("tf_train_desc", 61, dict(speaker_tokens=True, num_speakers=7, description_embeddings=True,
                                             description_embeddings_dim=24), [12, 16], [13, 19])
     case_infer()
+    # prosody-controls extension (model/decoder.py:40-48,97-109; model/tacotron2.py:279-286)
+    case_tf_train("tf_train_ctrl", 71, dict(controls=True, controls_dim=5), [14, 9, 6], [17, 11, 8])
+    case_infer("infer_ctrl", 86, dict(controls=True, controls_dim=5))   # stops per sample at different frames; runs to the cap
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

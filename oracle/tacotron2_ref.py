@@ -39,7 +39,7 @@ def default_dims(**over) -> dict:
         num_chars=39, encoded_dim=512, encoder_kernel_size=5, num_mels=80, prenet_dim=256,
         att_rnn_dim=1024, att_dim=128, rnn_hidden_dim=1024, postnet_dim=512, dropout=0.5,
         speaker_tokens=False, num_speakers=1, description_embeddings=False,
-        description_embeddings_dim=0, loc_filters=32, loc_kernel=31,
+        description_embeddings_dim=0, loc_filters=32, loc_kernel=31, controls=False, controls_dim=0,
     )
     d.update(over)
     return d
@@ -83,11 +83,12 @@ def param_shapes(d: dict) -> Dict[str, tuple]:
     s["decoder.attention.v.weight"] = (1, Ad)
     s["decoder.attention.location_conv.weight"] = (d["loc_filters"], 2, d["loc_kernel"])
     s["decoder.attention.location_dense.weight"] = (Ad, d["loc_filters"])
-    s["decoder.lstm.weight_ih"] = (4 * D, A + Ef)
+    C = d.get("controls_dim", 0) if d.get("controls") else 0      # model/tacotron2.py:119 extra_decoder_in_dim
+    s["decoder.lstm.weight_ih"] = (4 * D, A + Ef + C)
     s["decoder.lstm.weight_hh"] = (4 * D, D)
     s["decoder.lstm.bias_ih"] = (4 * D,)
     s["decoder.lstm.bias_hh"] = (4 * D,)
-    s["decoder.mel_out.weight"] = (M, D + Ef)
+    s["decoder.mel_out.weight"] = (M, D + Ef + C)
     s["decoder.mel_out.bias"] = (M,)
     s["decoder.gate.weight"] = (1, D + Ef)
     s["decoder.gate.bias"] = (1,)
@@ -283,8 +284,10 @@ def attention_fwd(P, att_h: Tensor, memory: Tensor, processed_memory: Tensor, w_
 
 
 def decoder_step(P, prenet_out, att_h, att_c, ctx, w, w_cum, dec_h, dec_c, memory, processed_memory, mask,
-                 att_drop: Optional[Tensor], dec_drop: Optional[Tensor]):
-    """model/decoder.py:68-119.  Returns new states; the dropped h is the carried h (Appendix C.1)."""
+                 att_drop: Optional[Tensor], dec_drop: Optional[Tensor], extra_decoder_in: Optional[Tensor] = None):
+    """model/decoder.py:68-119.  Returns new states; the dropped h is the carried h (Appendix C.1).
+    extra_decoder_in (the controls vector, model/tacotron2.py:279-286) is appended to the decoder-LSTM input and to the
+    mel projection input, not to the gate projection (model/decoder.py:94-109)."""
     g = torch.cat([prenet_out, ctx], -1) @ P["decoder.att_rnn.weight_ih"].T + P["decoder.att_rnn.bias_ih"] \
         + att_h @ P["decoder.att_rnn.weight_hh"].T + P["decoder.att_rnn.bias_hh"]
     att_h, att_c = lstm_cell(g, att_c)
@@ -292,14 +295,15 @@ def decoder_step(P, prenet_out, att_h, att_c, ctx, w, w_cum, dec_h, dec_c, memor
         att_h = att_h * att_drop
     ctx, w = attention_fwd(P, att_h, memory, processed_memory, torch.stack([w, w_cum], 1), mask)
     w_cum = w_cum + w
-    g = torch.cat([att_h, ctx], -1) @ P["decoder.lstm.weight_ih"].T + P["decoder.lstm.bias_ih"] \
+    xe = [extra_decoder_in] if extra_decoder_in is not None else []
+    g = torch.cat([att_h, ctx] + xe, -1) @ P["decoder.lstm.weight_ih"].T + P["decoder.lstm.bias_ih"] \
         + dec_h @ P["decoder.lstm.weight_hh"].T + P["decoder.lstm.bias_hh"]
     dec_h, dec_c = lstm_cell(g, dec_c)
     if dec_drop is not None:
         dec_h = dec_h * dec_drop
     hc = torch.cat([dec_h, ctx], -1)
     gate = hc @ P["decoder.gate.weight"].T + P["decoder.gate.bias"]
-    mel = hc @ P["decoder.mel_out.weight"].T + P["decoder.mel_out.bias"]
+    mel = torch.cat([hc] + xe, -1) @ P["decoder.mel_out.weight"].T + P["decoder.mel_out.bias"]
     return mel, gate, att_h, att_c, ctx, w, w_cum, dec_h, dec_c
 
 
@@ -326,12 +330,13 @@ def tacotron2_fwd(P, d: dict, chars_idx: Tensor, chars_len: Tensor, teacher_forc
                   mel: Optional[Tensor] = None, mel_len: Optional[Tensor] = None, speaker_id=None,
                   description_embeddings=None, max_len_override: Optional[int] = None,
                   training: bool = True, masks: Optional[dict] = None, new_stats: Optional[dict] = None,
-                  trace: Optional[dict] = None):
+                  trace: Optional[dict] = None, controls: Optional[Tensor] = None):
     """model/tacotron2.py:155-347.  ``masks`` keys (all optional):
        enc_drop [3x(B,L,E)], prenet_drop (TF: [2x(B,T+1,P)]; inference: list per step of [2x(B,P)],
        entry 0 is for the initial zero frame), att_drop (T,B,A), dec_drop (T,B,D), post_drop [5x(B,T,C)].
     Returns (mels, mels_post, gates, alignments) as the reference does."""
     masks = masks or {}
+    assert bool(d.get("controls")) == (controls is not None), "controls tensor and the controls flag must agree (model/tacotron2.py:185-191)"
     dt = P["prenet.0.weight"].dtype
     B, L = chars_idx.shape
     encoded = encoder_fwd(P, chars_idx, chars_len, training, masks.get("enc_drop"), new_stats)
@@ -364,7 +369,7 @@ def tacotron2_fwd(P, d: dict, chars_idx: Tensor, chars_len: Tensor, teacher_forc
     for i in range(max_len):
         mel_o, gate_o, att_h, att_c, ctx, w, w_cum, dec_h, dec_c = decoder_step(
             P, prev, att_h, att_c, ctx, w, w_cum, dec_h, dec_c, memory, pm, mask,
-            ad[i] if ad is not None else None, dd[i] if dd is not None else None)
+            ad[i] if ad is not None else None, dd[i] if dd is not None else None, extra_decoder_in=controls)
         mels.append(mel_o); gates.append(gate_o); aligns.append(w)
         if trace is not None:
             trace.setdefault("att_h", []).append(att_h); trace.setdefault("ctx", []).append(ctx)

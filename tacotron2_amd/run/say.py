@@ -1,6 +1,7 @@
 """do_say (run/say.py:25-179): text -> ids -> checkpoint -> forward(teacher_forcing=False, max_len_override=5000) ON THE GPU
 (the reference runs this on CPU at batch 1; here any number of texts is decoded as one batch, up to 64 per group) ->
-log-mel written as .npy.  Vocoding (Griffin-Lim / HiFi-GAN) is outside the hot-path scope."""
+log-mel written as .npy, or - when the output name ends in .wav - Griffin-Lim audio (tacotron2_amd/vocoder.py, the branch
+run/say.py:161-171 takes without a HiFi-GAN checkpoint).  HiFi-GAN is outside the scope."""
 from __future__ import annotations
 
 from typing import List, Optional, Union
@@ -46,5 +47,13 @@ def do_say(dataset_config: dict, training_config: dict, model_config: dict, exte
     post = post.cpu().numpy()
     valid = (gates.cpu().numpy()[:, :, 0] != -1000.0).sum(1)
     mels = [post[b, :max(int(valid[b]) - 1, 1)] for b in range(len(texts))]     # callers drop the stop frame (run/say.py:155)
+    if output.endswith(".wav"):
+        from ..vocoder import GriffinLim, write_wav
+        sr = int(pre.get("sample_rate", 22050))
+        gl = GriffinLim(n_mels=post.shape[2], sample_rate=sr, device=dev)
+        for i, m in enumerate(mels):
+            name = output if isinstance(text, str) else f"{output[:-4]}_{i}.wav"
+            write_wav(name, gl.mel_to_audio(torch.from_numpy(m), seed=int(random_seed or 0)), sr)
+        return mels
     np.save(output, mels[0] if isinstance(text, str) else np.array(mels, dtype=object), allow_pickle=not isinstance(text, str))
     return mels

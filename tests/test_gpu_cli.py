@@ -51,6 +51,13 @@ def test_cli_train_synthetic_then_say(tmp_path):
     # an untrained model never emits a stop, so `say` runs to its 5000-frame cap like the reference would
     mel = np.load(npy)
     assert mel.ndim == 2 and mel.shape[1] == 80 and np.isfinite(mel).all()
+    # the same call with a .wav target runs the Griffin-Lim branch of run/say.py:161-173 (16-bit PCM at the dataset's rate)
+    wav = tmp_path / "say.wav"
+    _run(["--config", str(cfg), "--device", "0", "say", "--checkpoint", str(res / "final.ckpt"), "--text",
+          "Hello, Mr. Smith-Jones!", "--out", str(wav), "--random-seed", "3", "--speaker-id", "1"])
+    import wave
+    with wave.open(str(wav), "rb") as w:
+        assert w.getframerate() == 22050 and w.getsampwidth() == 2 and w.getnframes() == 256 * (mel.shape[0] - 1)
 
 
 def test_cli_train_on_wav_manifest_resume(tmp_path):

@@ -1,5 +1,7 @@
 """Kernel-level parity on the GPU: every call goes through the C ABI (tacotron2_amd._lib) and is compared with a
 plain fp32/fp64 torch restatement of the same op on CPU.  Tolerances are fp32 re-association level."""
+import math
+
 import pytest
 import torch
 
@@ -333,3 +335,46 @@ def test_logmel_matches_float64_restatement(dev):
     got = fe(torch.from_numpy(wav.astype(np.float32)), id="0").double().cpu().numpy()
     assert got.shape == ref.shape == (1 + n // 256, 80)
     assert np.abs(got - ref).max() < 2e-3 and np.abs(got - ref).mean() < 1e-4
+
+
+# ---- Griffin-Lim vocoding on the GEMM kernel (tacotron2_amd/vocoder.py; parity unpinned: properties only) -------------
+@pytest.mark.gpu
+def test_stft_istft_round_trip_is_exact():
+    from tacotron2_amd.vocoder import GriffinLim
+    gl = GriffinLim(n_iter=2)
+    g = torch.Generator().manual_seed(3)
+    y = (torch.rand(256 * 37, generator=g) * 2 - 1).cuda()
+    spec = gl.stft(y)
+    assert spec.shape == (38, 2, 513)
+    # analysis against torch's FFT (same centring, reflect padding and periodic Hann window)
+    ref = torch.stft(y.cpu().double(), 1024, 256, 1024, torch.hann_window(1024, periodic=True, dtype=torch.float64),
+                     center=True, pad_mode="reflect", return_complex=True).t()
+    assert torch.allclose(spec[:, 0].cpu().double(), ref.real, atol=2e-3)
+    assert torch.allclose(spec[:, 1].cpu().double(), ref.imag, atol=2e-3)
+    back = gl.istft(spec)
+    assert back.shape == y.shape
+    assert float((back - y).abs().max()) < 1e-4
+
+
+@pytest.mark.gpu
+def test_griffin_lim_converges_and_mel_round_trip():
+    from tacotron2_amd.vocoder import GriffinLim
+    gl = GriffinLim(n_iter=32)
+    t = torch.arange(256 * 60, dtype=torch.float64) / 22050.0
+    y = sum(a * torch.sin(2 * math.pi * f * t * (1 + 0.02 * torch.sin(2 * math.pi * 3 * t)))
+            for a, f in ((0.4, 220.0), (0.25, 440.0), (0.15, 1320.0), (0.1, 3300.0))).float().cuda()
+    spec = gl.stft(y)
+    S = torch.sqrt((spec * spec).sum(1))
+    out = gl.magnitude_to_audio(S, seed=1)
+    assert out.shape == y.shape and bool(torch.isfinite(out).all())
+    s2 = gl.stft(out)
+    S2 = torch.sqrt((s2 * s2).sum(1))
+    conv = float(torch.linalg.norm(S2 - S) / torch.linalg.norm(S))
+    assert conv < 0.15, conv                      # spectral convergence after 32 iterations
+    # the model-side entry point: log-mel in, audio out, and the audio's log-mel matches where there is energy
+    lm = gl.front(y)
+    wav = gl.mel_to_audio(lm, seed=2)
+    assert wav.shape == y.shape and bool(torch.isfinite(wav).all())
+    lm2 = gl.front(wav)
+    loud = lm > (lm.max() - 6.0)
+    assert float((lm2 - lm)[loud].abs().mean()) < 0.5
