@@ -354,6 +354,9 @@ typedef struct {
     float* xs; float* att_h; float* att_c; float* dec_c; float* cum; float* xproj; float* p1; float* p2; float* e_part;
     float* proj; int64_t ld_proj; float* align;
     int32_t* done; int64_t* lengths; int32_t* state;
+    const float* dec_pre;            /* optional [B][4D]: per-utterance term added to the decoder-LSTM pre-activations of
+                                        every frame (controls . W_ih[:, A+Ef:]^T, model/decoder.py:94-99); the matching mel
+                                        term is pre-filled into proj by the caller instead of zeros */
 } T2Infer;
 int t2_decoder_infer(const T2Infer* a, int t0, int t1, void* stream);
 

@@ -24,6 +24,7 @@ struct LinK {
     const float* bias;
     const float* mask; long ldmask;
     int relu;
+    int accum;                     // unsplit path: add to the existing output instead of overwriting it
     float* out; long ldo;
     float* out_t; int out_col0; long out_cs;   // optional x16-tiled copy of the output (chunk stride out_cs floats)
     int ksplit;                                // > 1: blockIdx.y owns a K slice, partial sums are atomically added into a
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(256, 1) void linear_rows_kernel(LinK p) {
                 atomicAdd(&p.out[(long)b * p.ldo + n], s);
                 continue;
             }
+            if (p.accum) s += p.out[(long)b * p.ldo + n];     // pre-filled output (per-utterance controls term)
             if (p.bias) s += p.bias[n];
             if (p.relu) s = fmaxf(s, 0.f);
             if (p.mask) s *= p.mask[(long)b * p.ldmask + n];
@@ -153,6 +155,7 @@ extern "C" int t2_linear_rows(const float* x, int64_t ldx, const float* w, int64
     hipStream_t st = (hipStream_t)stream;
     for (int b0 = 0; b0 < B; b0 += 64) {
         LinK k;
+        memset(&k, 0, sizeof(k));
         k.B = (B - b0) < 64 ? (B - b0) : 64; k.N = N; k.K = K;
         k.x = x + (long)b0 * ldx; k.ldx = ldx; k.w = w; k.ldw = ldw; k.bias = bias;
         k.mask = mask ? mask + (long)b0 * ldmask : nullptr; k.ldmask = ldmask; k.relu = relu;
@@ -235,6 +238,7 @@ extern "C" int t2_decoder_infer(const T2Infer* a, int t0, int t1, void* stream) 
         d.seg[0].x = a->xproj; d.seg[0].ldx = ldp; d.seg[0].K = A + Ef + D;    // (row-major operand unused: xt is set)
         d.xt = xs_nxt + (long)(P / 16) * cs;
         d.bias1 = a->b_dec_ih; d.bias2 = a->b_dec_hh;
+        d.pre = a->dec_pre; d.ldpre = 4 * D;
         d.c_prev = a->dec_c + (long)(t & 1) * B * D; d.ldc_prev = D;
         d.h_out = a->xproj; d.ldh = ldp;
         d.ht_out = xs_cur; d.ht_col0 = P + A + Ef;
@@ -248,6 +252,7 @@ extern "C" int t2_decoder_infer(const T2Infer* a, int t0, int t1, void* stream) 
             k.B = B; k.N = M + 1; k.K = (int)ldp; k.x = a->xproj; k.ldx = ldp; k.w = a->W_proj; k.ldw = ldp; k.bias = a->b_proj;
             k.mask = nullptr; k.ldmask = 0; k.relu = 0; k.out = out; k.ldo = ldo;
             k.out_t = nullptr; k.out_col0 = 0; k.out_cs = 0; k.ksplit = ksplit;
+            k.accum = a->dec_pre != nullptr;     // the caller pre-filled proj with the mel term of the controls
             T2_TRY(launch_linear(k, st));
         }
         if (t == t1 - 1)   // the last frame of the call: nobody else will run its stop logic before the host looks

@@ -292,8 +292,28 @@ class Engine:
         return enc
 
     # ---- full teacher-forced forward -------------------------------------------------------------
+    def controls_terms(self, controls, B):
+        """Prosody controls (model/tacotron2.py:279-286, model/decoder.py:94-109): the same (B, controls_dim) vector is
+        appended to the decoder-LSTM input and to the mel projection input at every frame, so its contribution is one
+        per-utterance term for each: cterm (B, 4D) and cmel1 (B, M+1) (stop column zero)."""
+        d, P = self.d, self.ps.P
+        C = d.get("controls_dim", 0) if d.get("controls") else 0
+        assert (controls is not None) == bool(C), \
+            "Controls are enabled, but no control vector was passed to the model!" if C else \
+            "Controls are disabled, but a control vector was passed to the model!"
+        if not C:
+            return None, None, None
+        M, D = d["num_mels"], d["rnn_hidden_dim"]
+        ctl = controls.to(self.dev, torch.float32).contiguous()
+        assert tuple(ctl.shape) == (B, C), f"controls must be (B, {C})"
+        cterm = self.buf("ctl.dec", B, 4 * D)
+        gemm(ctl, P["decoder.lstm.weight_ih#controls"], cterm, B, 4 * D, C, C, C, 4 * D)
+        cmel1 = self.buf("ctl.mel", B, M + 1, zero=True)
+        gemm(ctl, P["decoder.mel_out.weight#controls"], cmel1, B, M, C, C, C, M + 1)
+        return ctl, cterm, cmel1
+
     def forward_tf(self, chars_idx, chars_len, mel, mel_len, speaker_id=None, description_embeddings=None,
-                   training=True, masks: Optional[dict] = None, save_for_backward=True):
+                   training=True, masks: Optional[dict] = None, save_for_backward=True, controls=None):
         """Returns (mels, mels_post, gates, alignments), ctx.  masks: oracle-convention dict (see oracle.tacotron2_ref)
         already on the device, with prenet/att/dec masks time-major; None entries = identity."""
         d, P, ps = self.d, self.ps.P, self.ps
@@ -414,9 +434,14 @@ class Engine:
             inc.seg_x[0] = B * ldp
             return stp, inc
 
+        ctl, cterm, cmel1 = self.controls_terms(controls, B)
+
         def pre_dec_gemm(c0, c1):
+            if cterm is not None:     # per-utterance controls term first, the projection accumulates on top
+                pre_dec[c0:c1].copy_(cterm.unsqueeze(0).expand(c1 - c0, B, 4 * D))
             gemm(_ptr(xdec, (c0 + 1) * B * (A + Ef)), P["decoder.lstm.weight_ih"], _ptr(pre_dec, c0 * B * 4 * D), (c1 - c0) * B,
-                 4 * D, A + Ef, A + Ef, A + Ef, 4 * D, bias=P["decoder.lstm.bias_ih"], bias2=P["decoder.lstm.bias_hh"])
+                 4 * D, A + Ef, A + Ef, A + Ef, 4 * D, bias=P["decoder.lstm.bias_ih"], bias2=P["decoder.lstm.bias_hh"],
+                 accumulate=1 if cterm is not None else 0)
 
         main, side = torch.cuda.current_stream(), self.side_stream()
         side.wait_stream(main)
@@ -481,7 +506,10 @@ class Engine:
         wproj = ps.cat_view("decoder.mel_out.weight", M + 1, D + Ef)
         bproj = ps.cat_view("decoder.mel_out.bias", M + 1, 0)
         proj = self.buf("proj", T, B, M + 1)
-        gemm(_ptr(xproj, B * ldp), wproj, proj, R, M + 1, ldp, ldp, ldp, M + 1, bias=bproj)
+        if cmel1 is not None:
+            proj.copy_(cmel1.unsqueeze(0).expand(T, B, M + 1))
+        gemm(_ptr(xproj, B * ldp), wproj, proj, R, M + 1, ldp, ldp, ldp, M + 1, bias=bproj,
+             accumulate=1 if cmel1 is not None else 0)
         self.mark("fwd.dec.proj_gemm")
         mels = torch.empty(B, T, M, dtype=torch.float32, device=self.dev)
         gates = torch.empty(B, T, 1, dtype=torch.float32, device=self.dev)
@@ -503,7 +531,7 @@ class Engine:
                                  res=post_in if last else None, Lp_res=T + 4, pad_res=2,
                                  length=mlen32 if last else None, fill=0.0)
         self.mark("fwd.postnet")
-        ctx.update(pmT=pmT, mel_tm=mel_tm, p1=p1, p2=p2, pd=pd, pre_att=pre_att, U=U, xdec=xdec, att_c=att_c, cum=cum,
+        ctx.update(controls=ctl, pmT=pmT, mel_tm=mel_tm, p1=p1, p2=p2, pd=pd, pre_att=pre_att, U=U, xdec=xdec, att_c=att_c, cum=cum,
                    xproj=xproj, gates_att=gates_att, th=th, align=align, pre_dec=pre_dec, dec_c=dec_c,
                    gates_dec=gates_dec, proj=proj, post_in=post_in, masks=masks, training=training)
         return (mels, post, gates, align), ctx
@@ -577,6 +605,12 @@ class Engine:
         self._wgrad(dproj, M + 1, _ptr(xproj, B * ldp), ldp, ps.cat_view("decoder.mel_out.weight", M + 1, ldp, grad=True),
                     ldp, M + 1, ldp, R)
         call("t2_colsum", dproj, M + 1, R, M + 1, ps.cat_view("decoder.mel_out.bias", M + 1, 0, grad=True), st)
+        ctl = ctx.get("controls")
+        if ctl is not None:       # controls columns: sum the gradient over frames per utterance, then (M, B) x (B, C)
+            C = ctl.shape[1]
+            s_proj = self.buf("ctl.dproj_sum", B, M + 1, zero=True)
+            call("t2_colsum", dproj, B * (M + 1), T, B * (M + 1), s_proj, st)
+            self._wgrad(s_proj, M + 1, ctl, C, G["decoder.mel_out.weight#controls"], C, M, C, B)
 
         # ---- both recurrences, back-propagation through time, as a two-stream pipeline over chunks of frames -----------
         # side stream: decoder-LSTM BPTT of chunk k (1 launch / frame) + the GEMM that turns its gate gradients into
@@ -654,6 +688,11 @@ class Engine:
                 db = self.buf("db_dec", 4 * D, zero=True)                      # both biases see the same gate gradients
                 call("t2_colsum", dgd, 4 * D, R, 4 * D, db, side.cuda_stream)
                 G["decoder.lstm.bias_ih"].add_(db); G["decoder.lstm.bias_hh"].add_(db)
+                if ctl is not None:
+                    s_dgd = self.buf("ctl.dgd_sum", B, 4 * D, zero=True)
+                    call("t2_colsum", dgd, B * 4 * D, T, B * 4 * D, s_dgd, side.cuda_stream)
+                    self._wgrad(s_dgd, 4 * D, ctl, ctl.shape[1], G["decoder.lstm.weight_ih#controls"], ctl.shape[1], 4 * D,
+                                ctl.shape[1], B)
 
         chunks = [(hi, max(0, hi - CH)) for hi in range(T, 0, -CH)]
         if self.co_schedule_bwd:
@@ -850,7 +889,7 @@ class Engine:
     # autoregressive inference: forward(teacher_forcing=False, max_len_override=N)  (model/tacotron2.py:262-325)
     # =============================================================================================
     def infer(self, chars_idx, chars_len, max_len, speaker_id=None, description_embeddings=None, training=False,
-              prenet_masks=None, seed=0, check_every=32):
+              prenet_masks=None, seed=0, check_every=32, controls=None):
         """Returns (mels, mels_post, gates, alignments) exactly as the reference's non-teacher-forced forward.
         prenet_masks: optional [n][2][B][P] scale masks (parity tests); otherwise Philox masks (AlwaysDropout)."""
         d, P, ps = self.d, self.ps.P, self.ps
@@ -899,6 +938,9 @@ class Engine:
         p2 = self.buf("inf.p2", B, Pd)
         e_part = self.buf("e_part", B, Ad // 16, L)
         proj = self.buf("inf.proj", Tcap, B, ldo, zero=True)     # the projection accumulates K slices atomically
+        _, cterm, cmel1 = self.controls_terms(controls, B)
+        if cmel1 is not None:                                    # ... on top of the per-utterance controls term
+            proj[:, :, :M + 1].copy_(cmel1.unsqueeze(0).expand(Tcap, B, M + 1))
         align = torch.zeros(B, Tcap, L, dtype=torch.float32, device=self.dev)
         zero_frame = self.buf("inf.zero", max(M, 64), zero=True)
         done = self.buf("inf.done", B, dtype=torch.int32, zero=True)
@@ -930,7 +972,8 @@ class Engine:
                      Wq=P["decoder.attention.query_layer.weight"], U=U, v=P["decoder.attention.v.weight"],
                      W_proj=wproj, b_proj=bproj, pmT=pmT, memory=memory, len=len32, prenet_mask=pm_ptr,
                      zero_frame=zero_frame, xs=xs, att_h=att_h, att_c=att_c, dec_c=dec_c, cum=cum, xproj=xproj, p1=p1, p2=p2,
-                     e_part=e_part, proj=proj, ld_proj=ldo, align=align, done=done, lengths=lengths, state=state)
+                     e_part=e_part, proj=proj, ld_proj=ldo, align=align, done=done, lengths=lengths, state=state,
+                     dec_pre=cterm)
             call("t2_decoder_infer", a, t0, t1, st)
             t0 = t1
             stt = state.cpu()            # the only host synchronisation: once per `check_every` frames

@@ -63,8 +63,8 @@ class Decoder(_Sub):
                 att_weights_cum, rnn_hidden: Tuple[Tensor, Tensor], encoded, att_encoded, encoded_mask,
                 speech_features: Optional[Tensor] = None, extra_att_in: Optional[Tensor] = None,
                 extra_decoder_in: Optional[Tensor] = None):
-        assert speech_features is None and extra_att_in is None and extra_decoder_in is None, \
-            "controls / extra inputs are outside the hot-path scope"
+        assert speech_features is None and extra_att_in is None, \
+            "speech_features / extra_att_in are never passed by the reference's Tacotron2 (model/tacotron2.py:288-301)"
         root = self._root()
         P = self._P()
         dev = encoded.device
@@ -110,12 +110,18 @@ class Decoder(_Sub):
                                                 (xin2[2], P["decoder.lstm.weight_hh"].data_ptr(), D, D))):
                 d.seg[i].x = x.data_ptr(); d.seg[i].ldx = x.shape[1]; d.seg[i].w = w_; d.seg[i].ldw = ld; d.seg[i].K = K
             d._keep += xin2
+            cterm = cmel1 = None
+            if extra_decoder_in is not None:       # the controls columns of weight_ih / mel_out.weight (model/decoder.py:94-109)
+                _, cterm, cmel1 = root._engine.controls_terms(extra_decoder_in, B)
+                d.pre = cterm.data_ptr(); d.ldpre = 4 * D
             call("t2_lstm_step_fwd", d, 1, st)
             hc = torch.cat([rnn_h, ctxv], 1).contiguous()
             out = torch.empty(B, M + 1, device=dev)
             wproj = root.store.cat_view("decoder.mel_out.weight", M + 1, D + Ef)
             bproj = root.store.cat_view("decoder.mel_out.bias", M + 1, 0)
             call("t2_linear_rows", hc, D + Ef, wproj, D + Ef, bproj, None, 0, 0, out, M + 1, B, M + 1, D + Ef, st)
+            if cmel1 is not None:
+                out += cmel1
         return (out[:, :M].contiguous(), out[:, M:].contiguous(), (att_h, att_c), ctxv, w, att_weights_cum, (rnn_h, rnn_c))
 
 

@@ -56,7 +56,8 @@ class _TacotronFn(torch.autograd.Function):
         outs, ectx = eng.forward_tf(batch["chars_idx"], batch["chars_len"], batch["mel"], batch["mel_len"],
                                     speaker_id=batch.get("speaker_id"),
                                     description_embeddings=batch.get("description_embeddings"),
-                                    training=model.training, masks=masks, save_for_backward=batch["need_grad"])
+                                    training=model.training, masks=masks, save_for_backward=batch["need_grad"],
+                                    controls=batch.get("controls"))
         ctx.model, ctx.ectx = model, ectx
         ctx.mark_non_differentiable(outs[3])
         return outs
@@ -85,8 +86,6 @@ class Tacotron2(nn.Module):
                  description_embeddings_dim: int = 0, device=None, seed: int = 0):
         super().__init__()
         assert not speaker_tokens or num_speakers is not None, "If speaker tokens are enabled, you must give a num_speakers!"
-        if controls:
-            raise NotImplementedError("the prosody-controls extension is outside the hot-path scope (SURVEY.md section 8f rank 4)")
         assert encoder_kernel_size == 5, "the conv-as-GEMM kernels are specialised for the reference's k=5"
         self.embedding_dim = self.char_embedding_dim = encoded_dim
         self.num_mels, self.att_rnn_dim, self.rnn_hidden_dim = num_mels, att_rnn_dim, rnn_hidden_dim
@@ -98,7 +97,8 @@ class Tacotron2(nn.Module):
                          rnn_hidden_dim=rnn_hidden_dim, postnet_dim=postnet_dim, dropout=dropout,
                          speaker_tokens=speaker_tokens, num_speakers=num_speakers,
                          description_embeddings=description_embeddings,
-                         description_embeddings_dim=description_embeddings_dim)
+                         description_embeddings_dim=description_embeddings_dim,
+                         controls=bool(controls), controls_dim=int(controls_dim) if controls else 0)
         if device is None:
             device = "cuda:0" if torch.cuda.is_available() else "cpu"
         self._seed, self._calls = seed, 0
@@ -164,7 +164,8 @@ class Tacotron2(nn.Module):
         assert not self.speaker_tokens or speaker_id is not None, "speaker_id tensor required when speaker tokens are active!"
         assert not self.description_embeddings or description_embeddings is not None, \
             "description tensor required when description tokens are active!"
-        assert controls is None, "Controls are disabled, but a control vector was passed to the model!"
+        assert not self.controls or controls is not None, "Controls are enabled, but no control vector was passed to the model!"
+        assert self.controls or controls is None, "Controls are disabled, but a control vector was passed to the model!"
         if max_len_override is None and mel_spectrogram is None:
             raise Exception("If Mel spectrogram is not given, max_len_override is required!")
         if not chars_idx.is_cuda:
@@ -176,7 +177,7 @@ class Tacotron2(nn.Module):
                          speaker_id=speaker_id,
                          description_embeddings=description_embeddings.contiguous().float()
                          if description_embeddings is not None else None, masks=dropout_masks,
-                         need_grad=torch.is_grad_enabled())
+                         controls=controls, need_grad=torch.is_grad_enabled())
             named = dict(self.named_parameters())
             params = [named[n] for n in self._param_names]      # store order = order of the returned gradients
             return _TacotronFn.apply(self, batch, *params)
@@ -189,7 +190,8 @@ class Tacotron2(nn.Module):
                                        speaker_id=speaker_id[sl] if speaker_id is not None else None,
                                        description_embeddings=description_embeddings[sl].contiguous().float()
                                        if description_embeddings is not None else None,
-                                       training=self.training, prenet_masks=pm, seed=self._seed + self._calls)
+                                       training=self.training, prenet_masks=pm, seed=self._seed + self._calls,
+                                       controls=controls[sl] if controls is not None else None)
                 self._calls += 1
                 outs.append(o[:4])
         if len(outs) == 1:

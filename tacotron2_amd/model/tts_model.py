@@ -66,6 +66,8 @@ class TTSModel(nn.Module):
             args["speaker_id"] = meta["speaker_id"]
         if self.description_embeddings:
             args["description_embeddings"] = meta["description_embeddings"]
+        if self.controls:
+            args["controls"] = meta["features"]           # model/tts_model.py:125,173,304
         return args
 
     def _loss(self, batch):

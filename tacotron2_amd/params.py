@@ -68,7 +68,17 @@ def param_manifest(d: dict) -> "OrderedDict[str, tuple]":
         s[f"postnet.postnet.{4 * li}.weight"] = (chans[li + 1], chans[li], 5)
         s[f"postnet.postnet.{4 * li + 1}.weight"] = (chans[li + 1],)
         s[f"postnet.postnet.{4 * li + 1}.bias"] = (chans[li + 1],)
+    # prosody-controls extension (model/decoder.py:40-48): the reference appends controls_dim input columns to the decoder
+    # LSTM's weight_ih and to mel_out.weight.  They are stored as separate blocks so that [att_h | ctx] stays one K segment
+    # and [mel_out ; gate] stays one (M+1, D+Ef) matrix; state_dict exchange splits / concatenates (CONTROL_SPLITS).
+    C = d.get("controls_dim", 0) if d.get("controls") else 0
+    if C:
+        s["decoder.lstm.weight_ih#controls"] = (4 * D, C)
+        s["decoder.mel_out.weight#controls"] = (M, C)
     return s
+
+
+CONTROL_SPLITS = ("decoder.lstm.weight_ih", "decoder.mel_out.weight")
 
 
 # pairs that must be contiguous without padding between them
@@ -144,6 +154,16 @@ class ParamStore:
         buf = self.grad if grad else self.flat
         return buf[o:o + rows * cols].view(rows, cols) if cols > 0 else buf[o:o + rows]
 
+    def reference_layout(self, table: Dict[str, torch.Tensor]) -> "OrderedDict[str, torch.Tensor]":
+        """Copies of `table` (self.P or self.G) under the reference's names and shapes (controls columns appended)."""
+        out = OrderedDict()
+        for name, v in table.items():
+            if name.endswith("#controls"):
+                continue
+            c = table.get(name + "#controls")
+            out[name] = torch.cat([v, c], 1) if c is not None else v.detach().clone()
+        return out
+
     def init_adam(self):
         if self.exp_avg is None:
             self.exp_avg = torch.zeros_like(self.flat)
@@ -152,10 +172,18 @@ class ParamStore:
     # --- state_dict exchange (reference layout) -----------------------------
     def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = "", strict: bool = True):
         missing = []
+        ctrl = any(n.endswith("#controls") for n in self.P)
         for name in self.P:
+            if name.endswith("#controls"):
+                continue                     # filled together with its base tensor below
             key = prefix + name
             if key in sd:
-                self.P[name].copy_(torch.as_tensor(sd[key]).to(torch.float32).reshape(self.shapes[name]))
+                t = torch.as_tensor(sd[key]).to(torch.float32)
+                if ctrl and name in CONTROL_SPLITS:       # reference layout: [main columns | controls columns]
+                    k0 = self.shapes[name][1]
+                    self.P[name + "#controls"].copy_(t[:, k0:])
+                    t = t[:, :k0]
+                self.P[name].copy_(t.reshape(self.shapes[name]))
             else:
                 missing.append(key)
         for name in self.Bf:
@@ -173,8 +201,8 @@ class ParamStore:
 
     def state_dict(self, prefix: str = "") -> "OrderedDict[str, torch.Tensor]":
         out = OrderedDict()
-        for name, v in self.P.items():
-            out[prefix + name] = v.detach().clone()
+        for name, v in self.reference_layout(self.P).items():
+            out[prefix + name] = v
         for name, v in self.Bf.items():
             out[prefix + name] = v.detach().clone()
         for name, v in self.num_batches_tracked.items():

@@ -23,8 +23,8 @@ def model_kwargs(cfg: dict) -> dict:
     args = dict(md.get("args", {}))
     if "char_embedding_dim" in args:
         args["encoded_dim"] = args.pop("char_embedding_dim")
-    if ext["controls"].get("active"):
-        raise NotImplementedError("controls extension is out of the hot-path scope (SURVEY.md section 8f)")
+    ctl = bool(ext["controls"].get("active"))          # run/train.py:176-180: one control per listed feature column
+    args.update(controls=ctl, controls_dim=len(ext["controls"].get("features", [])) if ctl else 0)
     spk = ext["speaker_tokens"].get("active", False)
     max_steps = tr.get("args", {}).get("max_steps", 100000)
     return dict(lr=tr["lr"], weight_decay=tr["weight_decay"],

@@ -42,6 +42,11 @@ def do_say(dataset_config: dict, training_config: dict, model_config: dict, exte
             raise NotImplementedError("BERT description encoding needs the remote google-bert weights (unavailable offline); "
                                       "pass precomputed embeddings through the Python API instead")
         kw["description_embeddings"] = torch.zeros(len(texts), dim, device=dev)
+    if model.controls:      # run/say.py:113-118: comma-separated values; the CLI help promises zeros by default
+        n_ctl = int(model.hparams["controls_dim"])
+        vals = [float(x) for x in controls.split(",")] if controls else [0.0] * n_ctl
+        assert len(vals) == n_ctl, f"--controls needs {n_ctl} comma-separated values"
+        kw["controls"] = torch.tensor([vals] * len(texts), dtype=torch.float32, device=dev)
     with torch.no_grad():
         _, post, gates, _ = model(chars_idx=chars, chars_idx_len=lens, teacher_forcing=False, max_len_override=max_len, **kw)
     post = post.cpu().numpy()

@@ -26,6 +26,8 @@ def _to_dev(batch, dev):
     for k in ("speaker_id", "description_embeddings"):
         if k in meta:
             out[k] = meta[k].to(dev)
+    if "features" in meta:                      # controls extension: model/tts_model.py:125 feeds metadata["features"]
+        out["controls"] = meta["features"].to(dev).float()
     return out
 
 
@@ -84,6 +86,7 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
             desc = [None if (isinstance(x, float)) else x for x in df.description_embedding]
         ds = TTSDataset(filenames=list(df.wav), texts=list(df.text), base_dir=speech_dir,
                         speaker_ids=list(df.speaker_id) if kw["speaker_tokens"] else None,
+                        features=df[extensions_config["controls"]["features"]].values.tolist() if kw.get("controls") else None,
                         cache_dir=os.path.join(results_dir, "mel_cache"), description_embeddings=desc, device=dev,
                         **dataset_config["preprocessing"])
         loader = TTSDataLoader(ds, batch_size=training_config["batch_size"], shuffle=True, drop_last=True)

@@ -68,7 +68,8 @@ class Trainer:
         eng.mark("masks")
         outs, ctx = eng.forward_tf(ci, batch["chars_idx_len"], mel, batch["mel_spectrogram_len"],
                                    speaker_id=batch.get("speaker_id"),
-                                   description_embeddings=batch.get("description_embeddings"), training=True, masks=masks)
+                                   description_embeddings=batch.get("description_embeddings"), training=True, masks=masks,
+                                   controls=batch.get("controls"))
         ps.grad.zero_()
         loss3 = eng.loss_and_grads(outs, ctx, mel, batch["gate"])
         if self.world > 1:

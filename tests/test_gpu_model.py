@@ -71,7 +71,8 @@ def test_forward_eval_matches_reference_golden():
 
 @pytest.mark.parametrize("name,extra", [("tf_train", {}),
                                         ("tf_train_desc", dict(speaker_tokens=True, num_speakers=7,
-                                                               description_embeddings=True, description_embeddings_dim=24))])
+                                                               description_embeddings=True, description_embeddings_dim=24)),
+                                        ("tf_train_ctrl", dict(controls=True, controls_dim=5))])
 def test_forward_train_matches_reference_golden(name, extra):
     dev = _dev()
     z = load_golden(name)
@@ -83,6 +84,8 @@ def test_forward_train_matches_reference_golden(name, extra):
         kw["speaker_id"] = t("speaker_id")
     if "description_embeddings" in z:
         kw["description_embeddings"] = t("description_embeddings")
+    if "controls" in z:
+        kw["controls"] = t("controls")
     masks = masks_to_device(tf_masks_from(z), dev)
     (mels, post, gates, al), _ = eng.forward_tf(t("chars_idx"), t("chars_len"), t("mel"), t("mel_len"), training=True,
                                                 masks=masks, **kw)
@@ -138,7 +141,7 @@ def test_forward_train_midsize_matches_oracle():
 def _grad_check(ps, ref_grads, tol=3e-4, floor=1e-3):
     """relative-to-scale comparison of every parameter gradient."""
     bad = []
-    for name, g in ps.G.items():
+    for name, g in ps.reference_layout(ps.G).items():     # reference names/shapes (controls columns appended)
         r = torch.as_tensor(ref_grads[name]).double()
         got = g.double().cpu()
         scale = max(float(r.abs().max()), floor)
@@ -150,7 +153,8 @@ def _grad_check(ps, ref_grads, tol=3e-4, floor=1e-3):
 
 @pytest.mark.parametrize("name,extra", [("tf_train", {}),
                                         ("tf_train_desc", dict(speaker_tokens=True, num_speakers=7,
-                                                               description_embeddings=True, description_embeddings_dim=24))])
+                                                               description_embeddings=True, description_embeddings_dim=24)),
+                                        ("tf_train_ctrl", dict(controls=True, controls_dim=5))])
 def test_backward_matches_reference_golden(name, extra):
     dev = _dev()
     z = load_golden(name)
@@ -162,6 +166,8 @@ def test_backward_matches_reference_golden(name, extra):
         kw["speaker_id"] = t("speaker_id")
     if "description_embeddings" in z:
         kw["description_embeddings"] = t("description_embeddings")
+    if "controls" in z:
+        kw["controls"] = t("controls")
     outs, ctx = eng.forward_tf(t("chars_idx"), t("chars_len"), t("mel"), t("mel_len"), training=True,
                                masks=masks_to_device(tf_masks_from(z), dev), **kw)
     ps.grad.zero_()
@@ -256,17 +262,18 @@ def test_pipeline_variants_match_oracle(co_fwd, co_bwd, chunk, plans, co_host):
 # ------------------------------------------------------------------------------------------------------
 # autoregressive inference
 # ------------------------------------------------------------------------------------------------------
-def test_inference_matches_reference_golden():
+@pytest.mark.parametrize("name,extra", [("infer", {}), ("infer_ctrl", dict(controls=True, controls_dim=5))])
+def test_inference_matches_reference_golden(name, extra):
     """forward(teacher_forcing=False): device-side stop logic, the non-sticky length count and early break must match
     the reference frame for frame (prenet dropout masks replayed from the fixture)."""
     dev = _dev()
-    z = load_golden("infer")
-    d = R.default_dims(**SMALL, dropout=0.5)
+    z = load_golden(name)
+    d = R.default_dims(**SMALL, dropout=0.5, **extra)
     eng, ps = build_engine(d, params_from(z), dev)
     t = lambda k: torch.from_numpy(z[k]).to(dev)
     pm = t("m.prenet_drop").contiguous()            # [n][2][B][P]
     mels, post, gates, al, lengths = eng.infer(t("chars_idx"), t("chars_len"), int(z["max_len"]), prenet_masks=pm,
-                                               check_every=4)
+                                               check_every=4, controls=t("controls") if "controls" in z else None)
     torch.cuda.synchronize()
     assert mels.shape == z["o_mels"].shape, (mels.shape, z["o_mels"].shape)
     assert l1(mels, z["o_mels"]) < MEL_L1_TOL and l1(post, z["o_post"]) < MEL_L1_TOL
@@ -486,3 +493,47 @@ def test_submodule_forward_signatures_match_oracle():
     X = torch.randn(B, 16, T, generator=g)
     post = m.postnet(X.to(dev))
     assert mx(post, R.postnet_fwd(P, X.transpose(1, 2), False).transpose(1, 2)) < 2e-5
+
+
+def test_controls_train_step_midsize_and_module_api_match_oracle():
+    """Prosody controls at H = 256: forward, loss and every gradient against the oracle, then the
+    nn.Module surface (state_dict in the reference layout, forward with `controls=`, the flag/tensor assertions)."""
+    dev = _dev()
+    d = R.default_dims(num_chars=39, encoded_dim=128, prenet_dim=64, att_rnn_dim=256, att_dim=64, rnn_hidden_dim=256,
+                       postnet_dim=128, num_mels=80, dropout=0.5, controls=True, controls_dim=5)
+    P = R.init_params(d, seed=5)
+    assert P["decoder.lstm.weight_ih"].shape == (1024, 256 + 128 + 5) and P["decoder.mel_out.weight"].shape == (80, 256 + 128 + 5)
+    ci, lens, mel, tl, gate, masks = random_case(d, 4, 33, 29, 23, dev)
+    ctl = torch.randn(4, 5, generator=torch.Generator().manual_seed(1))
+    for k, v in P.items():
+        if v.is_floating_point() and not R.is_buffer(k):
+            v.requires_grad_(True)
+    ref = R.tacotron2_fwd(P, d, ci, lens, True, mel, tl, training=True, masks=masks, controls=ctl)
+    loss = R.tts_loss(ref[0], ref[1], ref[2], mel, gate)[0]
+    loss.backward()
+    eng, ps = build_engine(d, {k: v.detach() for k, v in P.items()}, dev)
+    outs, ctx = eng.forward_tf(ci.to(dev), lens.to(dev), mel.to(dev), tl.to(dev), training=True,
+                               masks=masks_to_device(masks, dev), controls=ctl.to(dev))
+    assert l1(outs[0], ref[0].detach()) < MEL_L1_TOL and l1(outs[1], ref[1].detach()) < MEL_L1_TOL
+    ps.grad.zero_()
+    loss3 = eng.loss_and_grads(outs, ctx, mel.to(dev), gate.to(dev))
+    torch.cuda.synchronize()
+    assert abs(float(loss3.sum()) - float(loss)) < 1e-4 * max(1.0, abs(float(loss)))
+    _grad_check(ps, {k: v.grad for k, v in P.items() if v.requires_grad}, tol=1e-3)
+    sd = ps.state_dict()
+    assert sd["decoder.lstm.weight_ih"].shape == (1024, 389)
+    assert mx(sd["decoder.mel_out.weight"], P["decoder.mel_out.weight"].detach()) == 0.0
+    # nn.Module surface
+    from tacotron2_amd.model.tacotron2 import Tacotron2
+    kw = {k: d[k] for k in ("num_chars", "encoded_dim", "encoder_kernel_size", "num_mels", "prenet_dim", "att_rnn_dim", "att_dim",
+                            "rnn_hidden_dim", "postnet_dim", "dropout")}
+    m = Tacotron2(**kw, controls=True, controls_dim=5, device=dev)
+    m.load_state_dict({k: v.detach() for k, v in P.items()})
+    m.train()
+    o = m(ci.to(dev), lens.to(dev), True, mel.to(dev), tl.to(dev), controls=ctl.to(dev), dropout_masks=masks_to_device(masks, dev))
+    assert l1(o[0], ref[0].detach()) < MEL_L1_TOL
+    with pytest.raises(AssertionError):
+        m(ci.to(dev), lens.to(dev), True, mel.to(dev), tl.to(dev))                     # controls enabled, none passed
+    m.eval()
+    oi = m(ci.to(dev), lens.to(dev), False, max_len_override=6, controls=ctl.to(dev))
+    assert oi[0].shape[0] == 4 and oi[0].shape[2] == 80 and bool(torch.isfinite(oi[0]).all())
