@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ALLOWED = "!'(),.:;? \\-abcdefghijklmnopqrstuvwxyz"
 
 
-def _cfg(tmp_path, train_csv="none.csv", batch=4):
+def _cfg(tmp_path, train_csv="none.csv", batch=4, controls=None):
     cfg = {"dataset": {"train": str(train_csv), "val": str(train_csv),
                        "preprocessing": {"allowed_chars": ALLOWED, "expand_abbreviations": True, "end_token": "^",
                                          "silence": 512, "trim": False, "num_mels": 80, "cache": True}},
@@ -25,6 +25,8 @@ def _cfg(tmp_path, train_csv="none.csv", batch=4):
                      "args": {"prenet_dim": 32, "att_rnn_dim": 64, "att_dim": 32, "rnn_hidden_dim": 64, "postnet_dim": 64,
                               "dropout": 0.5, "char_embedding_dim": 64, "encoder_kernel_size": 5}},
            "extensions": {"speaker_tokens": {"active": True, "num_speakers": 4}, "controls": {"active": False}}}
+    if controls:
+        cfg["extensions"]["controls"] = {"active": True, "features": list(controls)}
     p = tmp_path / "cfg.json"
     p.write_text(json.dumps(cfg))
     return p
@@ -81,6 +83,43 @@ def test_cli_train_on_wav_manifest_resume(tmp_path):
     out = _run(["--config", str(cfg), "train", "--speech-dir", str(speech), "--results-dir", str(res), "--max-steps", "4",
                 "--resume-ckpt", str(res / "final.ckpt")])
     assert "step 3/4" in out or "step 4/4" in out
+
+
+def test_cli_controls_extension_train_then_say(tmp_path):
+    """extensions.controls (run/train.py:78-83,176-180; run/say.py:113-118): feature columns of the manifest become the
+    per-utterance controls vector in training; `say --controls a,b` feeds one at synthesis time."""
+    sr = 22050
+    speech = tmp_path / "wavs"
+    speech.mkdir()
+    rows = ["text|wav|speaker_id|pitch_speaker_norm|rate_speaker_norm"]
+    for i in range(4):
+        n = sr // 2 + 733 * i
+        x = 0.3 * np.sin(2 * np.pi * (180 + 30 * i) * np.arange(n) / sr)
+        with wave.open(str(speech / f"c{i}.wav"), "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(sr); w.writeframes((x * 32767).astype("<i2").tobytes())
+        rows.append(f"Controlled utterance {i}.|c{i}.wav|{i % 4}|{0.5 * i - 1.0}|{1.0 - 0.25 * i}")
+    csvp = tmp_path / "train.csv"
+    csvp.write_text("\n".join(rows) + "\n")
+    cfg = _cfg(tmp_path, csvp, batch=2, controls=("pitch_speaker_norm", "rate_speaker_norm"))
+    res = tmp_path / "res"
+    _run(["--config", str(cfg), "train", "--speech-dir", str(speech), "--results-dir", str(res), "--max-steps", "2"])
+    ck = torch.load(res / "final.ckpt", map_location="cpu", weights_only=True)
+    assert ck["hyper_parameters"]["controls"] and ck["hyper_parameters"]["controls_dim"] == 2
+    assert ck["state_dict"]["tacotron2.decoder.lstm.weight_ih"].shape == (4 * 64, 64 + 64 + 2)       # reference layout
+    assert ck["state_dict"]["tacotron2.decoder.mel_out.weight"].shape == (80, 64 + 64 + 2)
+    outs = []
+    for vals in ("0.5,-1.0", "-2.0,3.0"):
+        npy = tmp_path / f"say_{len(outs)}.npy"
+        _run(["--config", str(cfg), "--device", "0", "say", "--checkpoint", str(res / "final.ckpt"), "--text", "Hi there.",
+              "--out", str(npy), "--random-seed", "3", "--speaker-id", "1", "--controls", vals])
+        outs.append(np.load(npy))
+    # (an untrained model stops at once, so the two outputs carry no signal to compare; the numerics of the controls path are
+    # pinned by tests/golden/tf_train_ctrl.npz and infer_ctrl.npz in test_gpu_model.py)
+    assert all(np.isfinite(o).all() and o.shape[1] == 80 for o in outs)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "--config", str(cfg), "--device", "0", "say", "--checkpoint",
+                        str(res / "final.ckpt"), "--text", "Hi.", "--out", str(tmp_path / "bad.npy"), "--controls", "1.0"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "comma-separated" in (r.stdout + r.stderr)      # wrong number of control values
 
 
 def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
