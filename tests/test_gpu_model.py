@@ -537,3 +537,18 @@ def test_controls_train_step_midsize_and_module_api_match_oracle():
     m.eval()
     oi = m(ci.to(dev), lens.to(dev), False, max_len_override=6, controls=ctl.to(dev))
     assert oi[0].shape[0] == 4 and oi[0].shape[2] == 80 and bool(torch.isfinite(oi[0]).all())
+    # one frame through Decoder.forward(..., extra_decoder_in=controls) (model/decoder.py:53-67,94-109)
+    Pd = {k: v.detach() for k, v in P.items()}
+    g = torch.Generator().manual_seed(2)
+    zr = lambda *s: torch.randn(*s, generator=g) * 0.3
+    B, L = ci.shape
+    with torch.no_grad():
+        mem, pmem = R.condition(Pd, d, R.encoder_fwd(Pd, ci, lens, False))
+    mask = torch.arange(L)[None] >= lens[:, None]
+    w0 = torch.softmax(torch.randn(B, L, generator=g), 1); cum0 = 1.5 * w0
+    pre, ah, ac, cx, dh, dc = zr(B, 64), zr(B, 256), zr(B, 256), zr(B, 128), zr(B, 256), zr(B, 256)
+    with torch.no_grad():
+        rs = R.decoder_step(Pd, pre, ah, ac, cx, w0, cum0.clone(), dh, dc, mem, pmem, mask, None, None, extra_decoder_in=ctl)
+    gs = m.decoder(pre.to(dev), (ah.to(dev), ac.to(dev)), cx.to(dev), w0.to(dev), cum0.clone().to(dev), (dh.to(dev), dc.to(dev)),
+                   mem.to(dev), pmem.to(dev), mask.to(dev), extra_decoder_in=ctl.to(dev))
+    assert mx(gs[0], rs[0]) < 5e-5 and mx(gs[1], rs[1]) < 5e-5 and mx(gs[6][0], rs[7]) < 2e-5
