@@ -500,25 +500,27 @@ def test_controls_train_step_midsize_and_module_api_match_oracle():
     nn.Module surface (state_dict in the reference layout, forward with `controls=`, the flag/tensor assertions)."""
     dev = _dev()
     d = R.default_dims(num_chars=39, encoded_dim=128, prenet_dim=64, att_rnn_dim=256, att_dim=64, rnn_hidden_dim=256,
-                       postnet_dim=128, num_mels=80, dropout=0.5, controls=True, controls_dim=5)
+                       postnet_dim=128, num_mels=80, dropout=0.5, controls=True, controls_dim=5,
+                       speaker_tokens=True, num_speakers=4)     # controllable configs are multi-speaker (run/train.py:53-60)
     P = R.init_params(d, seed=5)
     assert P["decoder.lstm.weight_ih"].shape == (1024, 256 + 128 + 5) and P["decoder.mel_out.weight"].shape == (80, 256 + 128 + 5)
     ci, lens, mel, tl, gate, masks = random_case(d, 4, 33, 29, 23, dev)
     ctl = torch.randn(4, 5, generator=torch.Generator().manual_seed(1))
+    spk = torch.tensor([3, 0, 2, 2], dtype=torch.int32)
     for k, v in P.items():
         if v.is_floating_point() and not R.is_buffer(k):
             v.requires_grad_(True)
-    ref = R.tacotron2_fwd(P, d, ci, lens, True, mel, tl, training=True, masks=masks, controls=ctl)
+    ref = R.tacotron2_fwd(P, d, ci, lens, True, mel, tl, training=True, masks=masks, controls=ctl, speaker_id=spk)
     loss = R.tts_loss(ref[0], ref[1], ref[2], mel, gate)[0]
     loss.backward()
     eng, ps = build_engine(d, {k: v.detach() for k, v in P.items()}, dev)
     outs, ctx = eng.forward_tf(ci.to(dev), lens.to(dev), mel.to(dev), tl.to(dev), training=True,
-                               masks=masks_to_device(masks, dev), controls=ctl.to(dev))
+                               masks=masks_to_device(masks, dev), controls=ctl.to(dev), speaker_id=spk.to(dev))
     assert l1(outs[0], ref[0].detach()) < MEL_L1_TOL and l1(outs[1], ref[1].detach()) < MEL_L1_TOL
     ps.grad.zero_()
     loss3 = eng.loss_and_grads(outs, ctx, mel.to(dev), gate.to(dev))
     torch.cuda.synchronize()
-    assert abs(float(loss3.sum()) - float(loss)) < 1e-4 * max(1.0, abs(float(loss)))
+    assert abs(float(loss3.sum()) - float(loss.detach())) < 1e-4 * max(1.0, abs(float(loss.detach())))
     _grad_check(ps, {k: v.grad for k, v in P.items() if v.requires_grad}, tol=1e-3)
     sd = ps.state_dict()
     assert sd["decoder.lstm.weight_ih"].shape == (1024, 389)
@@ -527,15 +529,16 @@ def test_controls_train_step_midsize_and_module_api_match_oracle():
     from tacotron2_amd.model.tacotron2 import Tacotron2
     kw = {k: d[k] for k in ("num_chars", "encoded_dim", "encoder_kernel_size", "num_mels", "prenet_dim", "att_rnn_dim", "att_dim",
                             "rnn_hidden_dim", "postnet_dim", "dropout")}
-    m = Tacotron2(**kw, controls=True, controls_dim=5, device=dev)
+    m = Tacotron2(**kw, controls=True, controls_dim=5, speaker_tokens=True, num_speakers=4, device=dev)
     m.load_state_dict({k: v.detach() for k, v in P.items()})
     m.train()
-    o = m(ci.to(dev), lens.to(dev), True, mel.to(dev), tl.to(dev), controls=ctl.to(dev), dropout_masks=masks_to_device(masks, dev))
+    o = m(ci.to(dev), lens.to(dev), True, mel.to(dev), tl.to(dev), controls=ctl.to(dev), speaker_id=spk.to(dev),
+          dropout_masks=masks_to_device(masks, dev))
     assert l1(o[0], ref[0].detach()) < MEL_L1_TOL
     with pytest.raises(AssertionError):
-        m(ci.to(dev), lens.to(dev), True, mel.to(dev), tl.to(dev))                     # controls enabled, none passed
+        m(ci.to(dev), lens.to(dev), True, mel.to(dev), tl.to(dev), speaker_id=spk.to(dev))     # controls enabled, none passed
     m.eval()
-    oi = m(ci.to(dev), lens.to(dev), False, max_len_override=6, controls=ctl.to(dev))
+    oi = m(ci.to(dev), lens.to(dev), False, max_len_override=6, controls=ctl.to(dev), speaker_id=spk.to(dev))
     assert oi[0].shape[0] == 4 and oi[0].shape[2] == 80 and bool(torch.isfinite(oi[0]).all())
     # one frame through Decoder.forward(..., extra_decoder_in=controls) (model/decoder.py:53-67,94-109)
     Pd = {k: v.detach() for k, v in P.items()}
@@ -543,7 +546,7 @@ def test_controls_train_step_midsize_and_module_api_match_oracle():
     zr = lambda *s: torch.randn(*s, generator=g) * 0.3
     B, L = ci.shape
     with torch.no_grad():
-        mem, pmem = R.condition(Pd, d, R.encoder_fwd(Pd, ci, lens, False))
+        mem, pmem = R.condition(Pd, d, R.encoder_fwd(Pd, ci, lens, False), speaker_id=spk)
     mask = torch.arange(L)[None] >= lens[:, None]
     w0 = torch.softmax(torch.randn(B, L, generator=g), 1); cum0 = 1.5 * w0
     pre, ah, ac, cx, dh, dc = zr(B, 64), zr(B, 256), zr(B, 256), zr(B, 128), zr(B, 256), zr(B, 256)
