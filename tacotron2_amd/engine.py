@@ -90,6 +90,8 @@ class Engine:
                                                                    # 73 KB-LDS workgroups per CU lock the attention kernels out (84.3 -> 83.2 ms)
         self.co_host = int(_os.environ.get("T2_CO_HOST", "1"))   # where the co-scheduled decoder cell rides: 1 = energies launch (measured best:
                                                                  # 26.85 ms vs 27.2 ms in the context launch, 29.2 ms split over both)
+        self.generation = 0           # bumped by every forward: activations live in the shared named workspaces,
+                                      # so only the LATEST forward can be back-propagated (checked in backward_tf)
         self.profile = False          # when True, mark() records HIP events at segment boundaries
         self.marks = []; self.spans = []               # [(name, event)] of the current step
 
@@ -324,6 +326,8 @@ class Engine:
         Ef = E + (128 if d.get("description_embeddings") else 0)
         F = d.get("loc_filters", 32)
         ctx: dict = dict(B=B, L=L, T=T)
+        self.generation += 1          # any forward (grad-enabled or not) rewrites the shared workspaces
+        ctx["generation"] = self.generation
         st = _stream()
         len32 = chars_len.to(torch.int32)
         mlen32 = mel_len.to(torch.int32)
@@ -574,6 +578,9 @@ class Engine:
         """d_post (B,T,M): gradient w.r.t. mels_post (masked positions zero).  dproj [T][B][M+1]: gradient w.r.t. the
         decoder projection from the mel / residual / gate terms.  Accumulates into ps.grad (caller zeroes it)."""
         d, P, G, ps = self.d, self.ps.P, self.ps.G, self.ps
+        if ctx.get("generation") != self.generation:
+            raise RuntimeError("backward of a stale forward: the activation stashes of this forward were overwritten by a later "
+                               "grad-enabled forward of the same model (one live teacher-forced graph per model; INTEGRATION.md)")
         B, L, T = ctx["B"], ctx["L"], ctx["T"]
         M, E, Pd, A, D, Ad = d["num_mels"], d["encoded_dim"], d["prenet_dim"], d["att_rnn_dim"], d["rnn_hidden_dim"], d["att_dim"]
         Ef = E + (128 if d.get("description_embeddings") else 0)
@@ -876,13 +883,17 @@ class Engine:
         self.backward_tf(ctx, d_post, dproj)
         return loss3
 
-    def adam_step(self, step, lr, weight_decay, max_norm=1.0, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):
+    def adam_step(self, step, lr, weight_decay, max_norm=1.0, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8, ranges=None):
+        """Global-norm clip + Adam(L2) on the flat buffers.  ranges: optional [(start, end)] element ranges to update (the
+        trainable tensors when some are frozen; the caller zeroes the frozen gradients so the norm excludes them)."""
         ps = self.ps
         ps.init_adam()
         sumsq = self.buf("sumsq", 1, dtype=torch.float64)
         call("t2_sumsq", ps.grad, ps.numel, sumsq, _stream())
-        call("t2_adam_step", ps.flat, ps.grad, ps.exp_avg, ps.exp_avg_sq, ps.numel, sumsq, float(max_norm), float(lr),
-             float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step), float(grad_scale), _stream())
+        for a, b in (ranges or [(0, ps.numel)]):
+            call("t2_adam_step", _ptr(ps.flat, a), _ptr(ps.grad, a), _ptr(ps.exp_avg, a), _ptr(ps.exp_avg_sq, a), b - a, sumsq,
+                 float(max_norm), float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step),
+                 float(grad_scale), _stream())
         return sumsq
 
     # =============================================================================================
@@ -895,6 +906,7 @@ class Engine:
         d, P, ps = self.d, self.ps.P, self.ps
         B, L = chars_idx.shape
         assert B <= 64, "engine.infer handles up to 64 utterances per call (callers split larger batches)"
+        self.generation += 1          # the encoder / postnet workspaces are shared with forward_tf
         M, E, Pd, A, D, Ad = d["num_mels"], d["encoded_dim"], d["prenet_dim"], d["att_rnn_dim"], d["rnn_hidden_dim"], d["att_dim"]
         Ef = E + (128 if d.get("description_embeddings") else 0)
         F = d.get("loc_filters", 32)

@@ -13,9 +13,9 @@ def init_parameters(ps: ParamStore, seed: int = 0) -> None:
     for name, p in ps.P.items():
         shp = tuple(p.shape)
         if name in ("encoder.embedding.weight", "speaker_embedding.weight"):
+            # .weight.data.normal_(0, 0.5) overwrites nn.Embedding's zeroed padding row too (model/encoder.py:25-26): row 0 is
+            # NOT zero in the reference and feeds the encoder convolutions at padded positions
             v = torch.randn(shp, generator=g) * 0.5
-            if name == "encoder.embedding.weight":
-                v[0].zero_()    # padding_idx = 0
         elif ("convolutions" in name or "postnet.postnet" in name) and len(shp) == 1 and int(name.split(".")[2]) % 4 == 1:
             v = torch.ones(shp) if name.endswith("weight") else torch.zeros(shp)   # BatchNorm affine
         elif "lstm" in name or "att_rnn" in name:

@@ -50,8 +50,12 @@ def do_say(dataset_config: dict, training_config: dict, model_config: dict, exte
     with torch.no_grad():
         _, post, gates, _ = model(chars_idx=chars, chars_idx_len=lens, teacher_forcing=False, max_len_override=max_len, **kw)
     post = post.cpu().numpy()
+    # run/say.py:155,161 keeps mel_spectrogram_post[:, :-1]: all emitted frames but the last.  The stop frame itself is already
+    # masked (gate -1000 from `lengths` on), so an utterance that stopped keeps its `lengths` = n - 1 frames; one that ran into
+    # max_len without stopping has n unmasked frames and loses the last one, as in the reference.
     valid = (gates.cpu().numpy()[:, :, 0] != -1000.0).sum(1)
-    mels = [post[b, :max(int(valid[b]) - 1, 1)] for b in range(len(texts))]     # callers drop the stop frame (run/say.py:155)
+    n_emitted = post.shape[1]
+    mels = [post[b, :max(min(int(valid[b]), n_emitted - 1), 1)] for b in range(len(texts))]
     if output.endswith(".wav"):
         from ..vocoder import GriffinLim, write_wav
         sr = int(pre.get("sample_rate", 22050))

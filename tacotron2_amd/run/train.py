@@ -59,13 +59,13 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
     tr = Trainer(model.tacotron2.store, lr=kw["lr"], weight_decay=kw["weight_decay"],
                  scheduler_milestones=kw["scheduler_milestones"], max_norm=1.0)
     if resume_ckpt:
+        # trainer.fit(ckpt_path=...) (run/train.py:245): weights, global_step, Adam moments and the scheduler state all come
+        # back, for plain resumes and for --finetune alike (the fine-tune then runs exactly `finetune_steps` more steps)
+        from ..checkpoint import restore_trainer
         ck = torch.load(resume_ckpt, map_location="cpu", weights_only=True)
         model.load_checkpoint_dict(ck)
-        if "t2_optimizer" in ck and not finetune:
-            st = ck["t2_optimizer"]
-            tr.ps.init_adam()
-            tr.ps.exp_avg.copy_(st["exp_avg"]); tr.ps.exp_avg_sq.copy_(st["exp_avg_sq"])
-            tr.global_step = start_step = int(ck.get("global_step", 0))
+        restore_trainer(ck, tr)
+        start_step = tr.global_step
     if finetune:   # run/train.py:229-233: encoder and speaker embedding are frozen
         tr.frozen = {n for n in tr.ps.P if n.startswith("encoder.") or n.startswith("speaker_embedding.")}
 
@@ -95,11 +95,52 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
                 for b in loader:
                     yield _to_dev(b, dev)
 
+    val_loader = None
+    if not synthetic and dataset_config.get("val") and os.path.exists(dataset_config["val"]):
+        vdf = pd.read_csv(dataset_config["val"], delimiter="|", quoting=csv.QUOTE_NONE, engine="c")
+        vdesc = None
+        if extensions_config["descriptions"].get("bert_embeddings"):
+            vdesc = [None if (isinstance(x, float)) else x for x in vdf.description_embedding]
+        vds = TTSDataset(filenames=list(vdf.wav), texts=list(vdf.text), base_dir=speech_dir,
+                         speaker_ids=list(vdf.speaker_id) if kw["speaker_tokens"] else None,
+                         features=vdf[extensions_config["controls"]["features"]].values.tolist() if kw.get("controls") else None,
+                         cache_dir=os.path.join(results_dir, "mel_cache"), description_embeddings=vdesc, device=dev,
+                         **dataset_config["preprocessing"])
+        val_loader = TTSDataLoader(vds, batch_size=min(64, max(2, len(vds))), shuffle=False, drop_last=False)   # run/train.py:160-168
+
+    def validate():
+        """The reference's validation pass (run/train.py:160-168, model/tts_model.py:204-253): teacher-forced forward in eval
+        mode over the validation manifest, mean of the per-batch validation losses."""
+        model.eval()
+        tot, n = 0.0, 0
+        for vb in val_loader:
+            data, meta, extra = vb
+            data = {k: v.to(dev) for k, v in data.items()}
+            meta = {k: v.to(dev) for k, v in meta.items()}
+            data["mel_spectrogram"] = data["mel_spectrogram"].float().contiguous()
+            out = model.validation_step((data, meta, extra), n)
+            tot += float(out["loss"]); n += 1
+        model.train()
+        return tot / max(n, 1)
+
+    # checkpoint / validation cadence: Lightning checkpoints at the end of every epoch and validates every
+    # `val_check_interval` (int: steps, float: fraction of an epoch; fine-tuning forces 1.0, run/train.py:112)
+    steps_per_epoch = max(1, len(loader)) if not synthetic else int(training_config["args"].get("checkpoint_every_n_steps", 1000))
+    vci = 1.0 if finetune else training_config["args"].get("val_check_interval", 1.0)
+    val_every = int(vci) if isinstance(vci, int) and not isinstance(vci, bool) else max(1, int(round(float(vci) * steps_per_epoch)))
+    ckpt_every = int(training_config["args"].get("checkpoint_every_n_steps", steps_per_epoch))
+
+    def save(path, step):
+        from ..checkpoint import lightning_checkpoint, save_atomic
+        save_atomic(lightning_checkpoint(model, tr, epoch=step // steps_per_epoch), path)
+
     t0, frames = time.time(), 0
     it = batches()
+    steps_done = 0
     for step in range(start_step, max_steps):
         batch = next(it)
         loss3, _ = tr.train_step(batch)
+        steps_done += 1
         frames += int(batch["mel_spectrogram_len"].sum())
         if rank == 0 and (step % 50 == 0 or step == max_steps - 1):
             l = [float(x) for x in loss3.cpu()]
@@ -107,13 +148,17 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
             print(f"step {step + 1}/{max_steps} training_gate_loss {l[0]:.5f} training_mel_loss {l[1]:.5f} "
                   f"training_mel_post_loss {l[2]:.5f} training_loss {sum(l):.5f} lr {tr.lr_at(step):.2e} "
                   f"{frames * world / max(dt, 1e-9):.0f} mel-frames/s", flush=True)
+        if val_loader is not None and (step + 1) % val_every == 0:
+            vl = validate()                       # every rank runs it (keeps the ranks in step); rank 0 reports
+            if rank == 0:
+                print(f"step {step + 1}/{max_steps} validation_loss {vl:.5f}", flush=True)
+        if rank == 0 and (step + 1) % ckpt_every == 0 and step + 1 < max_steps:
+            save(os.path.join(results_dir, "last.ckpt"), step + 1)
     if rank == 0:
-        ck = model.checkpoint(extra=dict(global_step=tr.global_step,
-                                         t2_optimizer=dict(exp_avg=tr.ps.exp_avg.cpu(), exp_avg_sq=tr.ps.exp_avg_sq.cpu())
-                                         if tr.ps.exp_avg is not None else {}))
         path = os.path.join(results_dir, "finetuned.ckpt" if finetune else "final.ckpt")
-        torch.save(ck, path)
-        print(f"saved {path}")
+        save(path, max_steps)
+        print(f"saved {path} ({steps_done} optimiser steps this run, global_step {tr.global_step})")
     if world > 1:
         dist.barrier()
+    model.steps_done = steps_done
     return model

@@ -33,6 +33,25 @@ class Trainer:
         self.rank = dist.get_rank() if self.world > 1 else 0
         self.frozen: set = set()   # parameter names excluded from updates (fine-tuning, run/train.py:229-233)
 
+    def trainable_ranges(self):
+        """[start, end) element ranges of the flat buffer that the optimizer updates: everything except the frozen tensors
+        (adjacent ranges merged; alignment padding between tensors carries zeros and may be included)."""
+        ps = self.ps
+        if not self.frozen:
+            return [(0, ps.numel)]
+        names = list(ps.offsets)
+        ranges = []
+        for i, name in enumerate(names):
+            if name in self.frozen:
+                continue
+            a = ps.offsets[name]
+            b = ps.offsets[names[i + 1]] if i + 1 < len(names) else ps.numel
+            if ranges and ranges[-1][1] == a:
+                ranges[-1] = (ranges[-1][0], b)
+            else:
+                ranges.append((a, b))
+        return ranges
+
     def lr_at(self, step: int) -> float:
         """MultiStepLR(gamma=0.1), stepped once per optimiser step (model/tts_model.py:83-88)."""
         return self.base_lr * (0.1 ** sum(1 for m in self.milestones if step >= m))
@@ -75,12 +94,14 @@ class Trainer:
         if self.world > 1:
             dist.all_reduce(ps.grad)              # ONE flat fp32 buffer over RCCL/xGMI
             eng.mark("allreduce")
-        saved = {name: ps.P[name].clone() for name in self.frozen}   # frozen tensors take no update at all
+        # Frozen tensors (requires_grad=False in the reference: grad None) take no part in the step: their gradients are
+        # excluded from the global-norm clip (Lightning's clip_grad_norm_ skips them) and neither the parameters nor their
+        # Adam moments move (torch.optim.Adam skips parameters without a gradient; no L2 term either).
+        for name in self.frozen:
+            ps.G[name].zero_()
         self.global_step += 1
         # MultiStepLR: the k-th optimiser step (k = global_step, 1-based) runs after k-1 scheduler steps
         eng.adam_step(self.global_step, self.lr_at(self.global_step - 1), self.weight_decay, self.max_norm,
-                      grad_scale=1.0 / self.world)
-        for name, v in saved.items():
-            ps.P[name].copy_(v)
+                      grad_scale=1.0 / self.world, ranges=self.trainable_ranges() if self.frozen else None)
         eng.mark("optimizer")
         return loss3, outs

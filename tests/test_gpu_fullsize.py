@@ -1,0 +1,208 @@
+"""Oracle parity at PRODUCTION dims (vanilla-lj-hifi: E=512, prenet 256, H=1024, Ad=128, postnet 512, 80 mels), the
+configuration bench.py measures.  The CPU oracle (oracle/tacotron2_ref.py, pinned to the reference's golden vectors)
+runs the same seeded inputs at batch / sequence sizes it finishes in seconds; the HIP path goes through the C ABI.
+
+Tolerances: mel L1 < 1e-4 (north_star) on mels / mels_post, alignments max-abs < 2e-5, loss 2e-5 relative, every
+parameter gradient < 3e-4 relative to the tensor's scale (tests/test_gpu_model.py::_grad_check), BatchNorm running
+statistics max-abs < 1e-5.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tacotron2_ref as R  # noqa: E402
+from tests.test_gpu_model import (MEL_L1_TOL, _dev, _grad_check, build_engine, l1, masks_to_device, mx,  # noqa: E402
+                                  random_case)
+
+
+def _ragged_case(d, B, L, T, seed, dev):
+    ci, lens, mel, tl, gate, masks = random_case(d, B, L, T, seed, dev)
+    return ci, lens, mel, tl, gate, masks
+
+
+def _oracle_train(P, d, ci, lens, mel, tl, gate, masks, **kw):
+    Pc = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not R.is_buffer(k)) else v.clone())
+          for k, v in P.items()}
+    new_stats = {}
+    o = R.tacotron2_fwd(Pc, d, ci, lens, True, mel, tl, training=True, masks=masks, new_stats=new_stats, **kw)
+    loss = R.tts_loss(o[0], o[1], o[2], mel, gate)[0]
+    names = [k for k, v in Pc.items() if v.requires_grad]
+    grads = torch.autograd.grad(loss, [Pc[k] for k in names])
+    return [x.detach() for x in o], float(loss), dict(zip(names, grads)), new_stats
+
+
+def _hip_train_and_compare(d, P, case, dev, kw_cpu=None, kw_dev=None, grad_tol=3e-4):
+    ci, lens, mel, tl, gate, masks = case
+    ref, loss, grads, new_stats = _oracle_train(P, d, ci, lens, mel, tl, gate, masks, **(kw_cpu or {}))
+    eng, ps = build_engine(d, P, dev)
+    outs, ctx = eng.forward_tf(ci.to(dev), lens.to(dev), mel.to(dev), tl.to(dev), training=True,
+                               masks=masks_to_device(masks, dev), **(kw_dev or {}))
+    ps.grad.zero_()
+    loss3 = eng.loss_and_grads(outs, ctx, mel.to(dev), gate.to(dev))
+    torch.cuda.synchronize()
+    assert l1(outs[0], ref[0]) < MEL_L1_TOL and l1(outs[1], ref[1]) < MEL_L1_TOL, (l1(outs[0], ref[0]), l1(outs[1], ref[1]))
+    assert mx(outs[0], ref[0]) < 1e-3 and mx(outs[1], ref[1]) < 2e-3
+    assert mx(outs[3], ref[3]) < 2e-5
+    assert ((outs[2].cpu() == -1000.0) == (ref[2] == -1000.0)).all()
+    assert abs(float(loss3.sum()) - loss) < 2e-5 * max(1.0, abs(loss))
+    _grad_check(ps, grads, tol=grad_tol)
+    sd = ps.state_dict()
+    for k, v in new_stats.items():
+        if not k.endswith("num_batches_tracked"):
+            assert mx(sd[k], v) < 1e-5, k
+    return eng, ps
+
+
+@pytest.mark.parametrize("B,L,T", [(3, 32, 16), (17, 29, 13)])
+def test_vanilla_dims_train_step_matches_oracle(B, L, T):
+    """configs[1] dims: forward outputs, loss, EVERY parameter gradient and the BN running statistics, ragged text and
+    frame lengths; B = 17 spans two 16-row MFMA tiles of the step kernels."""
+    dev = _dev()
+    d = R.default_dims(speaker_tokens=True, num_speakers=4)       # vanilla-lj-hifi-stop.json: 4 speaker tokens
+    P = R.init_params(d, seed=40 + B)
+    case = _ragged_case(d, B, L, T, 500 + B, dev)
+    spk = torch.randint(0, 4, (B,), generator=torch.Generator().manual_seed(B), dtype=torch.int32)
+    _hip_train_and_compare(d, P, case, dev, kw_cpu=dict(speaker_id=spk), kw_dev=dict(speaker_id=spk.to(dev)))
+
+
+def test_descriptions_libritts_dims_train_step_matches_oracle():
+    """configs[3] dims: description embeddings (768 -> 128, E' = 640) + 562 speaker tokens."""
+    dev = _dev()
+    d = R.default_dims(speaker_tokens=True, num_speakers=562, description_embeddings=True, description_embeddings_dim=768)
+    P = R.init_params(d, seed=71)
+    B = 5
+    case = _ragged_case(d, B, 27, 12, 571, dev)
+    g = torch.Generator().manual_seed(9)
+    spk = torch.randint(0, 562, (B,), generator=g, dtype=torch.int32)
+    spk[1] = spk[0]                                              # two utterances of one speaker: the embedding gradient accumulates
+    desc = torch.randn(B, 768, generator=g)
+    _hip_train_and_compare(d, P, case, dev, kw_cpu=dict(speaker_id=spk, description_embeddings=desc),
+                           kw_dev=dict(speaker_id=spk.to(dev), description_embeddings=desc.to(dev)))
+
+
+def test_vanilla_dims_chunked_pipeline_matches_oracle():
+    """The same production-dims step with the frame loop cut into several pipeline chunks (chunk 5 forward / 4 backward),
+    so the chunked co-scheduled forward and the two-stream backward are exercised at H = 1024 against the oracle."""
+    dev = _dev()
+    d = R.default_dims()
+    P = R.init_params(d, seed=3)
+    B, L, T = 4, 24, 14
+    ci, lens, mel, tl, gate, masks = _ragged_case(d, B, L, T, 77, dev)
+    ref, loss, grads, _ = _oracle_train(P, d, ci, lens, mel, tl, gate, masks)
+    eng, ps = build_engine(d, P, dev)
+    eng.chunk, eng.chunk_bwd = 5, 4
+    outs, ctx = eng.forward_tf(ci.to(dev), lens.to(dev), mel.to(dev), tl.to(dev), training=True, masks=masks_to_device(masks, dev))
+    ps.grad.zero_()
+    loss3 = eng.loss_and_grads(outs, ctx, mel.to(dev), gate.to(dev))
+    torch.cuda.synchronize()
+    assert l1(outs[0], ref[0]) < MEL_L1_TOL and l1(outs[1], ref[1]) < MEL_L1_TOL and mx(outs[3], ref[3]) < 2e-5
+    assert abs(float(loss3.sum()) - loss) < 2e-5 * max(1.0, abs(loss))
+    _grad_check(ps, grads)
+
+
+def test_vanilla_dims_batch64_inference_matches_oracle():
+    """configs[4]: autoregressive decoding of 64 variable-length utterances at production dims, ~10 frames, prenet
+    dropout masks replayed, stop-logit bias nudged so utterances stop at different frames; frame count, masked tails,
+    lengths and outputs against the oracle."""
+    dev = _dev()
+    d = R.default_dims(speaker_tokens=True, num_speakers=4)
+    P = R.init_params(d, seed=64)
+    P["decoder.gate.weight"] = P["decoder.gate.weight"] * 8.0      # stop logits cross zero at different frames (min |logit| 6e-4)
+    g = torch.Generator().manual_seed(64)
+    B, L, N = 64, 40, 10
+    lens = torch.randint(9, L + 1, (B,), generator=g); lens[0] = L
+    ci = torch.zeros(B, L, dtype=torch.int64)
+    for b in range(B):
+        ci[b, :lens[b]] = torch.randint(1, 40, (int(lens[b]),), generator=g)
+    spk = torch.randint(0, 4, (B,), generator=g, dtype=torch.int32)
+    pm = (torch.rand(N + 1, 2, B, 256, generator=g) >= 0.5).float() * 2
+    masks = dict(prenet_drop=[[pm[i, 0], pm[i, 1]] for i in range(N + 1)])
+    trace = {}
+    with torch.no_grad():
+        ref = R.tacotron2_fwd(P, d, ci, lens, False, speaker_id=spk, max_len_override=N, training=False, masks=masks, trace=trace)
+    eng, ps = build_engine(d, P, dev)
+    mels, post, gates, al, lengths = eng.infer(ci.to(dev), lens.to(dev), N, speaker_id=spk.to(dev),
+                                               prenet_masks=pm.to(dev).contiguous(), check_every=4)
+    torch.cuda.synchronize()
+    assert mels.shape == ref[0].shape, (mels.shape, ref[0].shape)
+    # the stop rule must have produced ragged lengths for this test to mean anything
+    assert len(set(trace["lengths"].tolist())) > 1, trace["lengths"]
+    assert (lengths.cpu() == trace["lengths"]).all()
+    assert l1(mels, ref[0]) < MEL_L1_TOL and l1(post, ref[1]) < MEL_L1_TOL
+    assert mx(al, ref[3]) < 5e-5
+    assert ((gates.cpu() == -1000.0) == (ref[2] == -1000.0)).all()
+    # bit-reproducible: the same call twice gives identical bits (no order-dependent reductions on the stop path)
+    mels2, post2, gates2, al2, lengths2 = eng.infer(ci.to(dev), lens.to(dev), N, speaker_id=spk.to(dev),
+                                                    prenet_masks=pm.to(dev).contiguous(), check_every=4)
+    torch.cuda.synchronize()
+    assert torch.equal(mels, mels2) and torch.equal(gates, gates2) and torch.equal(lengths, lengths2)
+
+
+def _bn_ref64(x, gamma, beta, act, drop, eps=1e-5):
+    """float64 BatchNorm1d (training statistics over all rows) + activation + dropout mask, with autograd."""
+    mean = x.mean(0)
+    var = x.var(0, unbiased=False)
+    y = (x - mean) / torch.sqrt(var + eps) * gamma + beta
+    if act == 1:
+        y = torch.relu(y)
+    elif act == 2:
+        y = torch.tanh(y)
+    return y * drop, mean, var
+
+
+@pytest.mark.parametrize("act", [1, 2])
+def test_batchnorm_28k_rows_offset_input_matches_float64(act):
+    """t2_bn_fwd / t2_bn_bwd at the bench's row count (B*T = 32*872 = 27,904 rows, C = 512) on an input with a large
+    mean (-5.5, the log-mel level) and small spread: the variance must not lose digits to E[x^2] - E[x]^2 cancellation."""
+    from tacotron2_amd._lib import call, make
+    dev = _dev()
+    B, L, C = 32, 872, 512
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(B, L, C, generator=g) * 0.25 - 5.5)
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.1
+    drop = (torch.rand(B, L, C, generator=g) >= 0.5).float() * 2
+    dy = torch.randn(B, L, C, generator=g) * 0.01
+    x64 = x.double().reshape(B * L, C).requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y64, mean64, var64 = _bn_ref64(x64, g64, b64, act, drop.double().reshape(B * L, C))
+    (y64 * dy.double().reshape(B * L, C)).sum().backward()
+
+    Lp = L + 4
+    xp = torch.zeros(B, Lp, C, device=dev)          # raw conv output in shifted row layout: row b*Lp + l
+    xp_rows = xp.view(B * Lp, C)
+    for b in range(B):
+        xp_rows[b * Lp: b * Lp + L] = x[b].to(dev)
+    y = torch.empty(B, Lp, C, device=dev)
+    mean = torch.empty(C, device=dev); invstd = torch.empty(C, device=dev)
+    sums = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    gam, bet, drp = gamma.to(dev), beta.to(dev), drop.to(dev).contiguous()
+    st = torch.cuda.current_stream().cuda_stream
+    bn = make("T2Bn", B=B, L=L, C=C, x=xp, Lp_x=Lp, gamma=gam, beta=bet, running_mean=rm, running_var=rv, training=1,
+              momentum=0.1, eps=1e-5, sums=sums, mean=mean, invstd=invstd, act=act, drop=drp, y=y, Lp_y=Lp, pad_y=2)
+    call("t2_bn_fwd", bn, st)
+    torch.cuda.synchronize()
+    n = B * L
+    assert mx(mean, mean64.detach()) < 2e-6
+    rel_istd = ((invstd.double().cpu() - 1 / torch.sqrt(var64.detach() + 1e-5)).abs() * torch.sqrt(var64.detach() + 1e-5)).max()
+    assert float(rel_istd) < 2e-5, float(rel_istd)
+    assert mx(rm, 0.1 * mean64.detach()) < 1e-6
+    assert mx(rv, 0.9 + 0.1 * var64.detach() * n / (n - 1)) < 1e-6
+    got = y[:, 2:2 + L].reshape(n, C)
+    assert mx(got, y64.detach()) < 5e-4 and l1(got, y64.detach()) < 2e-5
+    assert float(y[:, :2].abs().max()) == 0.0 and float(y[:, 2 + L:].abs().max()) == 0.0
+    # backward
+    dyd = dy.to(dev).contiguous()
+    dx = torch.empty(B, Lp, C, device=dev)
+    dgam, dbet = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    bnb = make("T2Bn", B=B, L=L, C=C, x=xp, Lp_x=Lp, gamma=gam, beta=bet, training=1, momentum=0.1, eps=1e-5, sums=sums,
+               mean=mean, invstd=invstd, act=act, drop=drp, dy=dyd, Lp_dy=L, pad_dy=0, dx=dx, Lp_dx=Lp, pad_dx=2,
+               dgamma=dgam, dbeta=dbet)
+    call("t2_bn_bwd", bnb, st)
+    torch.cuda.synchronize()
+    rel = lambda a, r: float((a.double().cpu() - r).abs().max() / r.abs().max())
+    assert rel(dgam, g64.grad) < 1e-4 and rel(dbet, b64.grad) < 1e-4, (rel(dgam, g64.grad), rel(dbet, b64.grad))
+    assert rel(dx[:, 2:2 + L].reshape(n, C), x64.grad) < 3e-4
