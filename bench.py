@@ -37,6 +37,14 @@ def decoder_step_bytes(B, L, Ef, P=256, A=1024, D=1024, Ad=128, M=80, F=32, Kl=3
     return 4 * w + B * (r + wr)
 
 
+def decoder_step_flops(B, L, Ef, P=256, A=1024, D=1024, Ad=128, M=80, F=32, Kl=31):
+    """Algorithmic flops of ONE autoregressive decoder step for B utterances (38.4 MFLOP per sample at
+    L = 160 + the prenet): both LSTM cells, query projection, location conv + dense, energies, context, mel/stop projection."""
+    per = (2 * 4 * A * (P + Ef + A) + 2 * 4 * D * (A + Ef + D) + 2 * A * Ad + L * (2 * 2 * Kl * F + 2 * F * Ad + 5 * Ad)
+           + 2 * L * Ef + 2 * (D + Ef) * (M + 1) + 2 * (M * P + P * P))
+    return B * per
+
+
 def cpu_baseline(dims, batch, t_cap, b_cap):
     """Oracle (CPU restatement pinned to the reference, oracle/tacotron2_ref.py) timed on this host's cores on a bounded
     sample of the same workload: the first b_cap utterances, frames capped at t_cap, one fwd+loss+bwd+Adam step."""
@@ -173,12 +181,26 @@ def main():
         eng.infer(ci, cl, 32, speaker_id=spk, training=False, seed=1)           # warm-up
         torch.cuda.synchronize()
         n_dec = 860     # a fixed 860 steps per utterance with the stop checks live
+        eng.profile = True; eng.marks = []; eng.spans = []
+        eng.mark("inf.start")
         t1 = time.perf_counter()
         eng.infer(ci, cl, n_dec, speaker_id=spk, training=False, seed=2, check_every=64)
         torch.cuda.synchronize()
         ddt = time.perf_counter() - t1
+        eng.profile = False
+        loop_ms = eng.segment_times_ms().get("inf.frame_loop", 0.0)      # HIP events around the frame loop only
+        Ld = int(ci.shape[1])
+        us_step = loop_ms * 1e3 / n_dec
+        gbs = decoder_step_bytes(64, Ld, 512) / (us_step * 1e-6) / 1e9 if us_step > 0 else 0.0
+        tfs = decoder_step_flops(64, Ld, 512) / (us_step * 1e-6) / 1e12 if us_step > 0 else 0.0
         decode = dict(decode_steps_per_s=n_dec / ddt, utterance_frames_per_s=64 * n_dec / ddt, batch=64, frames=n_dec,
-                      L=int(ci.shape[1]), note="includes encoder, conditioning and postnet of the call")
+                      L=Ld, launches_per_frame=6, note="decode_steps_per_s includes encoder, conditioning and postnet of the call",
+                      frame_loop_us_per_step=us_step, frame_loop_steps_per_s=1e6 / us_step if us_step > 0 else None,
+                      roofline=dict(bound="mfma", kernel="autoregressive decoder step, 64 utterances (6 launches / frame)",
+                                    achieved=tfs, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=tfs / MFMA_F32_PEAK_TFLOPS,
+                                    hbm_achieved_GBs=gbs, hbm_frac=gbs / HBM_PEAK_GBS,
+                                    algorithmic_bytes_per_step=decoder_step_bytes(64, Ld, 512),
+                                    algorithmic_flops_per_step=decoder_step_flops(64, Ld, 512)))
 
     if rank == 0:
         Ef = 512

@@ -61,6 +61,9 @@ typedef struct {
     int batch; int64_t sA, sB, sC;
     int share_cu;                    /* hint: 1 = keep ONE workgroup per CU (extra dynamic LDS), leaving LDS for the small kernels
                                         of a concurrent stream; two 73 KB workgroups per CU otherwise lock them out */
+    int native_fp32;                 /* 0 (default): fp32 result on the bf16 matrix pipe by error-free 3-way operand splitting
+                                        (6 exact bf16 products per element pair, two fp32 accumulators; csrc/t2_gemm.hip);
+                                        1: v_mfma_f32_32x32x2_f32 (f32-input MFMA, 1/16 of the bf16 rate) */
 } T2Gemm;
 int t2_gemm(const T2Gemm* g, void* stream);
 
@@ -116,12 +119,6 @@ typedef struct {
     int64_t xt, ht_out;
 } T2LstmStride;
 int t2_lstm_seq_fwd(const T2LstmStep* base, const T2LstmStride* inc, int n, int S, void* stream);
-/* Planned variant (see T2AttnSeq.plan): the operand blocks of all S steps are written into a host table, the caller keeps a
- * device copy, and t2_lstm_seq_fwd_run launches steps [s_begin, s_end) with (table, step index) as the only arguments.
- * `base` supplies the launch geometry (B, H, K); packed single-segment path, B <= 64. */
-int64_t t2_lstm_seq_fwd_plan(const T2LstmStep* base, const T2LstmStride* inc, int n, int S, void* host_tab, int64_t host_bytes);
-int t2_lstm_seq_fwd_run(const void* dev_tab, const T2LstmStep* base, int n, int s_begin, int s_end, void* stream);
-
 /* One step of back-propagation through time for an LSTM cell (autograd of the cells above):
  *   dx[b][u] = sum_n dg_next[b][n] * W[n*ldw + u]          (n over N4 = 4H' rows of the producing cell)
  *   epi = 0: dx_out = dx + ext1 + ext2                      (gradient w.r.t. a non-recurrent input slice)
@@ -154,9 +151,6 @@ typedef struct { int64_t dg, dg2, ext1, ext2, drop, gates, c_prev, c_cur; int dt
 /* S steps; every pointer advances by its stride each step.  The caller lays the dgates stash out with one extra
  * zero-filled slot so that base[i].dg_next (the slot 'after' the first processed step) is valid and zero. */
 int t2_lstm_seq_bwd(const T2LstmBwdStep* base, const T2LstmBwdStride* inc, int n, int S, void* stream);
-int64_t t2_lstm_seq_bwd_plan(const T2LstmBwdStep* base, const T2LstmBwdStride* inc, int n, int S, void* host_tab,
-                             int64_t host_bytes);
-int t2_lstm_seq_bwd_run(const void* dev_tab, const T2LstmBwdStep* base, int n, int s_begin, int s_end, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Location-sensitive attention, one frame (model/attention.py:52-69 + cumulative update model/decoder.py:78-90).
@@ -207,27 +201,15 @@ typedef struct {
     float* xdec_t;                   /* optional (with wpacked): x16-tiled copy of xdec, [T+1][(A+Ef)/16][Bp][16], slot 0
                                         zero-filled by the caller; the attention-LSTM step then reads its input from it */
     /* Optional co-scheduled recurrence: step i of an independent LSTM sequence (the decoder LSTM of an EARLIER chunk of
-     * frames, whose hoisted input projection is already computed) runs INSIDE the attention-context launch of frame
-     * t_begin+i (heterogeneous launch: extra workgroups next to the context workgroups).  Dependent launches cost ~2.7 us +
+     * frames, whose hoisted input projection is already computed) runs INSIDE the attention-energies launch of frame
+     * t_begin+i (heterogeneous launch: extra workgroups next to the energies workgroups).  Dependent launches cost ~1.7 us +
      * a memory round trip each and kernels of two streams do not overlap at this size; a cell step (MFMA + weight
-     * stream) next to the latency-bound context kernel uses otherwise idle pipes.  Needs the packed single-segment path and
+     * stream) next to the latency-bound energies kernel uses otherwise idle pipes.  Needs the packed single-segment path and
      * co_step->B <= 32 (else, and for steps beyond the frame range, the steps run as plain launches). */
     const T2LstmStep* co_step; const T2LstmStride* co_inc; int co_steps;
-    int co_host;                     /* where the co-scheduled step rides: 0 = context launch, 1 = energies launch, 2 = its
-                                        workgroups split between the two (by-value launches only) */
-    /* Optional kernel-parameter tables ("plan").  Every launch of the chain otherwise carries a 230-600 byte by-value
-     * operand block; a dependent launch costs 2.8 us with a 16-byte block and 3.4-3.7 us with 260-520 bytes
-     * (tools/ubench_kernarg.hip), so the blocks of all T frames are written ONCE into a table:
-     *   bytes = t2_attn_seq_fwd_plan(a, NULL, 0);  t2_attn_seq_fwd_plan(a, host_buffer, bytes);   (host side only)
-     * the caller copies the table to device memory that no kernel writes and sets `plan` to the device copy; launches
-     * then pass (table, frame index).  The plan covers all frames whatever t_begin/t_end were; with a plan the co-scheduled
-     * sequence is described once for the whole chain: co step i rides frame co_first + i (steps that would ride frames
-     * >= T are left to the caller).  The table must be rebuilt whenever any pointer or dimension changes. */
-    const void* plan; int co_first;
     uint64_t* clk;                   /* diagnostic (T2AttnStep.clk), normally NULL */
 } T2AttnSeq;
 int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream);
-int64_t t2_attn_seq_fwd_plan(const T2AttnSeq* a, void* host_tab, int64_t host_bytes);   /* bytes required / written, -1 on error */
 
 /* Back-propagation through the attention chain, frames T-1 .. 0 (autograd of t2_attn_seq_fwd), 4 launches / frame:
  *   one launch for both products of dgates[t+1] (dctx_tot[t] = dctx_ext1[t] + dctx_ext2[t] + dgates[t+1].W_ih_ctx and
@@ -256,11 +238,6 @@ typedef struct {
     int t_hi, t_lo;                  /* frames t_hi-1 .. t_lo of this call (descending); 0,0 = T-1 .. 0 */
     float* dgates_t;                 /* optional x16-tiled copy of the dgates part of Z: [T+1][4A/16][Bp][16], slot T
                                         zero-filled by the caller; read by the per-frame products of dgates[t+1] */
-    /* Optional co-scheduled recurrence (see T2AttnSeq.co_step): BPTT step i of an independent LSTM (the decoder LSTM of the
-     * NEXT-lower chunk of frames) runs INSIDE the attention-ds launch of frame t_hi-1-i (extra workgroups in the same
-     * launch; the ds workgroups are VALU/LDS bound, the step MFMA/memory bound).  Needs the packed path (wtpacked, dg_next,
-     * no second segment); otherwise, and for steps beyond the frame range, the steps run as plain launches. */
-    const T2LstmBwdStep* co_step; const T2LstmBwdStride* co_inc; int co_steps;
     uint64_t* clk;                   /* diagnostic, normally NULL: 32 device words, s_memtime stamps of workgroup (0,0) at phase
                                         boundaries of the dw kernel [16..19] and the ds kernel [24..30] */
 } T2AttnSeqBwd;
@@ -284,7 +261,12 @@ int t2_unpack_conv_wgrad(const float* gp, float* g, int Co, int Ci, int K, void*
  * stats updated with momentum (unbiased variance), exactly nn.BatchNorm1d; eval: running statistics.
  * forward  (t2_bn_fwd): y[b][pad_y + l][c] = mask(act(bn(x))*drop + res); pad rows of y are zero-filled.
  * backward (t2_bn_bwd): dx (grad w.r.t. x, written at rows b*Lp_dx + pad_dx + l, other rows zero), dgamma/dbeta +=.
- * act: 0 none, 1 relu, 2 tanh.  sums: workspace of 2*C doubles. */
+ * act: 0 none, 1 relu, 2 tanh.  sums: workspace of 2*C + 2 doubles (two sums per channel, then the row count they cover).
+ * Synchronised statistics over data-parallel ranks (model/encoder.py:41, model/postnet.py:16,30,44 see the WHOLE batch in the
+ * single-device reference): phase 1 = accumulate the sums only, the caller all-reduces `sums` (count included), phase 2 =
+ * finalize + apply from the reduced sums; `shift` [C] must then be a rank-independent shift of the statistics sums (the
+ * running mean), and in the backward `grad_share` = 1/world scales this rank's dgamma/dbeta contribution (the gradient
+ * all-reduce adds the ranks' shares).  phase 0 / shift NULL / grad_share 0 = single-device behaviour. */
 typedef struct {
     int B, L, C;
     const float* x; int Lp_x;
@@ -301,6 +283,7 @@ typedef struct {
     const float* dy; int Lp_dy, pad_dy;
     float* dx; int Lp_dx, pad_dx;
     float* dgamma; float* dbeta;
+    int phase; const float* shift; float grad_share;
 } T2Bn;
 int t2_bn_fwd(const T2Bn* s, void* stream);
 int t2_bn_bwd(const T2Bn* s, void* stream);
@@ -330,35 +313,46 @@ int t2_tanh_bwd(const float* g, const float* y, float* out, int64_t n, void* str
 /* ------------------------------------------------------------------------------------------------
  * Autoregressive decoding: forward(teacher_forcing=False, max_len_override=N) of model/tacotron2.py:262-325.
  *   t2_linear_rows  out[b][n] = act(x[b][:] . w[n][:] + bias[n]) * mask[b][n]   (nn.Linear on <= batch rows; K % 16 == 0)
- *   t2_decoder_infer runs frames [t0, t1) with no host synchronisation: state[0] = all-done flag, state[1] = number of
- *   emitted frames, done [B] int32, lengths [B] int64 (counts every frame whose stop logit is >= 0, Appendix C.4).
+ *   t2_decoder_infer runs frames [t0, t1) of one group of <= 64 utterances with no host synchronisation, 6 launches per
+ *   frame: state[0] = "every utterance of the group has stopped" (sticky), state[1] = frames emitted, done [B] int32.
+ *   The first prenet layer is folded onto the mel projection (two linear maps with nothing in between):
+ *     W_comb [(P+M+1)][D+Ef] = [W_pre1 . W_mel ; W_mel ; W_gate],  b_comb [(P+M+1)] = [W_pre1 . b_mel ; b_mel ; b_gate],
+ *     row_comb (optional) [B][P+M+1] = per-utterance term of the prosody controls ([W_pre1 . cmel_b ; cmel_b ; 0])
+ *   (built by the caller with t2_gemm once per call), so frame t's first launch yields p1_t AND the outputs of frame t-1
+ *   from xproj_{t-1}, every sum in a fixed order (bit-reproducible stop decisions).
+ *   t2_stop_scan derives the reference's break frame and `lengths` (model/tacotron2.py:319-322: counts every emitted frame
+ *   whose stop logit is >= 0, Appendix C.4) from the stored logits of all groups, so groups may be decoded a few frames past
+ *   the break (the host looks at state[0] only now and then; with several groups all run until ALL have stopped, exactly as
+ *   the reference's single loop over the whole batch does).
  * Buffers: xs [2][(P+A+Ef+D)/16][Bp][16] = the recurrent state in the x16-tiled layout of T2LstmStep.xt, columns
  * [prenet_out | att_h | ctx | dec_h], two ping-pong slots, zero-filled by the caller (P, A, Ef, D multiples of 16);
- * att_h [B][A] and xproj [B][D+Ef] = [dec_h | ctx] row-major copies; p1, p2 [B][P] prenet activations;
+ * att_h [B][A] and xproj [B][D+Ef] = [dec_h | ctx] row-major copies; p1 [B][P] prenet scratch;
  * att_c [2][B][A], dec_c [2][B][D], cum [2][B][L] (ping-pong, slot 0 zero-filled by the caller);
- * proj [Tcap][B][ld_proj] (cols 0..M-1 mel, col M stop logit; ld_proj % 4 == 0), ZERO-FILLED by the caller (the projection
- * accumulates K slices atomically); align [B][Tcap][L]; prenet_mask [Tcap][2][B][P] or NULL;
+ * proj [Tcap][B][ld_proj] (cols 0..M-1 mel, col M stop logit; row t is written by the first launch of frame t+1 or by the
+ * call's tail); align [B][Tcap][L]; prenet_mask [frames][2][B][P] or NULL (frame 0's masks are never read);
  * wp_att = t2_lstm_pack_fwd of the attention-LSTM weights in the column order [prenet | att_h | ctx],
  * wp_dec = t2_lstm_pack_fwd of the decoder-LSTM weights in the column order [att_h | ctx | dec_h]. */
 int t2_linear_rows(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* mask,
                    int64_t ldmask, int relu, float* out, int64_t ldo, int B, int N, int K, void* stream);
 typedef struct {
     int B, L, A, D, Ef, Ad, P, M, Kl, Tcap;
-    const float* W_pre1; const float* W_pre2;
+    const float* W_comb; const float* b_comb; const float* row_comb;
+    const float* W_pre2;
     const float* wp_att; const float* b_att_ih; const float* b_att_hh;
     const float* wp_dec; const float* b_dec_ih; const float* b_dec_hh;
     const float* Wq; const float* U; const float* v;
-    const float* W_proj; const float* b_proj;
     const float* pmT; const float* memory; const int32_t* len;
-    const float* prenet_mask; const float* zero_frame;
-    float* xs; float* att_h; float* att_c; float* dec_c; float* cum; float* xproj; float* p1; float* p2; float* e_part;
+    const float* prenet_mask;
+    float* xs; float* att_h; float* att_c; float* dec_c; float* cum; float* xproj; float* p1; float* e_part;
     float* proj; int64_t ld_proj; float* align;
-    int32_t* done; int64_t* lengths; int32_t* state;
+    int32_t* done; int32_t* state;
     const float* dec_pre;            /* optional [B][4D]: per-utterance term added to the decoder-LSTM pre-activations of
-                                        every frame (controls . W_ih[:, A+Ef:]^T, model/decoder.py:94-99); the matching mel
-                                        term is pre-filled into proj by the caller instead of zeros */
+                                        every frame (controls . W_ih[:, A+Ef:]^T, model/decoder.py:94-99) */
 } T2Infer;
 int t2_decoder_infer(const T2Infer* a, int t0, int t1, void* stream);
+/* proj[g] [nframes][Bg[g]][ld_proj] for g < ngroups (<= 8) -> lengths [sum Bg] int64, out2 = {frames emitted n, 0} */
+typedef struct { const float* proj[8]; int Bg[8]; int ngroups; int64_t ld_proj; int M, nframes; } T2StopScan;
+int t2_stop_scan(const T2StopScan* s, int64_t* lengths, int32_t* out2, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Log-mel front-end (datasets/tts_dataset.py:166-168,204; definition restated from datasets/prosody_dataset.py:39-50,67):

@@ -145,7 +145,8 @@ def make(struct_name: str, **kw):
         fld = getattr(st, k)
         if isinstance(fld, C.Array):
             for i, item in enumerate(v):
-                fld[i] = item
+                fld[i] = item.data_ptr() if hasattr(item, "data_ptr") else item
+            st._keep += [item for item in v if hasattr(item, "data_ptr")]
         else:
             setattr(st, k, _addr(v) if (hasattr(v, "data_ptr") or v is None) else v)
     return st

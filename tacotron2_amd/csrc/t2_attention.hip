@@ -22,8 +22,6 @@ int t2_lstm_step_fwd_launch(const T2LstmStep* steps, int n, hipStream_t st);
 int t2_lstm_step_bwd_launch(const T2LstmBwdStep* steps, int n, hipStream_t st);
 void t2_lstm_fwd_advance(T2LstmStep& c, const T2LstmStride& inc);
 void t2_lstm_bwd_advance(T2LstmBwdStep& c, const T2LstmBwdStride& inc);
-int t2_lstm_step_fwd_tab(const T2LstmStep* steps, int n, hipStream_t st, LstmK2* fill, const LstmK2* tab, int idx);
-int t2_lstm_step_bwd_tab(const T2LstmBwdStep* steps, int n, hipStream_t st, BwdK2* fill, const BwdK2* tab, int idx);
 
 namespace {
 
@@ -415,17 +413,6 @@ __global__ __launch_bounds__(256, 1) void attn_context_kernel(AttnK p) {
     attn_context_body(p, blockIdx.x, blockIdx.y * 32, sm);
 }
 
-// Heterogeneous launch: workgroups [0, nC) are the context workgroups (b = id % B, column slice id / B), workgroups
-// [nC, nC + H/4) run one step of a co-scheduled LSTM cell (t2_lstm_step.hpp).  3 waves per SIMD (<= 168 VGPRs) so that two
-// context workgroups and one cell workgroup fit on a CU.
-template <int MT>
-__global__ __launch_bounds__(256, 3) void attn_context_co_kernel(AttnK p, LstmK c, int nC, int bx0) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int bid = blockIdx.x;
-    if (bid < nC) attn_context_body(p, bid % p.B, (bid / p.B) * 32, sm);
-    else t2_lstm_fwd_fast_body<MT, 4>(c, bx0 + bid - nC, sm);
-}
-
 // U[a][c][k] = sum_f Wd[a][f] * Wc[f][c][k]
 __global__ void fold_location_kernel(const float* Wd, const float* Wc, float* U, int Ad, int F, int CK) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -457,119 +444,44 @@ void to_ak(const T2AttnStep& s, AttnK& k) {
     k.clk = (unsigned long long*)s.clk;
 }
 
-// The same co-scheduling with the ENERGIES launch as the host (T2AttnSeq.co_host = 1): 512-thread workgroups; the cell
-// body uses 256 threads, the upper four waves of a cell workgroup end at once (finished waves do not count at s_barrier
-// and release their registers), so an energies workgroup (2 waves per SIMD) and a cell workgroup (1 wave per SIMD) share a
-// CU at <= 168 VGPRs.
+// Heterogeneous launch: workgroups [0, nE) are the energies workgroups (b = id % B, attention-dim slice id / B), workgroups
+// [nE, nE + H/4) run one step of a co-scheduled LSTM cell (t2_lstm_step.hpp).  512-thread workgroups; the cell body uses 256
+// threads, the upper four waves of a cell workgroup end at once (finished waves do not count at s_barrier and release their
+// registers), so an energies workgroup (2 waves per SIMD) and a cell workgroup (1 wave per SIMD) share a CU at <= 168 VGPRs.
 template <int MT>
-__global__ __launch_bounds__(ENT, 3) void attn_energy_co_kernel(AttnK p, LstmK c, int nE, int bx0) {
+__global__ __launch_bounds__(ENT, 3) void attn_energy_co_kernel(AttnK p, LstmK c, int nE) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int bid = blockIdx.x;
     if (bid < nE) { attn_energy_body(p, bid % p.B, bid / p.B, sm); return; }
     if (threadIdx.x >= 256) return;
-    t2_lstm_fwd_fast_body<MT, 4>(c, bx0 + bid - nE, sm);
+    t2_lstm_fwd_fast_body<MT, 4>(c, bid - nE, sm);
 }
 
-// Table variants: the operand block comes from a device-resident table entry (16-byte kernel-argument block; see
-// lstm_step_fwd_fast_tab_kernel).
-__global__ __launch_bounds__(ENT, 2) void attn_energy_tab_kernel(const T2_CONST_AS AttnK* tab, int idx) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const AttnK p = t2_tab_entry(&tab[idx]);
-    attn_energy_body(p, blockIdx.x, blockIdx.y, sm);
-}
-__global__ __launch_bounds__(256, 1) void attn_context_tab_kernel(const T2_CONST_AS AttnK* tab, int idx) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const AttnK p = t2_tab_entry(&tab[idx]);
-    attn_context_body(p, blockIdx.x, blockIdx.y * 32, sm);
-}
-template <int MT>
-__global__ __launch_bounds__(256, 3) void attn_context_co_tab_kernel(const T2_CONST_AS AttnK* tab, const T2_CONST_AS LstmK* ctab, int idx,
-                                                                     int nC) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int bid = blockIdx.x;
-    if (bid < nC) {
-        const AttnK p = t2_tab_entry(&tab[idx]);
-        attn_context_body(p, bid % p.B, (bid / p.B) * 32, sm);
-    } else {
-        const LstmK c = t2_tab_entry(&ctab[idx]);
-        t2_lstm_fwd_fast_body<MT, 4>(c, bid - nC, sm);
-    }
-}
-
-// Per-frame parameter tables of one teacher-forced attention chain (t2_attn_seq_fwd_plan): [T x cell][T x attention][T x co]
-struct FwdTabs { LstmK2* cell; AttnK* attn; LstmK* co; };
-inline int64_t fwd_tab_bytes(int T) { return (int64_t)T * (sizeof(LstmK2) + sizeof(AttnK) + sizeof(LstmK)); }
-inline FwdTabs fwd_tabs(const void* base, int T) {
-    char* p = (char*)base;
-    FwdTabs v;
-    v.cell = (LstmK2*)p; p += (size_t)T * sizeof(LstmK2);
-    v.attn = (AttnK*)p; p += (size_t)T * sizeof(AttnK);
-    v.co = (LstmK*)p;
-    return v;
-}
-enum { T2_BY_VALUE = 0, T2_FILL = 1, T2_TABLE = 2 };
-
-// A cell step can ride in the context launch if it takes the packed single-segment path with <= 32 batch rows.
+// A cell step can ride in the energies launch if it takes the packed single-segment path with <= 32 batch rows.
 bool co_eligible(const T2LstmStep& c) { return c.wpacked && c.nseg == 1 && c.B <= 32 && c.H % 4 == 0; }
 
-int launch_attn(const T2AttnStep& s, hipStream_t st, const T2LstmStep* co = nullptr, int mode = T2_BY_VALUE,
-                const FwdTabs* tabs = nullptr, int idx = 0, int co_host = 0) {
+int launch_attn(const T2AttnStep& s, hipStream_t st, const T2LstmStep* co = nullptr) {
     AttnK k;
     to_ak(s, k);
     const int NG = (s.L + 3) >> 2, Lp = 4 * NG + 36;
     const size_t sm_e = (size_t)(2 * Lp + 16 * 64 + 16 + 16 * 4 * NG) * sizeof(float);
     const int wsn = ((s.L + 3) & ~3) > 192 ? ((s.L + 3) & ~3) : 192;
     const size_t sm_c = (size_t)(wsn + 8 + 256) * sizeof(float);
-    LstmK ck;
-    int MT = 1;
-    size_t smx = sm_c;
+    T2_REQUIRE(t2_allow_lds(attn_energy_kernel, sm_e), "attention: LDS budget exceeded (energies kernel)");
     if (co) {
         T2_TRY(t2_lstm_check_step(*co));
+        LstmK ck;
         t2_lstm_to_k(*co, ck, 0, co->B);
-        MT = co->B <= 16 ? 1 : 2;
-        const size_t sm_co = (size_t)4 * MT * 256 * sizeof(float);
-        smx = sm_c > sm_co ? sm_c : sm_co;
-    }
-    const int nC = s.B * (s.Ef / 32);
-    T2_REQUIRE(t2_allow_lds(attn_energy_kernel, sm_e) && t2_allow_lds(attn_energy_tab_kernel, sm_e),
-               "attention: LDS budget exceeded (energies kernel)");
-    if (mode == T2_FILL) {
-        tabs->attn[idx] = k;
-        if (co) tabs->co[idx] = ck;
-        return T2_OK;
-    }
-    if (mode == T2_TABLE) {
-        const T2_CONST_AS AttnK* at = (const T2_CONST_AS AttnK*)tabs->attn;
-        const T2_CONST_AS LstmK* ct = (const T2_CONST_AS LstmK*)tabs->co;
-        hipLaunchKernelGGL(attn_energy_tab_kernel, dim3(s.B, s.Ad / 16), dim3(ENT), sm_e, st, at, idx);
-        if (co) {
-            if (MT == 1) hipLaunchKernelGGL(attn_context_co_tab_kernel<1>, dim3(nC + co->H / 4), dim3(256), smx, st, at, ct, idx, nC);
-            else hipLaunchKernelGGL(attn_context_co_tab_kernel<2>, dim3(nC + co->H / 4), dim3(256), smx, st, at, ct, idx, nC);
-        } else {
-            hipLaunchKernelGGL(attn_context_tab_kernel, dim3(s.B, s.Ef / 32), dim3(256), sm_c, st, at, idx);
-        }
-        T2_CHECK_LAUNCH();
-        return T2_OK;
-    }
-    // co_host 0: the whole cell step rides in the context launch; 1: in the energies launch; 2: its workgroups are split
-    // between the two (first half in the energies launch)
-    const int ncell = co ? co->H / 4 : 0;
-    const int ne_cell = !co ? 0 : (co_host == 1 ? ncell : (co_host == 2 ? ncell / 2 : 0)), nc_cell = ncell - ne_cell;
-    if (ne_cell > 0) {
+        const int MT = co->B <= 16 ? 1 : 2;
         const int nE = s.B * (s.Ad / 16);
         const size_t sm_co = (size_t)4 * MT * 256 * sizeof(float), sme = sm_e > sm_co ? sm_e : sm_co;
         T2_REQUIRE(t2_allow_lds(attn_energy_co_kernel<1>, sme) && t2_allow_lds(attn_energy_co_kernel<2>, sme), "attention: LDS budget exceeded");
-        if (MT == 1) hipLaunchKernelGGL(attn_energy_co_kernel<1>, dim3(nE + ne_cell), dim3(ENT), sme, st, k, ck, nE, 0);
-        else hipLaunchKernelGGL(attn_energy_co_kernel<2>, dim3(nE + ne_cell), dim3(ENT), sme, st, k, ck, nE, 0);
+        if (MT == 1) hipLaunchKernelGGL(attn_energy_co_kernel<1>, dim3(nE + co->H / 4), dim3(ENT), sme, st, k, ck, nE);
+        else hipLaunchKernelGGL(attn_energy_co_kernel<2>, dim3(nE + co->H / 4), dim3(ENT), sme, st, k, ck, nE);
     } else {
         hipLaunchKernelGGL(attn_energy_kernel, dim3(s.B, s.Ad / 16), dim3(ENT), sm_e, st, k);
     }
-    if (nc_cell > 0) {
-        if (MT == 1) hipLaunchKernelGGL(attn_context_co_kernel<1>, dim3(nC + nc_cell), dim3(256), smx, st, k, ck, nC, ne_cell);
-        else hipLaunchKernelGGL(attn_context_co_kernel<2>, dim3(nC + nc_cell), dim3(256), smx, st, k, ck, nC, ne_cell);
-    } else {
-        hipLaunchKernelGGL(attn_context_kernel, dim3(s.B, s.Ef / 32), dim3(256), sm_c, st, k);
-    }
+    hipLaunchKernelGGL(attn_context_kernel, dim3(s.B, s.Ef / 32), dim3(256), sm_c, st, k);
     T2_CHECK_LAUNCH();
     return T2_OK;
 }
@@ -597,28 +509,23 @@ extern "C" int t2_attn_step_fwd(const T2AttnStep* s, void* stream) {
     return t2_attn_step_launch(s, (hipStream_t)stream);
 }
 
-// Teacher-forced attention chain over all T frames: per frame  attention-LSTMCell -> energies -> softmax/context.
-// mode T2_BY_VALUE: launch frames [t_begin, t_end) with by-value operand blocks (co step i rides frame t_begin + i);
-// mode T2_FILL: write the tables of ALL T frames (co step i rides frame co_first + i);  mode T2_TABLE: launch frames
-// [t_begin, t_end) from the device tables.
-static int attn_seq_fwd_core(const T2AttnSeq* a, hipStream_t st, int mode, const FwdTabs* tabs) {
+// Teacher-forced attention chain over frames [t_begin, t_end): per frame  attention-LSTMCell -> energies -> softmax/context
+// (co step i rides the energies launch of frame t_begin + i).
+extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
+    T2_REQUIRE(a != nullptr, "t2_attn_seq_fwd: null");
+    hipStream_t st = (hipStream_t)stream;
     const int B = a->B, L = a->L, T = a->T, A = a->A, Ef = a->Ef, Ad = a->Ad;
     const long ldx = A + Ef;
-    int tb = (a->t_begin == 0 && a->t_end == 0) ? 0 : a->t_begin, te = (a->t_begin == 0 && a->t_end == 0) ? T : a->t_end;
+    const int tb = (a->t_begin == 0 && a->t_end == 0) ? 0 : a->t_begin, te = (a->t_begin == 0 && a->t_end == 0) ? T : a->t_end;
     T2_REQUIRE(tb >= 0 && te <= T && tb <= te, "t2_attn_seq_fwd: bad frame range");
     T2_REQUIRE(!a->xdec_t || (a->wpacked && (A + Ef) % 16 == 0 && A % 16 == 0), "t2_attn_seq_fwd: xdec_t needs wpacked and A, Ef multiples of 16");
-    if (mode == T2_FILL) { tb = 0; te = T; }
     T2LstmStep co;
-    int co_left = 0, co_at = tb;     // co step rides frames co_at, co_at + 1, ... while co_left > 0
+    int co_left = 0;
     bool co_ride = false;
     if (a->co_step && a->co_steps > 0) {
         T2_REQUIRE(a->co_inc != nullptr, "t2_attn_seq_fwd: co_inc required with co_step");
         co = *a->co_step; co_left = a->co_steps; co_ride = co_eligible(co);
-        if (mode != T2_BY_VALUE) {
-            T2_REQUIRE(co_ride && a->co_first >= 0, "t2_attn_seq_fwd: planned co-scheduling needs an eligible cell and co_first >= 0");
-            co_at = a->co_first;
-            for (; co_at < tb && co_left > 0; ++co_at, --co_left) t2_lstm_fwd_advance(co, *a->co_inc);   // skip to the range
-        }
     }
     for (int t = tb; t < te; ++t) {
         T2LstmStep s;
@@ -643,8 +550,7 @@ static int attn_seq_fwd_core(const T2AttnSeq* a, hipStream_t st, int mode, const
         s.h_out = slot1; s.ldh = ldx;
         s.c_out = a->att_c + (long)(t + 1) * B * A; s.ldc_out = A;
         if (a->gates) { s.gates_out = a->gates + (long)t * B * 4 * A; s.ldg = 4 * A; }
-        if (mode == T2_BY_VALUE) T2_TRY(t2_lstm_step_fwd_launch(&s, 1, st));
-        else T2_TRY(t2_lstm_step_fwd_tab(&s, 1, st, mode == T2_FILL ? &tabs->cell[t] : nullptr, mode == T2_TABLE ? tabs->cell : nullptr, t));
+        T2_TRY(t2_lstm_step_fwd_launch(&s, 1, st));
 
         T2AttnStep q;
         memset(&q, 0, sizeof(q));
@@ -661,41 +567,18 @@ static int attn_seq_fwd_core(const T2AttnSeq* a, hipStream_t st, int mode, const
         if (a->xdec_t) { q.ctxt_out = a->xdec_t + (long)(t + 1) * xts; q.ctxt_col0 = A; }
         q.clk = a->clk;
         if (t == tb) T2_TRY(check_attn(q));
-        if (co_left > 0 && co_ride && t >= co_at) {
-            T2_TRY(launch_attn(q, st, &co, mode, tabs, t, a->co_host));
+        if (co_left > 0 && co_ride) {
+            T2_TRY(launch_attn(q, st, &co));
             t2_lstm_fwd_advance(co, *a->co_inc); --co_left;
         } else {
-            T2_TRY(launch_attn(q, st, nullptr, mode, tabs, t));
+            T2_TRY(launch_attn(q, st));
         }
     }
-    if (mode == T2_BY_VALUE) {
-        for (; co_left > 0; --co_left) {   // co-scheduled steps that did not ride in a context launch
-            T2_TRY(t2_lstm_step_fwd_launch(&co, 1, st));
-            t2_lstm_fwd_advance(co, *a->co_inc);
-        }
+    for (; co_left > 0; --co_left) {   // co-scheduled steps that did not ride in an energies launch
+        T2_TRY(t2_lstm_step_fwd_launch(&co, 1, st));
+        t2_lstm_fwd_advance(co, *a->co_inc);
     }
     return T2_OK;
-}
-
-extern "C" int64_t t2_attn_seq_fwd_plan(const T2AttnSeq* a, void* host_tab, int64_t bytes) {
-    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
-    if (!a) return -1;
-    const int64_t need = fwd_tab_bytes(a->T);
-    if (!host_tab) return need;
-    if (bytes < need) return -1;
-    memset(host_tab, 0, (size_t)need);
-    const FwdTabs tabs = fwd_tabs(host_tab, a->T);
-    return attn_seq_fwd_core(a, nullptr, T2_FILL, &tabs) == T2_OK ? need : -1;
-}
-
-extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
-    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
-    T2_REQUIRE(a != nullptr, "t2_attn_seq_fwd: null");
-    if (a->plan) {
-        const FwdTabs tabs = fwd_tabs(a->plan, a->T);
-        return attn_seq_fwd_core(a, (hipStream_t)stream, T2_TABLE, &tabs);
-    }
-    return attn_seq_fwd_core(a, (hipStream_t)stream, T2_BY_VALUE, nullptr);
 }
 
 // =================================================================================================
@@ -1047,16 +930,6 @@ __global__ __launch_bounds__(ENT, 2) void attn_bwd_ds_kernel(AttnBwdK p) {
     attn_bwd_ds_body(p, blockIdx.x, blockIdx.y, sm);
 }
 
-// Heterogeneous launch: workgroups [0, nD) are the ds workgroups (b = id % B, j = id / B); workgroups [nD, nD + ntx*nty)
-// run one BPTT step of a co-scheduled LSTM (16 x 16 tiles, 8 waves split K).  4 waves per SIMD (<= 128 VGPRs) so that one
-// workgroup of each kind fits on a CU: the ds workgroups are VALU/LDS bound, the step workgroups MFMA/memory bound.
-__global__ __launch_bounds__(ENT, 4) void attn_bwd_ds_co_kernel(AttnBwdK p, BwdK c, int nD, int ntx) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int bid = blockIdx.x;
-    if (bid < nD) attn_bwd_ds_body(p, bid % p.B, bid / p.B, sm);
-    else t2_lstm_bwd_fast_body<8, 4>(c, (bid - nD) % ntx, (bid - nD) / ntx, sm);
-}
-
 }  // namespace
 
 extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
@@ -1070,8 +943,7 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
     const int NG = (L + 3) >> 2, Lp = 4 * NG + 36, L4 = 4 * NG;
     const size_t sm_dw = (size_t)((Ef > 640 ? Ef : 640) + ((L + 3) & ~3) + 8) * sizeof(float);
     const size_t sm_ds = (size_t)(18 * Lp + 16 * 64 + 32 * L4) * sizeof(float);
-    T2_REQUIRE(t2_allow_lds(attn_bwd_ds_kernel, sm_ds) && t2_allow_lds(attn_bwd_ds_co_kernel, sm_ds),
-               "t2_attn_seq_bwd: LDS budget exceeded");
+    T2_REQUIRE(t2_allow_lds(attn_bwd_ds_kernel, sm_ds), "t2_attn_seq_bwd: LDS budget exceeded");
     T2_REQUIRE(a->wtp_ctx && a->wtp_h, "t2_attn_seq_bwd: packed weight streams (t2_lstm_pack_bwd) are required");
     // Z[s][b] = [ dgates_s (4A) | dq_{s-1} (Ad) ], s = 0..T; slot T's dgates part is zero-filled by the caller, so the
     // backward step of frame t always reads ONE contiguous row Z[t+1] (no special case for the last frame).
@@ -1082,14 +954,6 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
     const int thi = (a->t_hi == 0 && a->t_lo == 0) ? T : a->t_hi, tlo = (a->t_hi == 0 && a->t_lo == 0) ? 0 : a->t_lo;
     T2_REQUIRE(tlo >= 0 && thi <= T && tlo <= thi, "t2_attn_seq_bwd: bad frame range");
     T2LstmBwdStep s2[2];
-    T2LstmBwdStep co;
-    int co_left = 0;
-    bool co_ride = false;
-    if (a->co_step && a->co_steps > 0) {
-        T2_REQUIRE(a->co_inc != nullptr, "t2_attn_seq_bwd: co_inc required with co_step");
-        co = *a->co_step; co_left = a->co_steps;
-        co_ride = co.wtpacked && co.dg_next && !co.dg2;
-    }
     for (int t = thi - 1; t >= tlo; --t) {
         const bool last = (t == T - 1);
         const float* zrow = Z + (long)(t + 1) * B * ldz;
@@ -1130,17 +994,7 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         k.dv_part = a->dv_part; k.dU_part = a->dU_part; k.din_part_out = a->din_part;
         k.clk = (unsigned long long*)a->clk;
         hipLaunchKernelGGL(attn_bwd_dw_kernel, dim3(B, t2_cdiv(L, 32)), dim3(256), sm_dw, st, k);
-        if (co_left > 0 && co_ride) {   // ds workgroups + one BPTT step of the co-scheduled recurrence in one launch
-            T2_TRY(t2_lstm_check_bwd(co));
-            BwdK ck;
-            t2_lstm_to_bk(co, ck);
-            const int ntx = t2_cdiv(co.ncols, 16), nty = t2_cdiv(co.B, 16), nD = B * NA;
-            const size_t sm_co = (size_t)8 * 256 * sizeof(float), smx = sm_ds > sm_co ? sm_ds : sm_co;
-            hipLaunchKernelGGL(attn_bwd_ds_co_kernel, dim3(nD + ntx * nty), dim3(ENT), smx, st, k, ck, nD, ntx);
-            t2_lstm_bwd_advance(co, *a->co_inc); --co_left;
-        } else {
-            hipLaunchKernelGGL(attn_bwd_ds_kernel, dim3(B, NA), dim3(ENT), sm_ds, st, k);
-        }
+        hipLaunchKernelGGL(attn_bwd_ds_kernel, dim3(B, NA), dim3(ENT), sm_ds, st, k);
         // (4) attention-LSTM cell backward: dh = (dh_ext + dgates_{t+1}.W_hh) + dq_t.Wq  (short K = Ad product + pointwise)
         T2LstmBwdStep c;
         memset(&c, 0, sizeof(c));
@@ -1155,10 +1009,6 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         c.dg_out = Z + (long)t * B * ldz; c.ldgo = ldz;
         if (a->dgates_t) c.dgt_out = a->dgates_t + (long)t * zts;
         T2_TRY(t2_lstm_step_bwd_launch(&c, 1, st));
-    }
-    for (; co_left > 0; --co_left) {   // co-scheduled steps that did not ride in a ds launch
-        T2_TRY(t2_lstm_step_bwd_launch(&co, 1, st));
-        t2_lstm_bwd_advance(co, *a->co_inc);
     }
     T2_CHECK_LAUNCH();
     return T2_OK;

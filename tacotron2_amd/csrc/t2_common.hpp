@@ -13,17 +13,6 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// Kernel-parameter tables live in device memory that no kernel writes: typing the kernel argument as a constant-address-
-// space pointer lets the compiler fetch entries with scalar loads and keeps the pointers loaded from them in the global
-// address space (generic/flat accesses would break the counted vmcnt pipelines).
-#define T2_CONST_AS __attribute__((address_space(4)))
-// copy of one table entry (the compiler turns it into lazy scalar loads of the fields that are used)
-template <typename T>
-__device__ __forceinline__ T t2_tab_entry(const T2_CONST_AS T* p) {
-    T v;
-    __builtin_memcpy(&v, p, sizeof(T));
-    return v;
-}
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define T2_WAVE 64

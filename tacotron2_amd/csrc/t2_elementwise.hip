@@ -68,7 +68,8 @@ struct BnK {
     const float* gamma; const float* beta;
     float* rmean; float* rvar;            // running stats (read in eval, updated in training)
     int training; float momentum, eps;
-    double* sums;                         // [2][C]
+    double* sums;                         // [2][C] + 2: sums, then the row count they cover (summed over ranks under sync-BN)
+    const float* shift;                   // [C] common shift of the statistics sums, or null (= the channel's first value)
     float* mean; float* invstd;           // [C] saved batch stats (training) / derived from running (eval)
     int act;                              // 0 none, 1 relu, 2 tanh
     const float* drop;                    // dense [B][L][C] scale mask or null
@@ -79,6 +80,7 @@ struct BnK {
     const float* dy; int Lp_dy, pad_dy;
     float* dx; int Lp_dx, pad_dx;
     float* dgamma; float* dbeta;
+    double grad_share;                    // 1, or 1/world under sync-BN
 };
 
 // grid (ceil(C/64), row chunks); block 256 = 64 channels x 4 row lanes
@@ -89,11 +91,15 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(BnK p, int rows_per_block
     const long R = (long)p.B * p.L;
     const long r0 = (long)blockIdx.y * rows_per_block;
     long r1 = r0 + rows_per_block; if (r1 > R) r1 = R;
+    // Sums of (x - shift) with shift = the channel's first value: E[d^2] - E[d]^2 then has no cancellation however far the
+    // channel mean is from zero (a -5.5 log-mel level with 0.25 spread loses ~3 digits of the variance otherwise).
     float a = 0.f, q = 0.f;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(&p.sums[2 * p.C], (double)R);
     if (c < p.C) {
+        const float sh = p.shift ? p.shift[c] : p.x[c];
         for (long r = r0 + rl; r < r1; r += 4) {
             const int b = (int)(r / p.L), l = (int)(r % p.L);
-            const float v = p.x[((long)b * p.Lp_x + l) * p.C + c];
+            const float v = p.x[((long)b * p.Lp_x + l) * p.C + c] - sh;
             a += v; q = fmaf(v, v, q);
         }
     }
@@ -111,10 +117,11 @@ __global__ void bn_finalize_kernel(BnK p) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= p.C) return;
     if (p.training) {
-        const double n = (double)p.B * p.L;
-        const double m = p.sums[c] / n;
-        double var = p.sums[p.C + c] / n - m * m;
+        const double n = p.sums[2 * p.C];                // rows behind the sums (all ranks' rows under sync-BN)
+        const double md = p.sums[c] / n;                 // mean of (x - shift) (bn_stats_kernel)
+        double var = p.sums[p.C + c] / n - md * md;
         if (var < 0) var = 0;
+        const double m = md + (double)(p.shift ? p.shift[c] : p.x[c]);
         p.mean[c] = (float)m;
         p.invstd[c] = (float)(1.0 / sqrt(var + (double)p.eps));
         if (p.rmean) {
@@ -169,6 +176,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnK p, int rows_per_
     const long r0 = (long)blockIdx.y * rows_per_block;
     long r1 = r0 + rows_per_block; if (r1 > R) r1 = R;
     float a = 0.f, q = 0.f;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(&p.sums[2 * p.C], (double)R);
     if (c < p.C) {
         for (long r = r0 + rl; r < r1; r += 4) {
             const int b = (int)(r / p.L), l = (int)(r % p.L);
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnK p, int rows_per_
 
 __global__ void bn_bwd_apply_kernel(BnK p) {
     const long n = (long)p.B * p.Lp_dx * p.C;
-    const float invn = 1.f / ((float)p.B * (float)p.L);
+    const float invn = (float)(1.0 / p.sums[2 * p.C]);      // rows behind the sums (all ranks' rows under sync-BN)
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % p.C);
         const long row = i / p.C;
@@ -202,9 +210,10 @@ __global__ void bn_bwd_apply_kernel(BnK p) {
             else v = gi * dz;
         }
         p.dx[i] = v;
-        if (lp == 0 && b == 0) {   // one thread per channel folds the parameter gradients
-            p.dbeta[c] += (float)p.sums[c];
-            p.dgamma[c] += (float)p.sums[p.C + c];
+        if (lp == 0 && b == 0) {   // one thread per channel folds the parameter gradients (this rank's share under sync-BN:
+                                   // the gradient all-reduce adds the ranks' shares, so the globally summed `sums` are scaled back)
+            p.dbeta[c] += (float)(p.sums[c] * p.grad_share);
+            p.dgamma[c] += (float)(p.sums[p.C + c] * p.grad_share);
         }
     }
 }
@@ -216,6 +225,7 @@ void to_bnk(const T2Bn* s, BnK& k) {
     k.res = s->res; k.Lp_res = s->Lp_res; k.pad_res = s->pad_res; k.len = s->len; k.fill = s->fill;
     k.y = s->y; k.Lp_y = s->Lp_y; k.pad_y = s->pad_y; k.dy = s->dy; k.Lp_dy = s->Lp_dy; k.pad_dy = s->pad_dy;
     k.dx = s->dx; k.Lp_dx = s->Lp_dx; k.pad_dx = s->pad_dx; k.dgamma = s->dgamma; k.dbeta = s->dbeta;
+    k.shift = s->shift; k.grad_share = s->grad_share > 0.f ? (double)s->grad_share : 1.0;
 }
 
 inline int ew_grid(long n) { long g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
@@ -541,15 +551,19 @@ extern "C" int t2_bn_fwd(const T2Bn* s, void* stream) {
     (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(s && s->x && s->gamma && s->beta && s->mean && s->invstd && s->y, "t2_bn_fwd: null operand");
     T2_REQUIRE(s->training ? (s->sums != nullptr) : (s->running_mean && s->running_var), "t2_bn_fwd: stats operands");
+    T2_REQUIRE(s->phase >= 0 && s->phase <= 2 && (s->phase == 0 || (s->training && s->shift)),
+               "t2_bn_fwd: phases 1/2 (sync-BN) need training statistics and a rank-independent shift");
     BnK k; to_bnk(s, k);
-    if (s->training) {
-        (void)hipMemsetAsync(s->sums, 0, sizeof(double) * 2 * s->C, ST);
+    if (s->training && s->phase != 2) {
+        (void)hipMemsetAsync(s->sums, 0, sizeof(double) * (2 * s->C + 2), ST);
         const long R = (long)s->B * s->L;
         const int rpb = 128;
         hipLaunchKernelGGL(bn_stats_kernel, dim3(t2_cdiv(s->C, 64), t2_cdiv(R, rpb)), dim3(256), 0, ST, k, rpb);
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(t2_cdiv(s->C, 256)), dim3(256), 0, ST, k);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid((long)s->B * s->Lp_y * s->C)), dim3(256), 0, ST, k);
+    if (s->phase != 1) {
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(t2_cdiv(s->C, 256)), dim3(256), 0, ST, k);
+        hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid((long)s->B * s->Lp_y * s->C)), dim3(256), 0, ST, k);
+    }
     T2_CHECK_LAUNCH(); return T2_OK;
 }
 
@@ -557,12 +571,15 @@ extern "C" int t2_bn_bwd(const T2Bn* s, void* stream) {
     (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(s && s->x && s->gamma && s->beta && s->mean && s->invstd && s->dy && s->dx && s->sums && s->dgamma && s->dbeta,
                "t2_bn_bwd: null operand");
+    T2_REQUIRE(s->phase >= 0 && s->phase <= 2, "t2_bn_bwd: bad phase");
     BnK k; to_bnk(s, k);
-    (void)hipMemsetAsync(s->sums, 0, sizeof(double) * 2 * s->C, ST);
-    const long R = (long)s->B * s->L;
-    const int rpb = 128;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(t2_cdiv(s->C, 64), t2_cdiv(R, rpb)), dim3(256), 0, ST, k, rpb);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid((long)s->B * s->Lp_dx * s->C)), dim3(256), 0, ST, k);
+    if (s->phase != 2) {
+        (void)hipMemsetAsync(s->sums, 0, sizeof(double) * (2 * s->C + 2), ST);
+        const long R = (long)s->B * s->L;
+        const int rpb = 128;
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(t2_cdiv(s->C, 64), t2_cdiv(R, rpb)), dim3(256), 0, ST, k, rpb);
+    }
+    if (s->phase != 1) hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid((long)s->B * s->Lp_dx * s->C)), dim3(256), 0, ST, k);
     T2_CHECK_LAUNCH(); return T2_OK;
 }
 

@@ -214,6 +214,231 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(GemmK p) {
     }
 }
 
+// =====================================================================================================================
+// fp32 GEMM on the bf16 matrix pipe by error-free operand splitting ("bf16x3 split, 6 products").
+//
+// gfx950 runs f32-input MFMA at the vector rate (64 FLOP/clk/SIMD); the bf16 forms run 16x faster.  Every fp32 value is the
+// EXACT sum of three bf16 values: a = a1 + a2 + a3 with a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2) (each
+// subtraction is exact in fp32 and 3 x 8 significand bits cover fp32's 24).  A product a*b is then the sum of 9 bf16
+// products, each EXACT in the fp32 accumulator of v_mfma_f32_32x32x16_bf16; the three terms a2*b3, a3*b2, a3*b3 are below
+// 2^-24 |a*b| (the size of one fp32 rounding) and are dropped, the other six are issued:
+//     lo += a3*b1 + a1*b3 + a2*b2 + a2*b1 + a1*b2        hi += a1*b1        C = hi + lo
+// The small terms have their own accumulator, so they are not rounded against the large partial sums.  The result has the
+// accuracy of an fp32 GEMM (tests/test_gpu_kernels.py compares both kernels with float64) at 16/6 = 2.7x the MFMA rate.
+//
+// Tile 128 x 128 x 16 per 256-thread workgroup (2 x 2 waves of 64 x 64, each 2 x 2 MFMA tiles of 32 x 32 and TWO
+// accumulator sets), two LDS stages of 36 KB (two workgroups per CU).  Operands are split once, on the way from the
+// fp32 global tile into LDS (global -> registers one stage ahead -> split -> three bf16 planes):
+//   k-major operand: plane[row][16 k] with 48-byte rows; a lane's fragment (8 consecutive k) is ONE ds_read_b128, the
+//     16 rows of a b128 lane group start 12 dwords apart: conflict-free.
+//   m-major operand (dgrad B, wgrad A and B): plane[k][128 rows] with 320-byte rows, written as it is read from global
+//     memory (4 consecutive rows of one k per lane: contiguous 8-byte stores) and read back TRANSPOSED with
+//     ds_read_b64_tr_b16 (a 16-lane group reads 4 k-rows x 16 columns, lane i receives column i's 4 k values): the
+//     four k-rows of a 32-lane half start 16 dwords apart: conflict-free.
+// Both images deliver fragment element j = k offset j, so A and B agree on the k order inside an MFMA.
+// =====================================================================================================================
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SBK = 16;
+constexpr int KM_ROW = 48, MM_ROW = 320;                   // bytes
+constexpr int KM_PLANE = BM * KM_ROW, MM_PLANE = SBK * MM_ROW;   // 6144, 5120 bytes
+constexpr int OP_BYTES = 3 * KM_PLANE;                     // one operand's three planes (the larger image)
+constexpr int STAGE_BYTES = 2 * OP_BYTES;                  // 36864
+
+__device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
+    h = __builtin_convertvector(v, bf16x4);
+    const f32x4 r = v - __builtin_convertvector(h, f32x4);      // exact
+    m = __builtin_convertvector(r, bf16x4);
+    const f32x4 r2 = r - __builtin_convertvector(m, f32x4);     // exact
+    l = __builtin_convertvector(r2, bf16x4);                    // exact (<= 8 significant bits are left)
+}
+
+// global -> 2 x f32x4 registers.  KMAJ: rows r0 + (idx>>2), k = k0 + 4*(idx&3); MMAJ: k = k0 + (idx>>5), rows r0 + 4*(idx&31)
+template <bool KMAJ>
+__device__ __forceinline__ void split_stage_load(f32x4 (&reg)[2], const float* __restrict__ base, long ld, int r0, int k0, int R,
+                                                 int Kend, bool vec, int tid) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int idx = tid + 256 * j;
+        if (KMAJ) {
+            const int r = r0 + (idx >> 2), k = k0 + ((idx & 3) << 2);
+            int nv = (r < R) ? (Kend - k) : 0;
+            nv = nv < 0 ? 0 : nv;
+            reg[j] = load4(base + (long)r * ld + k, nv, vec);
+        } else {
+            const int k = k0 + (idx >> 5), r = r0 + ((idx & 31) << 2);
+            int nv = (k < Kend) ? (R - r) : 0;
+            nv = nv < 0 ? 0 : nv;
+            reg[j] = load4(base + (long)k * ld + r, nv, vec);
+        }
+    }
+}
+
+template <bool KMAJ>
+__device__ __forceinline__ void split_stage_store(const f32x4 (&reg)[2], char* op, int tid) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int idx = tid + 256 * j;
+        bf16x4 h, m, l;
+        split3(reg[j], h, m, l);
+        const int off = KMAJ ? (idx >> 2) * KM_ROW + (idx & 3) * 8 : (idx >> 5) * MM_ROW + (idx & 31) * 8;
+        constexpr int PL = KMAJ ? KM_PLANE : MM_PLANE;
+        *reinterpret_cast<bf16x4*>(op + off) = h;
+        *reinterpret_cast<bf16x4*>(op + PL + off) = m;
+        *reinterpret_cast<bf16x4*>(op + 2 * PL + off) = l;
+    }
+}
+
+// fragment of plane `pl` for the 32-row MFMA tile starting at tile row r0: element j = k offset 8*(lane>>5) + j
+template <bool KMAJ>
+__device__ __forceinline__ bf16x8 split_frag(const char* op, int pl, int r0, int lane) {
+    if (KMAJ) {
+        return *reinterpret_cast<const bf16x8*>(op + pl * KM_PLANE + (r0 + (lane & 31)) * KM_ROW + (lane >> 5) * 16);
+    } else {
+        const int q = (lane & 15) >> 2, p4 = lane & 3, g2 = (lane >> 4) & 1, h = lane >> 5;
+        const char* a0 = op + pl * MM_PLANE + (8 * h + q) * MM_ROW + (r0 + 16 * g2 + 4 * p4) * 2;
+        typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+        const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0));
+        const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0 + 4 * MM_ROW));
+        bf16x8 f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f[i] = __builtin_bit_cast(__bf16, t0[i]); f[4 + i] = __builtin_bit_cast(__bf16, t1[i]); }
+        return f;
+    }
+}
+
+template <bool AK, bool BKM>
+__global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(GemmK p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // ---- XCD-aware tile mapping (as gemm_f32_mfma) ----
+    const int nblk = p.ntm * p.ntn;
+    int id = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = id & 7, slot = id >> 3;
+        id = slot + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q);
+    }
+    constexpr int GM = 8;
+    const int per_group = GM * p.ntn;
+    const int grp = id / per_group;
+    const int gm0 = grp * GM;
+    const int gsz = (p.ntm - gm0) < GM ? (p.ntm - gm0) : GM;
+    const int within = id - grp * per_group;
+    const int tm = gm0 + within % gsz, tn = within / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int kz = blockIdx.z % p.splitk, bz = blockIdx.z / p.splitk;
+    const float* A = p.A + (long)bz * p.sA;
+    const float* B = p.B + (long)bz * p.sB;
+    float* C = p.C + (long)bz * p.sC;
+    const int nkt = (p.K + SBK - 1) / SBK;
+    const int per = (nkt + p.splitk - 1) / p.splitk;
+    const int kt0 = kz * per;
+    const int kt1 = (kt0 + per) < nkt ? (kt0 + per) : nkt;
+    if (kt0 >= kt1) return;
+    const int Kend = (kt1 * SBK) < p.K ? (kt1 * SBK) : p.K;
+
+    f32x16 hi[2][2], lo[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { hi[i][j][r] = 0.f; lo[i][j][r] = 0.f; }
+
+    f32x4 ra[2], rb[2];
+    split_stage_load<AK>(ra, A, p.lda, m0, kt0 * SBK, p.M, Kend, p.a_vec, tid);
+    split_stage_load<BKM>(rb, B, p.ldb, n0, kt0 * SBK, p.N, Kend, p.b_vec, tid);
+    split_stage_store<AK>(ra, smem, tid);
+    split_stage_store<BKM>(rb, smem + OP_BYTES, tid);
+    __syncthreads();
+
+    int cur = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const bool more = (kt + 1) < kt1;
+        if (more) {
+            split_stage_load<AK>(ra, A, p.lda, m0, (kt + 1) * SBK, p.M, Kend, p.a_vec, tid);
+            split_stage_load<BKM>(rb, B, p.ldb, n0, (kt + 1) * SBK, p.N, Kend, p.b_vec, tid);
+        }
+        const char* As = smem + cur * STAGE_BYTES;
+        const char* Bs = As + OP_BYTES;
+        bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                fa[i][pl] = split_frag<AK>(As, pl, wm * 64 + i * 32, lane);
+                fb[i][pl] = split_frag<BKM>(Bs, pl, wn * 64 + i * 32, lane);
+            }
+        // small terms first into `lo`, the leading term into `hi`; the four output tiles are interleaved
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], lo[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], lo[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], lo[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], lo[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], lo[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], hi[i][j], 0, 0, 0);
+        if (more) {
+            char* An = smem + (cur ^ 1) * STAGE_BYTES;
+            split_stage_store<AK>(ra, An, tid);
+            split_stage_store<BKM>(rb, An + OP_BYTES, tid);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + li;
+            if (col >= p.N) continue;
+            float badd = 0.f;
+            if (p.bias && kz == 0) badd += p.bias[col];
+            if (p.bias2 && kz == 0) badd += p.bias2[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row >= p.M) continue;
+                float v = p.alpha * (hi[i][j][r] + lo[i][j][r]) + badd;
+                float* cp = C + (long)row * p.ldc + col;
+                if (p.accumulate == 2) {
+                    atomicAdd(cp, v);
+                } else {
+                    if (p.accumulate == 1) v += *cp;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.mulmask) v *= p.mulmask[(long)row * p.ldmask + col];
+                    *cp = v;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int t2_gemm(const T2Gemm* g, void* stream) {
@@ -240,6 +465,13 @@ extern "C" int t2_gemm(const T2Gemm* g, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     // share_cu: 24 KB of (unused) dynamic LDS on top of the 73.7 KB static tile buffers -> a second workgroup no longer fits
     const size_t pad = g->share_cu ? 24 * 1024 : 0;
+    if (!g->native_fp32) {
+        if (g->a_kmajor && g->b_kmajor) hipLaunchKernelGGL((gemm_f32_split_bf16<true, true>), grid, block, pad, s, p);
+        else if (g->a_kmajor && !g->b_kmajor) hipLaunchKernelGGL((gemm_f32_split_bf16<true, false>), grid, block, pad, s, p);
+        else hipLaunchKernelGGL((gemm_f32_split_bf16<false, false>), grid, block, pad, s, p);
+        T2_CHECK_LAUNCH();
+        return T2_OK;
+    }
     if (g->a_kmajor && g->b_kmajor) hipLaunchKernelGGL((gemm_f32_mfma<true, true>), grid, block, pad, s, p);
     else if (g->a_kmajor && !g->b_kmajor) hipLaunchKernelGGL((gemm_f32_mfma<true, false>), grid, block, pad, s, p);
     else hipLaunchKernelGGL((gemm_f32_mfma<false, false>), grid, block, pad, s, p);

@@ -1,7 +1,18 @@
 // Autoregressive decoding (model/tacotron2.py:262-325, teacher_forcing=False): per frame
 //   prenet(prev mel) -> attention-LSTMCell -> attention -> decoder-LSTMCell -> mel/stop projection -> stop logic
-// as 8 dependent launches with NO host synchronisation inside the loop: `done`, `lengths`, the all-done flag and the
-// emitted frame count live on the device (the reference syncs `done.all()` every frame, model/tacotron2.py:321).
+// as 6 dependent launches with NO host synchronisation inside the loop: the per-group done flags and the emitted frame
+// count live on the device (the reference syncs `done.all()` every frame, model/tacotron2.py:321).
+//
+//   L1  combined linear on xproj_{t-1} = [dec_h | ctx] (K = D+Ef), N = P + M + 1 output columns:
+//         columns [0, P)      p1_t = relu((W_pre1 . W_mel) x + W_pre1 . b_mel) * mask1   - the first prenet layer folded
+//                             onto the mel projection (two linear maps with nothing in between: pure re-association,
+//                             like the location filter fold), so the prenet does not wait for a separate projection launch
+//         columns [P, P+M+1)  mel_{t-1}, stop logit_{t-1}                                 - the frame's outputs
+//       every sum runs in a fixed order inside one workgroup: the outputs (and the stop decision taken from them) are
+//       bit-reproducible (round 1 added K-slice partials with fp32 atomics)
+//   L2  second prenet layer -> tiled state; one extra workgroup runs the stop logic of frame t-1
+//   L3  attention LSTM cell   L4/L5 attention energies / softmax + context   L6 decoder LSTM cell
+// Frame 0 has no L1/L2: the prenet of the all-zero start frame is zero whatever the masks are (no biases, ReLU).
 //
 // Recurrent state lives in ONE x16-tiled buffer (layout of T2LstmStep.xt) with two ping-pong slots and the column order
 //   xs[slot] = [ prenet_out (P) | att_h (A) | ctx (Ef) | dec_h (D) ]
@@ -22,67 +33,67 @@ struct LinK {
     const float* x; long ldx;
     const float* w; long ldw;      // [N][K] row-major
     const float* bias;
+    const float* rowterm; long ldrt;   // optional per-row term added before the activation: rowterm[b][n]
     const float* mask; long ldmask;
     int relu;
-    int accum;                     // unsplit path: add to the existing output instead of overwriting it
-    float* out; long ldo;
-    float* out_t; int out_col0; long out_cs;   // optional x16-tiled copy of the output (chunk stride out_cs floats)
-    int ksplit;                                // > 1: blockIdx.y owns a K slice, partial sums are atomically added into a
-                                               // ZERO-FILLED out (bias by slice 0; no relu/mask/out_t)
+    int split_n;                   // columns n < split_n: act/mask epilogue into `out`; columns n >= split_n: plain linear into out2
+    float* out; long ldo;          // may be null when only the tiled copy is wanted
+    float* out2; long ldo2;        // column n lands at out2[b*ldo2 + n - split_n]
+    float* out_t; int out_col0; long out_cs;   // optional x16-tiled copy of the `out` columns (chunk stride out_cs floats)
     // optional stop logic of the PREVIOUS frame, run by one extra workgroup next to the linear (saves one dependent launch per frame)
     const float* stop_proj; long stop_ldp; int stop_M, stop_t;
-    int32_t* stop_done; int64_t* stop_lengths; int32_t* stop_state;
+    int32_t* stop_done; int32_t* stop_state;
 };
 
-// model/tacotron2.py:319-322: done[gate < 0] = True; lengths[gate >= 0] += 1; if done.all(): break  (the frame that
-// completes `done` is still emitted).  state = {all_done, n_frames}; nothing changes once all_done is set.  One workgroup.
-__device__ __forceinline__ void stop_logic(const float* proj, long ldp, int M, int B, int t, int32_t* done, int64_t* lengths,
-                                           int32_t* state, int* notdone /* LDS */) {
+// model/tacotron2.py:319-322: done[gate < 0] = True; if done.all(): break.  The device keeps the sticky per-utterance flags
+// and state = {every utterance of this group has stopped, frames emitted}; the exact break frame and the `lengths` count
+// (every emitted frame whose stop logit is >= 0, Appendix C.4) are derived from the stored logits afterwards (stop_scan),
+// so a group that is decoded a few frames past the break - the host looks only every `check_every` frames, and with several
+// groups every group runs until ALL have stopped, as the reference's single loop does - still reports the reference's values.
+__device__ __forceinline__ void stop_logic(const float* proj, long ldp, int M, int B, int t, int32_t* done, int32_t* state,
+                                           int* notdone /* LDS */) {
     if (threadIdx.x == 0) *notdone = 0;
     __syncthreads();
-    if (state[0] == 0) {
-        for (int b = threadIdx.x; b < B; b += blockDim.x) {
-            const float g = proj[(long)b * ldp + M];
-            if (g < 0.f) done[b] = 1; else lengths[b] += 1;
-            if (!done[b]) atomicAdd(notdone, 1);
-        }
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        if (proj[(long)b * ldp + M] < 0.f) done[b] = 1;
+        if (!done[b]) atomicAdd(notdone, 1);
     }
     __syncthreads();
-    if (threadIdx.x == 0 && state[0] == 0) {
+    if (threadIdx.x == 0) {
         state[1] = t + 1;
         if (*notdone == 0) state[0] = 1;
     }
 }
 
-// out[b][n] = act(sum_k x[b][k] w[n][k] + bias[n]) * mask[b][n]; M = batch rows on the MFMA M axis (<= 64), one
-// 16-column tile per workgroup, K split over the 4 waves (K % 16 == 0), all loads issued before the first MFMA wait.
+// out[b][n] = act(sum_k x[b][k] w[n][k] + bias[n] + rowterm[b][n]) * mask[b][n]; batch rows on the MFMA M axis (MT tiles of
+// 16 rows per workgroup, blockIdx.y selects the row block), one 16-column tile per workgroup, K split over the 4 waves
+// (K % 16 == 0), all loads of a group issued before the first MFMA wait; partial tiles are summed in fixed wave order.
 template <int MT>
 __global__ __launch_bounds__(256, 1) void linear_rows_kernel(LinK p) {
     __shared__ float red[4 * MT * 256];
     __shared__ int notdone;
     if (p.stop_proj && blockIdx.x == gridDim.x - 1) {   // one extra workgroup: the stop logic runs next to the linear, not in front
-        stop_logic(p.stop_proj, p.stop_ldp, p.stop_M, p.B, p.stop_t, p.stop_done, p.stop_lengths, p.stop_state, &notdone);
+        if (blockIdx.y == 0) stop_logic(p.stop_proj, p.stop_ldp, p.stop_M, p.B, p.stop_t, p.stop_done, p.stop_state, &notdone);
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
-    const int n0 = blockIdx.x * 16;
+    const int n0 = blockIdx.x * 16, b0 = blockIdx.y * (MT * 16);
     const int nrow = (n0 + r) < p.N ? (n0 + r) : p.N - 1;
     const float* wb = p.w + (long)nrow * p.ldw + 4 * q;
     const float* xb[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        const int row = m * 16 + r;
+        const int row = b0 + m * 16 + r;
         xb[m] = p.x + (long)(row < p.B ? row : 0) * p.ldx + 4 * q;
     }
     f32x4 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int NTall = p.K >> 4, per = (NTall + p.ksplit - 1) / p.ksplit;
-    const int cbeg = blockIdx.y * per, NT = (cbeg + per) < NTall ? (cbeg + per) : NTall;
+    const int NT = p.K >> 4;
     constexpr int U = 4;
-    for (int c0 = cbeg + w; c0 < NT; c0 += 4 * U) {
+    for (int c0 = w; c0 < NT; c0 += 4 * U) {
         f32x4 bw[U], ax[U][MT];
 #pragma unroll
         for (int j = 0; j < U; ++j) {
@@ -107,21 +118,17 @@ __global__ __launch_bounds__(256, 1) void linear_rows_kernel(LinK p) {
         for (int g = 0; g < 4; ++g) red[((w * MT + m) * 16 + (q * 4 + g)) * 16 + r] = acc[m][g];
     __syncthreads();
     for (int o = tid; o < MT * 256; o += 256) {
-        const int b = o >> 4, nl = o & 15, n = n0 + nl;
+        const int bl = o >> 4, nl = o & 15, n = n0 + nl, b = b0 + bl;
         if (b < p.B && n < p.N) {
             float s = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < 4; ++ww) s += red[((ww * MT + (b >> 4)) * 16 + (b & 15)) * 16 + nl];
-            if (p.ksplit > 1) {
-                if (p.bias && blockIdx.y == 0) s += p.bias[n];
-                atomicAdd(&p.out[(long)b * p.ldo + n], s);
-                continue;
-            }
-            if (p.accum) s += p.out[(long)b * p.ldo + n];     // pre-filled output (per-utterance controls term)
+            for (int ww = 0; ww < 4; ++ww) s += red[((ww * MT + (bl >> 4)) * 16 + (bl & 15)) * 16 + nl];
             if (p.bias) s += p.bias[n];
+            if (p.rowterm) s += p.rowterm[(long)b * p.ldrt + n];
+            if (n >= p.split_n) { p.out2[(long)b * p.ldo2 + (n - p.split_n)] = s; continue; }
             if (p.relu) s = fmaxf(s, 0.f);
             if (p.mask) s *= p.mask[(long)b * p.ldmask + n];
-            p.out[(long)b * p.ldo + n] = s;
+            if (p.out) p.out[(long)b * p.ldo + n] = s;
             if (p.out_t) { const int col = p.out_col0 + n; p.out_t[(long)(col >> 4) * p.out_cs + b * 16 + (col & 15)] = s; }
         }
     }
@@ -131,19 +138,51 @@ int launch_linear(const LinK& k, hipStream_t st) {
     T2_REQUIRE(k.K % 16 == 0 && k.ldx % 4 == 0 && k.ldw % 4 == 0 && t2_aligned16(k.x) && t2_aligned16(k.w),
                "linear rows: K % 16 == 0 and 16-byte aligned operands required");
     T2_REQUIRE(k.B >= 1 && k.B <= 64, "linear rows: 1 <= B <= 64");
-    T2_REQUIRE(k.ksplit >= 1 && (k.ksplit == 1 || (!k.relu && !k.mask && !k.out_t)), "linear rows: K split needs a plain linear");
-    T2_REQUIRE(!k.stop_proj || k.ksplit == 1, "linear rows: stop logic rides only in unsplit launches");
-    dim3 grid(t2_cdiv(k.N, 16) + (k.stop_proj ? 1 : 0), k.ksplit), block(256);
-    if (k.B <= 16) hipLaunchKernelGGL((linear_rows_kernel<1>), grid, block, 0, st, k);
-    else if (k.B <= 32) hipLaunchKernelGGL((linear_rows_kernel<2>), grid, block, 0, st, k);
-    else hipLaunchKernelGGL((linear_rows_kernel<4>), grid, block, 0, st, k);
+    T2_REQUIRE(k.split_n >= k.N || k.out2 != nullptr, "linear rows: out2 required for columns >= split_n");
+    T2_REQUIRE(k.out || k.out_t || k.split_n <= 0, "linear rows: no destination for the activated columns");
+    // one 16-row tile per workgroup, row blocks over blockIdx.y: these launches have few column tiles (16-22), so the rows
+    // are what spreads them over the chip; each workgroup streams its 16 weight rows (re-read from L2 by the other row
+    // blocks) and 16 activation rows
+    const int ny = t2_cdiv(k.B, 16);
+    dim3 grid(t2_cdiv(k.N, 16) + (k.stop_proj ? 1 : 0), ny), block(256);
+    hipLaunchKernelGGL((linear_rows_kernel<1>), grid, block, 0, st, k);
     T2_CHECK_LAUNCH();
     return T2_OK;
 }
 
-__global__ void stop_kernel(const float* proj, long ldp, int M, int B, int t, int32_t* done, int64_t* lengths, int32_t* state) {
+__global__ void stop_kernel(const float* proj, long ldp, int M, int B, int t, int32_t* done, int32_t* state) {
     __shared__ int notdone;
-    stop_logic(proj, ldp, M, B, t, done, lengths, state, &notdone);
+    stop_logic(proj, ldp, M, B, t, done, state, &notdone);
+}
+
+// Exact break frame and lengths from the stored stop logits of ALL utterances (several groups: proj_g [n][B_g][ldp]):
+// first[b] = first frame with logit < 0; the loop breaks after frame n* = max_b first[b] (or runs to `nframes` if some
+// utterance never stops); lengths[b] = #{t <= n* : logit[t][b] >= 0}; out2 = {frames emitted, 0}.  One workgroup.
+struct StopScan { const float* proj[8]; int Bg[8]; int ng; long ldp; int M; int nframes; int64_t* lengths; int32_t* out2; };
+__global__ void stop_scan_kernel(StopScan p) {
+    __shared__ int nstar;
+    if (threadIdx.x == 0) nstar = 0;
+    __syncthreads();
+    int Btot = 0;
+    for (int g = 0; g < p.ng; ++g) Btot += p.Bg[g];
+    for (int bb = threadIdx.x; bb < Btot; bb += blockDim.x) {
+        int g = 0, b = bb;
+        while (b >= p.Bg[g]) { b -= p.Bg[g]; ++g; }
+        int first = p.nframes - 1;     // never stops: the loop runs to the cap
+        for (int t = 0; t < p.nframes; ++t)
+            if (p.proj[g][((long)t * p.Bg[g] + b) * p.ldp + p.M] < 0.f) { first = t; break; }
+        atomicMax(&nstar, first);
+    }
+    __syncthreads();
+    const int n = nstar + 1;
+    for (int bb = threadIdx.x; bb < Btot; bb += blockDim.x) {
+        int g = 0, b = bb;
+        while (b >= p.Bg[g]) { b -= p.Bg[g]; ++g; }
+        long cnt = 0;
+        for (int t = 0; t < n; ++t) cnt += p.proj[g][((long)t * p.Bg[g] + b) * p.ldp + p.M] >= 0.f ? 1 : 0;
+        p.lengths[bb] = cnt;
+    }
+    if (threadIdx.x == 0) { p.out2[0] = n; p.out2[1] = 0; }
 }
 
 }  // namespace
@@ -159,11 +198,24 @@ extern "C" int t2_linear_rows(const float* x, int64_t ldx, const float* w, int64
         k.B = (B - b0) < 64 ? (B - b0) : 64; k.N = N; k.K = K;
         k.x = x + (long)b0 * ldx; k.ldx = ldx; k.w = w; k.ldw = ldw; k.bias = bias;
         k.mask = mask ? mask + (long)b0 * ldmask : nullptr; k.ldmask = ldmask; k.relu = relu;
-        k.out = out + (long)b0 * ldo; k.ldo = ldo;
-        k.out_t = nullptr; k.out_col0 = 0; k.out_cs = 0; k.ksplit = 1;
-        k.stop_proj = nullptr;
+        k.out = out + (long)b0 * ldo; k.ldo = ldo; k.split_n = N;
         T2_TRY(launch_linear(k, st));
     }
+    return T2_OK;
+}
+
+extern "C" int t2_stop_scan(const T2StopScan* s, int64_t* lengths, int32_t* out2, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
+    T2_REQUIRE(s && lengths && out2 && s->ngroups >= 1 && s->ngroups <= 8 && s->nframes >= 1, "t2_stop_scan: bad arguments");
+    StopScan p;
+    memset(&p, 0, sizeof(p));
+    for (int g = 0; g < s->ngroups; ++g) {
+        T2_REQUIRE(s->proj[g] && s->Bg[g] >= 1, "t2_stop_scan: bad group");
+        p.proj[g] = s->proj[g]; p.Bg[g] = s->Bg[g];
+    }
+    p.ng = s->ngroups; p.ldp = s->ld_proj; p.M = s->M; p.nframes = s->nframes; p.lengths = lengths; p.out2 = out2;
+    hipLaunchKernelGGL(stop_scan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p);
+    T2_CHECK_LAUNCH();
     return T2_OK;
 }
 
@@ -174,39 +226,40 @@ extern "C" int t2_decoder_infer(const T2Infer* a, int t0, int t1, void* stream) 
     hipStream_t st = (hipStream_t)stream;
     const int B = a->B, L = a->L, A = a->A, D = a->D, Ef = a->Ef, Ad = a->Ad, P = a->P, M = a->M;
     T2_REQUIRE(P % 16 == 0 && A % 16 == 0 && Ef % 16 == 0 && D % 16 == 0, "t2_decoder_infer: P, A, Ef, D must be multiples of 16");
+    T2_REQUIRE(a->W_comb && a->W_pre2 && a->proj && a->xs, "t2_decoder_infer: null operand");
     const long ldp = D + Ef, ldo = a->ld_proj;
     const int Bp = (B + 15) / 16 * 16;
     const long cs = (long)Bp * 16;                               // chunk stride of the tiled state
     const long slot = (long)((P + A + Ef + D) / 16) * cs;        // one tiled slot
-    const int ksplit = (D + Ef) >= 512 ? 8 : 1;                  // the 6-workgroup projection is latency bound: split K
+    // L1 of frame t: [p1_t | mel_{t-1} | stop logit_{t-1}] from xproj_{t-1}
+    auto combined = [&](int t, bool with_mask) -> int {
+        LinK k;
+        memset(&k, 0, sizeof(k));
+        k.B = B; k.N = P + M + 1; k.K = (int)ldp; k.x = a->xproj; k.ldx = ldp; k.w = a->W_comb; k.ldw = ldp; k.bias = a->b_comb;
+        k.rowterm = a->row_comb; k.ldrt = P + M + 1;
+        k.mask = (with_mask && a->prenet_mask) ? a->prenet_mask + ((long)t * 2 + 0) * B * P : nullptr;
+        k.ldmask = P; k.relu = 1; k.split_n = P;
+        k.out = a->p1; k.ldo = P; k.out2 = a->proj + (long)(t - 1) * B * ldo; k.ldo2 = ldo;
+        return launch_linear(k, st);
+    };
     for (int t = t0; t < t1; ++t) {
         float* xs_cur = a->xs + (long)(t & 1) * slot;
         float* xs_nxt = a->xs + (long)((t + 1) & 1) * slot;
-        // prenet on the previous frame (zeros for t = 0), AlwaysDropout masks (model/modules.py)
-        const float* prev = t == 0 ? a->zero_frame : a->proj + (long)(t - 1) * B * ldo;
-        const long ldprev = t == 0 ? 0 : ldo;
-        const float* m1 = a->prenet_mask ? a->prenet_mask + ((long)t * 2 + 0) * B * P : nullptr;
-        const float* m2 = a->prenet_mask ? a->prenet_mask + ((long)t * 2 + 1) * B * P : nullptr;
-        {   // first prenet layer; one extra workgroup of the launch runs the stop logic of frame t-1 (frames of this call only)
-            LinK k;
+        if (t > 0) {
+            T2_TRY(combined(t, true));
+            LinK k;     // second prenet layer -> tiled state; one extra workgroup: stop logic of frame t-1 (frames of this call only)
             memset(&k, 0, sizeof(k));
-            k.B = B; k.N = P; k.K = M; k.x = prev; k.ldx = ldprev; k.w = a->W_pre1; k.ldw = M; k.mask = m1; k.ldmask = P;
-            k.relu = 1; k.out = a->p1; k.ldo = P; k.ksplit = 1;
+            k.B = B; k.N = P; k.K = P; k.x = a->p1; k.ldx = P; k.w = a->W_pre2; k.ldw = P;
+            k.mask = a->prenet_mask ? a->prenet_mask + ((long)t * 2 + 1) * B * P : nullptr;
+            k.ldmask = P; k.relu = 1; k.split_n = P;
+            k.out_t = xs_cur; k.out_col0 = 0; k.out_cs = cs;
             if (t > t0) {
-                k.stop_proj = prev; k.stop_ldp = ldo; k.stop_M = M; k.stop_t = t - 1;
-                k.stop_done = a->done; k.stop_lengths = a->lengths; k.stop_state = a->state;
+                k.stop_proj = a->proj + (long)(t - 1) * B * ldo; k.stop_ldp = ldo; k.stop_M = M; k.stop_t = t - 1;
+                k.stop_done = a->done; k.stop_state = a->state;
             }
             T2_TRY(launch_linear(k, st));
         }
-        {
-            LinK k;
-            memset(&k, 0, sizeof(k));
-            k.B = B; k.N = P; k.K = P; k.x = a->p1; k.ldx = P; k.w = a->W_pre2; k.ldw = P; k.bias = nullptr;
-            k.mask = m2; k.ldmask = P; k.relu = 1; k.out = a->p2; k.ldo = P;
-            k.out_t = xs_cur; k.out_col0 = 0; k.out_cs = cs; k.ksplit = 1;
-            T2_TRY(launch_linear(k, st));
-        }
-        // attention LSTM cell: [prenet_t | att_h_{t-1} | ctx_{t-1}]
+        // attention LSTM cell: [prenet_t | att_h_{t-1} | ctx_{t-1}]  (frame 0: the prenet columns of the zero-filled state)
         T2LstmStep s;
         memset(&s, 0, sizeof(s));
         s.B = B; s.H = A; s.nseg = 1; s.wpacked = a->wp_att;
@@ -244,19 +297,13 @@ extern "C" int t2_decoder_infer(const T2Infer* a, int t0, int t1, void* stream) 
         d.ht_out = xs_cur; d.ht_col0 = P + A + Ef;
         d.c_out = a->dec_c + (long)((t + 1) & 1) * B * D; d.ldc_out = D;
         T2_TRY(t2_lstm_step_fwd_launch(&d, 1, st));
-        // mel + stop projection over xproj = [dec_h | ctx] (K split, atomics into the zero-filled row block), stop logic
-        float* out = a->proj + (long)t * B * ldo;
-        {
-            LinK k;
-            memset(&k, 0, sizeof(k));
-            k.B = B; k.N = M + 1; k.K = (int)ldp; k.x = a->xproj; k.ldx = ldp; k.w = a->W_proj; k.ldw = ldp; k.bias = a->b_proj;
-            k.mask = nullptr; k.ldmask = 0; k.relu = 0; k.out = out; k.ldo = ldo;
-            k.out_t = nullptr; k.out_col0 = 0; k.out_cs = 0; k.ksplit = ksplit;
-            k.accum = a->dec_pre != nullptr;     // the caller pre-filled proj with the mel term of the controls
-            T2_TRY(launch_linear(k, st));
-        }
-        if (t == t1 - 1)   // the last frame of the call: nobody else will run its stop logic before the host looks
-            hipLaunchKernelGGL(stop_kernel, dim3(1), dim3(256), 0, st, out, ldo, M, B, t, a->done, a->lengths, a->state);
+    }
+    if (t1 > t0) {
+        // the last frame of the call: its outputs (mel, stop logit) and stop logic, so that the host can look at the flags.  The
+        // next call's first L1 recomputes the same row bit for bit (and the p1 scratch written here, with its mask).
+        T2_TRY(combined(t1, false));
+        hipLaunchKernelGGL(stop_kernel, dim3(1), dim3(256), 0, st, a->proj + (long)(t1 - 1) * B * ldo, ldo, M, B, t1 - 1, a->done,
+                           a->state);
     }
     T2_CHECK_LAUNCH();
     return T2_OK;

@@ -160,56 +160,26 @@ __global__ __launch_bounds__(256, 1) void lstm_step_fwd_fast_kernel(LstmK2 pp) {
     if (stamp) { g_t2_clk[6] = __builtin_amdgcn_s_memtime(); g_t2_clk[7] = __builtin_amdgcn_s_memrealtime(); }
 }
 
-// Same step with its operand block fetched from a device-resident table entry instead of the kernel-argument segment:
-// a dependent launch with a 16-byte argument block costs 2.8 us, with a 520-byte one 3.7 us (tools/ubench_kernarg.hip).
-template <int MT, int U>
-__global__ __launch_bounds__(256, 1) void lstm_step_fwd_fast_tab_kernel(const T2_CONST_AS LstmK2* tab, int idx) {
-    __shared__ float red[4 * MT * 256];
-    const LstmK p = t2_tab_entry(&tab[idx].s[blockIdx.y]);
-    t2_lstm_fwd_fast_body<MT, U>(p, blockIdx.x, red);
-}
-
-// fill != null: only write the operand block (plan building, no launch);  tab != null: launch the table kernel on entry idx
-int launch_fwd(const T2LstmStep* steps, int n, hipStream_t st, LstmK2* fill = nullptr, const LstmK2* tab = nullptr, int idx = 0) {
+int launch_fwd(const T2LstmStep* steps, int n, hipStream_t st) {
     T2_REQUIRE(n == 1 || n == 2, "lstm step: n must be 1 or 2");
     for (int i = 0; i < n; ++i) T2_TRY(t2_lstm_check_step(steps[i]));
     if (n == 2) T2_REQUIRE(steps[0].B == steps[1].B && steps[0].H == steps[1].H, "lstm step: cells must share B,H");
     const int B = steps[0].B;
-    if (fill || tab) {
-        bool fastp = B <= 64;
-        for (int i = 0; i < n; ++i) fastp = fastp && steps[i].wpacked && steps[i].nseg == 1;
-        T2_REQUIRE(fastp, "lstm step: parameter tables need the packed single-segment path and B <= 64");
-    }
     for (int b0 = 0; b0 < B; b0 += 64) {
         const int bn = (B - b0) < 64 ? (B - b0) : 64;
         LstmK2 kk;
         for (int i = 0; i < n; ++i) t2_lstm_to_k(steps[i], kk.s[i], b0, bn);
         if (n == 1) kk.s[1] = kk.s[0];
-        if (fill) { *fill = kk; return T2_OK; }
         dim3 grid(steps[0].H / 4, n), block(256);
         bool fast = true;
         for (int i = 0; i < n; ++i) fast = fast && steps[i].wpacked && steps[i].nseg == 1;
-        if (tab) {
-            const int ntpad = ((steps[0].seg[0].K >> 4) + 15) & ~15;
-            const bool u8 = (ntpad % 32 == 0) && (n == 1 || ((((steps[1].seg[0].K >> 4) + 15) & ~15) % 32 == 0));
-            const T2_CONST_AS LstmK2* ct = (const T2_CONST_AS LstmK2*)tab;
-            if (bn <= 16) { if (u8) hipLaunchKernelGGL((lstm_step_fwd_fast_tab_kernel<1, 8>), grid, block, 0, st, ct, idx);
-                            else hipLaunchKernelGGL((lstm_step_fwd_fast_tab_kernel<1, 4>), grid, block, 0, st, ct, idx); }
-            else if (bn <= 32) { if (u8) hipLaunchKernelGGL((lstm_step_fwd_fast_tab_kernel<2, 8>), grid, block, 0, st, ct, idx);
-                                 else hipLaunchKernelGGL((lstm_step_fwd_fast_tab_kernel<2, 4>), grid, block, 0, st, ct, idx); }
-            else hipLaunchKernelGGL((lstm_step_fwd_fast_tab_kernel<4, 4>), grid, block, 0, st, ct, idx);
-        } else if (fast) {
-            // 8 chunks per group (24 x 1 KB loads per wave per group, two groups in flight) when the padded chunk count allows
-            const int ntpad = ((steps[0].seg[0].K >> 4) + 15) & ~15;
-            // Pipeline depth: measured in one session on the training step (tools/ab_session.sh), 4 chunks per group beat 8
-            // (82.05 against 82.37 ms), and every deeper variant (two groups requested ahead, all loads of the step issued
-            // at entry) was slower still: past ~24 KB per wave the first operands only arrive later.  T2_CELL_U=8 restores 8.
-            static const int force_u = [] { const char* e = getenv("T2_CELL_U"); return e ? atoi(e) : 4; }();
-            const bool u8 = force_u == 8 && (ntpad % 32 == 0) && (n == 1 || ((((steps[1].seg[0].K >> 4) + 15) & ~15) % 32 == 0));
-            if (bn <= 16) { if (u8) hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<1, 8>), grid, block, 0, st, kk);
-                            else hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<1, 4>), grid, block, 0, st, kk); }
-            else if (bn <= 32) { if (u8) hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<2, 8>), grid, block, 0, st, kk);
-                                 else hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<2, 4>), grid, block, 0, st, kk); }
+        if (fast) {
+            // Pipeline depth: 4 chunks per group (12 x 1 KB loads per wave per group at two row tiles, two groups in flight).
+            // Measured in one session on the training step, 4 chunks per group beat 8 (82.05 against 82.37 ms), and every
+            // deeper variant (two groups requested ahead, all loads of the step issued at entry) was slower still: past
+            // ~24 KB per wave the first operands only arrive later.
+            if (bn <= 16) hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<1, 4>), grid, block, 0, st, kk);
+            else if (bn <= 32) hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<2, 4>), grid, block, 0, st, kk);
             else hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<4, 4>), grid, block, 0, st, kk);
         } else {
             if (bn <= 16) hipLaunchKernelGGL((lstm_step_fwd_kernel<1>), grid, block, 0, st, kk);
@@ -344,13 +314,7 @@ __global__ __launch_bounds__(256, 1) void lstm_step_bwd_fast_kernel(BwdK2 pp) {
     t2_lstm_bwd_fast_body<4, 4>(pp.s[blockIdx.z], blockIdx.x, blockIdx.y, red);
 }
 
-__global__ __launch_bounds__(256, 1) void lstm_step_bwd_fast_tab_kernel(const T2_CONST_AS BwdK2* tab, int idx) {
-    __shared__ float red[4 * 256];
-    const BwdK p = t2_tab_entry(&tab[idx].s[blockIdx.z]);
-    t2_lstm_bwd_fast_body<4, 4>(p, blockIdx.x, blockIdx.y, red);
-}
-
-int launch_bwd(const T2LstmBwdStep* steps, int n, hipStream_t st, BwdK2* fill = nullptr, const BwdK2* tab = nullptr, int idx = 0) {
+int launch_bwd(const T2LstmBwdStep* steps, int n, hipStream_t st) {
     T2_REQUIRE(n == 1 || n == 2, "lstm bwd step: n must be 1 or 2");
     BwdK2 kk;
     for (int i = 0; i < n; ++i) { T2_TRY(t2_lstm_check_bwd(steps[i])); t2_lstm_to_bk(steps[i], kk.s[i]); }
@@ -365,10 +329,7 @@ int launch_bwd(const T2LstmBwdStep* steps, int n, hipStream_t st, BwdK2* fill = 
     int maxcols = steps[0].ncols;
     for (int i = 1; i < n; ++i) maxcols = steps[i].ncols > maxcols ? steps[i].ncols : maxcols;
     dim3 grid(t2_cdiv(maxcols, 16), t2_cdiv(steps[0].B, 16), n), block(256);
-    if (fill || tab) T2_REQUIRE(fast, "lstm bwd step: parameter tables need the packed path");
-    if (fill) { *fill = kk; return T2_OK; }
-    if (tab) hipLaunchKernelGGL(lstm_step_bwd_fast_tab_kernel, grid, block, 0, st, (const T2_CONST_AS BwdK2*)tab, idx);
-    else if (fast) hipLaunchKernelGGL(lstm_step_bwd_fast_kernel, grid, block, 0, st, kk);
+    if (fast) hipLaunchKernelGGL(lstm_step_bwd_fast_kernel, grid, block, 0, st, kk);
     else hipLaunchKernelGGL(lstm_step_bwd_kernel, grid, block, 0, st, kk);
     T2_CHECK_LAUNCH();
     return T2_OK;
@@ -445,14 +406,6 @@ void t2_lstm_bwd_advance(T2LstmBwdStep& c, const T2LstmBwdStride& inc) {
 // internal entries used by the attention sequence (t2_attention.hip)
 int t2_lstm_step_fwd_launch(const T2LstmStep* steps, int n, hipStream_t st) { return launch_fwd(steps, n, st); }
 int t2_lstm_step_bwd_launch(const T2LstmBwdStep* steps, int n, hipStream_t st) { return launch_bwd(steps, n, st); }
-// table variants: fill a host entry / launch from device entry idx (see launch_fwd)
-int t2_lstm_step_fwd_tab(const T2LstmStep* steps, int n, hipStream_t st, LstmK2* fill, const LstmK2* tab, int idx) {
-    return launch_fwd(steps, n, st, fill, tab, idx);
-}
-int t2_lstm_step_bwd_tab(const T2LstmBwdStep* steps, int n, hipStream_t st, BwdK2* fill, const BwdK2* tab, int idx) {
-    return launch_bwd(steps, n, st, fill, tab, idx);
-}
-
 extern "C" int t2_lstm_step_fwd(const T2LstmStep* steps, int n, void* stream) {
     (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(steps != nullptr, "t2_lstm_step_fwd: null");
@@ -474,53 +427,6 @@ extern "C" int t2_lstm_seq_fwd(const T2LstmStep* base, const T2LstmStride* inc, 
         T2_TRY(launch_fwd(cur, n, (hipStream_t)stream));
         for (int i = 0; i < n; ++i) t2_lstm_fwd_advance(cur[i], inc[i]);
     }
-    return T2_OK;
-}
-
-// Planned variants: the operand blocks of all S steps are written once into a table (host side), the caller uploads it,
-// and every launch then carries a 16-byte argument block (table pointer + step index).
-extern "C" int64_t t2_lstm_seq_fwd_plan(const T2LstmStep* base, const T2LstmStride* inc, int n, int S, void* host_tab, int64_t bytes) {
-    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
-    const int64_t need = (int64_t)S * sizeof(LstmK2);
-    if (!host_tab) return need;
-    if (!base || !inc || (n != 1 && n != 2) || S < 0 || bytes < need) return -1;
-    T2LstmStep cur[2];
-    for (int i = 0; i < n; ++i) cur[i] = base[i];
-    LstmK2* tab = (LstmK2*)host_tab;
-    for (int s = 0; s < S; ++s) {
-        if (launch_fwd(cur, n, nullptr, &tab[s]) != T2_OK) return -1;
-        for (int i = 0; i < n; ++i) t2_lstm_fwd_advance(cur[i], inc[i]);
-    }
-    return need;
-}
-
-extern "C" int t2_lstm_seq_fwd_run(const void* dev_tab, const T2LstmStep* base, int n, int s_begin, int s_end, void* stream) {
-    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
-    T2_REQUIRE(dev_tab && base && (n == 1 || n == 2) && s_begin >= 0 && s_end >= s_begin, "t2_lstm_seq_fwd_run: bad arguments");
-    for (int s = s_begin; s < s_end; ++s) T2_TRY(launch_fwd(base, n, (hipStream_t)stream, nullptr, (const LstmK2*)dev_tab, s));
-    return T2_OK;
-}
-
-extern "C" int64_t t2_lstm_seq_bwd_plan(const T2LstmBwdStep* base, const T2LstmBwdStride* inc, int n, int S, void* host_tab,
-                                        int64_t bytes) {
-    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
-    const int64_t need = (int64_t)S * sizeof(BwdK2);
-    if (!host_tab) return need;
-    if (!base || !inc || (n != 1 && n != 2) || S < 0 || bytes < need) return -1;
-    T2LstmBwdStep cur[2];
-    for (int i = 0; i < n; ++i) cur[i] = base[i];
-    BwdK2* tab = (BwdK2*)host_tab;
-    for (int s = 0; s < S; ++s) {
-        if (launch_bwd(cur, n, nullptr, &tab[s]) != T2_OK) return -1;
-        for (int i = 0; i < n; ++i) t2_lstm_bwd_advance(cur[i], inc[i]);
-    }
-    return need;
-}
-
-extern "C" int t2_lstm_seq_bwd_run(const void* dev_tab, const T2LstmBwdStep* base, int n, int s_begin, int s_end, void* stream) {
-    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
-    T2_REQUIRE(dev_tab && base && (n == 1 || n == 2) && s_begin >= 0 && s_end >= s_begin, "t2_lstm_seq_bwd_run: bad arguments");
-    for (int s = s_begin; s < s_end; ++s) T2_TRY(launch_bwd(base, n, (hipStream_t)stream, nullptr, (const BwdK2*)dev_tab, s));
     return T2_OK;
 }
 

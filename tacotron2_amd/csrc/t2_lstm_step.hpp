@@ -264,7 +264,6 @@ __device__ __forceinline__ BwdEpi bwd_epi_load(const BwdK& p, int tid, int u0, i
     if (p.ext1) e.ext = p.ext1[b * p.ldx1 + u];
     if (p.ext2) e.ext += p.ext2[b * p.ldx2 + u];
     if (p.epi == 1) {
-        const int H = p.H;
         if (p.drop) e.drop = p.drop[b * p.lddrop + u];
         const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gates + b * p.ldgs + 4 * u);   // gate-interleaved stash [b][u][4]
         e.gi = g4[0]; e.gf = g4[1]; e.gg = g4[2]; e.go = g4[3];

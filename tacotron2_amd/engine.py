@@ -29,6 +29,10 @@ def _stream():
 
 
 SHARE_CU = [0]     # set to [1] while enqueuing GEMMs that run next to a latency-bound chain on another stream
+# 0: fp32 GEMMs on the bf16 matrix pipe by error-free 3-way operand splitting (csrc/t2_gemm.hip, fp32-accurate, 2.7x the MFMA
+# rate); 1: f32-input MFMA.  One process-wide switch for A/B measurements and the kernel tests.
+import os as _os
+GEMM_NATIVE_FP32 = [int(_os.environ.get("T2_GEMM_NATIVE_FP32", "0"))]
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_k=1, b_k=1, alpha=1.0, bias=None, bias2=None, mulmask=None, ldmask=0,
@@ -36,7 +40,7 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_k=1, b_k=1, alpha=1.0, bias=None, bi
     """C-ABI t2_gemm on raw pointers (ints) or tensors."""
     g = make("T2Gemm", A=A, B=B, C=C, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, a_kmajor=a_k, b_kmajor=b_k,
              alpha=alpha, bias=bias, bias2=bias2, mulmask=mulmask, ldmask=ldmask, relu=relu, accumulate=accumulate,
-             splitk=splitk, batch=batch, sA=sA, sB=sB, sC=sC, share_cu=SHARE_CU[0])
+             splitk=splitk, batch=batch, sA=sA, sB=sB, sC=sC, share_cu=SHARE_CU[0], native_fp32=GEMM_NATIVE_FP32[0])
     call("t2_gemm", g, _stream())
 
 
@@ -69,55 +73,15 @@ class Engine:
         self.dev = ps.device
         self._ws: Dict[str, torch.Tensor] = {}
         self._side = None
-        self._plans: Dict[str, dict] = {}
-        self.use_plans = False        # kernel-parameter tables for the forward frame loop (16-byte kernel arguments): cuts the
-                                      # HOST cost per launch (2.8 vs 3.7 us enqueue rate); GPU-side a dependent launch costs
-                                      # 1.7 us whatever the argument size (tools/ubench_gpu_launch.hip), so off by default
-        self.chunk = 64               # frames per pipeline chunk (two-stream overlap of the two recurrences)
+        self.chunk = 64               # frames per pipeline chunk of the forward frame loop
         self.chunk_bwd = 80           # frames per chunk of the backward pipeline (80*32 rows = 240 tiles of the dxdec GEMM)
-        self.co_schedule = True       # forward: decoder-LSTM steps ride in the attention-context launches (T2AttnSeq.co_step)
-        self.co_schedule_bwd = False  # backward: decoder-LSTM BPTT steps ride in the attention-ds launches (measured
-                                      # slower than the two-stream pipeline at B=32: 41.5 vs 39.9 ms, profiles/README.md)
-        import os as _os               # tuning overrides for experiments (tools/)
-        self.chunk = int(_os.environ.get("T2_CHUNK", self.chunk))
-        self.chunk_bwd = int(_os.environ.get("T2_CHUNK_BWD", self.chunk_bwd))
-        self.co_schedule = _os.environ.get("T2_CO_SCHEDULE", "1") != "0"
-        self.co_schedule_bwd = _os.environ.get("T2_CO_SCHEDULE_BWD", "0") != "0"
-        self.use_plans = _os.environ.get("T2_USE_PLANS", "0") != "0"
-        self.bwd_lag = int(_os.environ.get("T2_BWD_LAG", "1"))     # co-scheduled backward only: 1 = chunk GEMMs on the main stream, 2 = side stream
-        self.fwd_lag = int(_os.environ.get("T2_FWD_LAG", "1"))     # 1: chunk GEMMs on the main stream between chunks; 2: on the side stream
-        self.share_cu = int(_os.environ.get("T2_SHARE_CU", "1"))   # side-stream GEMMs next to the chains at ONE workgroup per CU: two
-                                                                   # 73 KB-LDS workgroups per CU lock the attention kernels out (84.3 -> 83.2 ms)
-        self.co_host = int(_os.environ.get("T2_CO_HOST", "1"))   # where the co-scheduled decoder cell rides: 1 = energies launch (measured best:
-                                                                 # 26.85 ms vs 27.2 ms in the context launch, 29.2 ms split over both)
+        self.share_cu = 1             # side-stream GEMMs next to the chains at ONE workgroup per CU: two 73 KB-LDS workgroups
+                                      # per CU lock the attention kernels out (84.3 -> 83.2 ms)
+        self.sync_bn_group = None     # torch.distributed group: BatchNorm statistics over all ranks' shards (Trainer(sync_bn=True))
         self.generation = 0           # bumped by every forward: activations live in the shared named workspaces,
                                       # so only the LATEST forward can be back-propagated (checked in backward_tf)
         self.profile = False          # when True, mark() records HIP events at segment boundaries
         self.marks = []; self.spans = []               # [(name, event)] of the current step
-
-    # ---- kernel-parameter tables ("plans", include/tacotron2_amd.h T2AttnSeq.plan) ---------------------------------
-    def plan_upload(self, name: str, plan_fn, *args):
-        """Build a table with the C plan function into pinned host memory (ring of 3 slots, so the host may run ahead of
-        the device) and copy it to its device buffer on the current stream.  Returns the device pointer."""
-        from ._lib import call_value
-        nbytes = int(call_value(plan_fn, *args, None, 0))
-        if nbytes < 0:
-            raise _lib.T2Error(f"{plan_fn} failed: {_lib.lib().t2_last_error().decode()}")
-        slot = self._plans.setdefault(name, dict(dev=None, host=[None] * 3, ev=[None] * 3, i=0))
-        i = slot["i"]; slot["i"] = (i + 1) % 3
-        if slot["host"][i] is None or slot["host"][i].numel() < nbytes:
-            slot["host"][i] = torch.empty(max(nbytes, 1), dtype=torch.uint8, pin_memory=True)
-        if slot["ev"][i] is not None:
-            slot["ev"][i].synchronize()                 # the copy that last read this pinned slot has run
-        host = slot["host"][i]
-        if int(call_value(plan_fn, *args, host.data_ptr(), nbytes)) != nbytes:
-            raise _lib.T2Error(f"{plan_fn} failed: {_lib.lib().t2_last_error().decode()}")
-        if slot["dev"] is None or slot["dev"].numel() < nbytes:
-            slot["dev"] = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.dev)
-        slot["dev"][:nbytes].copy_(host[:nbytes], non_blocking=True)
-        ev = torch.cuda.Event(); ev.record()
-        slot["ev"][i] = ev
-        return slot["dev"].data_ptr()
 
     def side_stream(self):
         if self._side is None:
@@ -227,14 +191,27 @@ class Engine:
         gemm(x_pad, wp, raw, B * Lp - 4, Co, 5 * Ci, Ci, 5 * Ci, Co, bias=bias)
         mean = self.buf(f"{tag}.mean", Co)
         invstd = self.buf(f"{tag}.invstd", Co)
-        sums = self.buf(f"{tag}.sums", 2 * Co, dtype=torch.float64)
+        sums = self.buf(f"{tag}.sums", 2 * Co + 2, dtype=torch.float64)
         if y is None:
             y = self.buf(f"{tag}.y", B, Lp, Co)
             Lp_y = Lp
+        sync = training and self.sync_bn_group is not None
         bn = make("T2Bn", B=B, L=L, C=Co, x=raw, Lp_x=Lp, gamma=P[bn_prefix + ".weight"], beta=P[bn_prefix + ".bias"],
                   running_mean=Bf[bn_prefix + ".running_mean"], running_var=Bf[bn_prefix + ".running_var"],
                   training=1 if training else 0, momentum=0.1, eps=1e-5, sums=sums, mean=mean, invstd=invstd, act=act,
                   drop=drop, res=res, Lp_res=Lp_res, pad_res=pad_res, len=length, fill=fill, y=y, Lp_y=Lp_y, pad_y=pad_y)
+        if sync:
+            # synchronised batch statistics: every rank sums (x - shift), (x - shift)^2 and its row count, ONE all-reduce of
+            # 2C + 2 doubles per layer, then every rank normalises with the statistics of the global batch (what the
+            # single-device reference computes over 8 x 32 = 256 utterances).  The shift must be the same on every rank:
+            # a copy of the running mean taken BEFORE this step's update.
+            shift = self.buf(f"{tag}.shift", Co)
+            shift.copy_(Bf[bn_prefix + ".running_mean"])
+            bn.shift = shift.data_ptr(); bn.phase = 1
+            call("t2_bn_fwd", bn, _stream())
+            import torch.distributed as dist
+            dist.all_reduce(sums, group=self.sync_bn_group)
+            bn.phase = 2
         call("t2_bn_fwd", bn, _stream())
         if training:
             self.ps.num_batches_tracked[bn_prefix + ".num_batches_tracked"] += 1
@@ -405,8 +382,7 @@ class Engine:
                    W_hh=P["decoder.att_rnn.weight_hh"], Wq=P["decoder.attention.query_layer.weight"], U=U,
                    v=P["decoder.attention.v.weight"], pre=pre_att, pmT=pmT, memory=memory, len=len32,
                    att_drop=masks.get("att_drop"), xdec=xdec, att_c=att_c, gates=gates_att, align=align, cum=cum, th=th,
-                   xproj_ctx=_ptr(xproj, B * (D + Ef) + D), ld_xproj=D + Ef, e_part=e_part, xdec_t=xdec_t,
-                   co_host=self.co_host)
+                   xproj_ctx=_ptr(xproj, B * (D + Ef) + D), ld_xproj=D + Ef, e_part=e_part, xdec_t=xdec_t)
         # decoder-LSTM chain operands (prepared before the pipeline below)
         pre_dec = self.buf("pre_dec", T, B, 4 * D)
         dec_c = self.buf("dec_c", T + 1, B, D)
@@ -416,12 +392,12 @@ class Engine:
         ldp = D + Ef
         wp_dec = self.pack_fwd("dec", [(P["decoder.lstm.weight_hh"], D, D)], D)
         # Software pipeline over chunks of CH frames.  In teacher-forced mode the attention chain never reads the decoder
-        # LSTM (model/decoder.py:70-101), so the decoder-LSTM chain of chunk i-2 is CO-SCHEDULED inside the attention
-        # chain of chunk i: its step rides in the attention-context launch of a frame (extra workgroups in the same
-        # launch, T2AttnSeq.co_step), and the hoisted input-projection GEMM of chunk i-1 runs meanwhile on the side stream.
+        # LSTM (model/decoder.py:70-101), so the decoder-LSTM chain of chunk i-1 is CO-SCHEDULED inside the attention chain of
+        # chunk i: its step rides in the attention-energies launch of a frame (extra workgroups in the same launch,
+        # T2AttnSeq.co_step), and the hoisted input-projection GEMM of a chunk runs on the main stream between chunks.
         # Measured (tools/ubench_cell.hip, profiles/): step kernels of two streams do NOT overlap each other and two cells
-        # in one launch take the sum of their times, but a cell step next to the latency-bound context workgroups does
-        # overlap, and the large side-stream GEMMs fill the gaps of the main chain.
+        # in one launch take the sum of their times, but a cell step next to the latency-bound energies workgroups does
+        # overlap.  Batches above 32 rows (no room for the hosted cell) fall back to a plain two-stream pipeline.
         CH = self.chunk
 
         def dec_chunk(c0, c1):
@@ -451,45 +427,17 @@ class Engine:
         side.wait_stream(main)
         import ctypes as _C
         chunks = [(c0, min(T, c0 + CH)) for c0 in range(0, T, CH)]
-        co = B <= 32 and self.co_schedule     # co-scheduling needs <= 32 batch rows; otherwise plain two-stream pipeline
-        plans = self.use_plans and B <= 64
-        drain_from = T
-        if plans:
-            # one table for the whole chain: per-frame operand blocks of the attention cell, the attention kernels and the
-            # co-scheduled decoder cell (decoder frame j rides attention frame j + CH)
-            if co and T > CH:
-                stp_all, inc_all = dec_chunk(0, T)
-                seq.co_step, seq.co_inc = _C.pointer(stp_all), _C.pointer(inc_all)
-                seq.co_steps, seq.co_first = T - CH, CH
-                drain_from = T - CH
-            else:
-                seq.co_step, seq.co_inc, seq.co_steps, seq.co_first = None, None, 0, 0
-                drain_from = 0
-            seq.t_begin, seq.t_end = 0, 0
-            seq.plan = self.plan_upload("fwd.attn", "t2_attn_seq_fwd_plan", seq)
-        lag = self.fwd_lag if (co and not plans) else 1      # 2: the chunk GEMMs run on the side stream, one chunk behind
-        gemm_done = []
+        co = B <= 32                            # the hosted cell needs <= 32 batch rows (register budget of the host kernel)
         for i, (c0, c1) in enumerate(chunks):
             seq.t_begin, seq.t_end = c0, c1
-            if not plans:
-                if co and i >= lag:
-                    if lag > 1:
-                        main.wait_event(gemm_done[i - lag])
-                    stp, inc = dec_chunk(*chunks[i - lag])
-                    seq.co_step, seq.co_inc = _C.pointer(stp), _C.pointer(inc)
-                    seq.co_steps = chunks[i - lag][1] - chunks[i - lag][0]
-                else:
-                    seq.co_step, seq.co_inc, seq.co_steps = None, None, 0
+            if co and i >= 1:
+                stp, inc = dec_chunk(*chunks[i - 1])
+                seq.co_step, seq.co_inc = _C.pointer(stp), _C.pointer(inc)
+                seq.co_steps = chunks[i - 1][1] - chunks[i - 1][0]
+            else:
+                seq.co_step, seq.co_inc, seq.co_steps = None, None, 0
             call("t2_attn_seq_fwd", seq, st)
-            if co and lag > 1:
-                ev = main.record_event()
-                with torch.cuda.stream(side):
-                    side.wait_event(ev)
-                    SHARE_CU[0] = self.share_cu
-                    pre_dec_gemm(c0, c1)
-                    SHARE_CU[0] = 0
-                    gemm_done.append(side.record_event())
-            elif co:
+            if co:
                 pre_dec_gemm(c0, c1)
             else:
                 ev = main.record_event()
@@ -500,10 +448,9 @@ class Engine:
                     call("t2_lstm_seq_fwd", stp, inc, 1, c1 - c0, side.cuda_stream)
         self.mark("fwd.dec.attn_chain")
         main.wait_stream(side)
-        if co:                                  # drain: the decoder-LSTM frames that found no attention frame to ride in
-            d0 = drain_from if plans else chunks[max(0, len(chunks) - lag)][0]
-            stp, inc = dec_chunk(d0, T)
-            call("t2_lstm_seq_fwd", stp, inc, 1, T - d0, st)
+        if co:                                  # drain: the decoder-LSTM frames of the last chunk found no attention frame to ride in
+            stp, inc = dec_chunk(*chunks[-1])
+            call("t2_lstm_seq_fwd", stp, inc, 1, chunks[-1][1] - chunks[-1][0], st)
         self.mark("fwd.dec.lstm_chain_tail")
 
         # mel + stop projection over all frames: [mel_out.weight ; gate.weight] is one (M+1, D+Ef) matrix
@@ -554,11 +501,18 @@ class Engine:
         Lp = L + 4
         st = _stream()
         draw = self.buf(f"{tag}.draw", B, Lp, Co)
-        sums = self.buf(f"{tag}.sums", 2 * Co, dtype=torch.float64)
+        sums = self.buf(f"{tag}.sums", 2 * Co + 2, dtype=torch.float64)
         bn = make("T2Bn", B=B, L=L, C=Co, x=c["raw"], Lp_x=Lp, gamma=P[bn_prefix + ".weight"], beta=P[bn_prefix + ".bias"],
                   training=1 if training else 0, momentum=0.1, eps=1e-5, sums=sums, mean=c["mean"], invstd=c["invstd"],
                   act=act, drop=c["drop"], dy=dy, Lp_dy=Lp_dy, pad_dy=pad_dy, dx=draw, Lp_dx=Lp, pad_dx=2,
                   dgamma=G[bn_prefix + ".weight"], dbeta=G[bn_prefix + ".bias"])
+        if training and self.sync_bn_group is not None:
+            # the batch-statistics terms of the BN backward (sum dz, sum dz * xhat) are sums over the GLOBAL batch too
+            import torch.distributed as dist
+            bn.phase = 1
+            call("t2_bn_bwd", bn, st)
+            dist.all_reduce(sums, group=self.sync_bn_group)
+            bn.phase = 2; bn.grad_share = 1.0 / dist.get_world_size(self.sync_bn_group)
         call("t2_bn_bwd", bn, st)
         R = B * Lp - 4
         if gbias is not None:
@@ -694,7 +648,8 @@ class Engine:
                 SHARE_CU[0] = 0
                 db = self.buf("db_dec", 4 * D, zero=True)                      # both biases see the same gate gradients
                 call("t2_colsum", dgd, 4 * D, R, 4 * D, db, side.cuda_stream)
-                G["decoder.lstm.bias_ih"].add_(db); G["decoder.lstm.bias_hh"].add_(db)
+                for nm in ("decoder.lstm.bias_ih", "decoder.lstm.bias_hh"):    # t2_colsum over ONE row = accumulate
+                    call("t2_colsum", db, 4 * D, 1, 4 * D, G[nm], side.cuda_stream)
                 if ctl is not None:
                     s_dgd = self.buf("ctl.dgd_sum", B, 4 * D, zero=True)
                     call("t2_colsum", dgd, B * 4 * D, T, B * 4 * D, s_dgd, side.cuda_stream)
@@ -702,59 +657,16 @@ class Engine:
                                 ctl.shape[1], B)
 
         chunks = [(hi, max(0, hi - CH)) for hi in range(T, 0, -CH)]
-        if self.co_schedule_bwd:
-            # software pipeline with lag `bwd_lag`: the decoder-LSTM BPTT of chunk k+lag is co-scheduled inside the attention
-            # chain of chunk k (its step rides in the attention-ds launch, T2AttnSeqBwd.co_step); the GEMM that turns a
-            # chunk's decoder gate gradients into d[att_h, ctx] runs between chunks on the main stream (lag 1) or, one
-            # chunk ahead, on the side stream (lag 2)
-            import ctypes as _C
-            n, lag = len(chunks), self.bwd_lag
-            gemm_done = [None] * n
-
-            def chunk_gemm(i):
-                if lag == 1:
-                    dxdec_gemm(*chunks[i])
-                else:
-                    ev = main.record_event()
-                    with torch.cuda.stream(side):
-                        side.wait_event(ev)
-                        dxdec_gemm(*chunks[i])
-                        gemm_done[i] = side.record_event()
-
-            for i in range(min(lag, n)):                   # prologue: the first `lag` decoder chunks run alone
-                s, inc = dec_bwd_chunk(*chunks[i])
-                call("t2_lstm_seq_bwd", s, inc, 1, chunks[i][0] - chunks[i][1], st)
-                if i == 0:
-                    dxdec_gemm(*chunks[0])
-            for k, (hi, lo) in enumerate(chunks):
-                if lag > 1 and k + 1 < n:
-                    chunk_gemm(k + 1)                      # decoder chunk k+1 is complete on the main stream at this point
-                sb.t_hi, sb.t_lo = hi, lo
-                if k + lag < n:
-                    s, inc = dec_bwd_chunk(*chunks[k + lag])
-                    sb.co_step, sb.co_inc = _C.pointer(s), _C.pointer(inc)
-                    sb.co_steps = chunks[k + lag][0] - chunks[k + lag][1]
-                else:
-                    sb.co_step, sb.co_inc, sb.co_steps = None, None, 0
-                    if k + lag == n or (n <= lag and k == 0):   # all decoder gate gradients are final
-                        side.wait_stream(main)
-                        dec_wgrads()
-                if gemm_done[k] is not None:
-                    main.wait_event(gemm_done[k])
-                call("t2_attn_seq_bwd", sb, st)
-                if lag == 1 and k + 1 < n:
-                    chunk_gemm(k + 1)
-        else:
-            for hi, lo in chunks:
-                with torch.cuda.stream(side):
-                    s, inc = dec_bwd_chunk(hi, lo)
-                    call("t2_lstm_seq_bwd", s, inc, 1, hi - lo, side.cuda_stream)
-                    dxdec_gemm(hi, lo)
-                    ev = side.record_event()
-                main.wait_event(ev)
-                sb.t_hi, sb.t_lo = hi, lo
-                call("t2_attn_seq_bwd", sb, st)
-            dec_wgrads()
+        for hi, lo in chunks:
+            with torch.cuda.stream(side):
+                s, inc = dec_bwd_chunk(hi, lo)
+                call("t2_lstm_seq_bwd", s, inc, 1, hi - lo, side.cuda_stream)
+                dxdec_gemm(hi, lo)
+                ev = side.record_event()
+            main.wait_event(ev)
+            sb.t_hi, sb.t_lo = hi, lo
+            call("t2_attn_seq_bwd", sb, st)
+        dec_wgrads()
         self.mark("bwd.dec.chains")
 
         # gradient w.r.t. the encoder memory: context path (batched over samples) + processed-memory path.  It heads the
@@ -776,7 +688,8 @@ class Engine:
             self._wgrad(dga, ldz, xdec, ldx, G["decoder.att_rnn.weight_hh"], A, 4 * A, A, R)
             db = self.buf("db_att", 4 * A, zero=True)
             call("t2_colsum", dga, ldz, R, 4 * A, db, sst)
-            G["decoder.att_rnn.bias_ih"].add_(db); G["decoder.att_rnn.bias_hh"].add_(db)
+            for nm in ("decoder.att_rnn.bias_ih", "decoder.att_rnn.bias_hh"):
+                call("t2_colsum", db, 4 * A, 1, 4 * A, G[nm], sst)
             self._wgrad(dq, ldz, _ptr(xdec, B * ldx), ldx, G["decoder.attention.query_layer.weight"], A, Ad, A, R)
             call("t2_colsum", dv_part, Ad, B, Ad, G["decoder.attention.v.weight"], sst)
             dU = self.buf("dU", Ad, 2 * KL, zero=True)
@@ -899,106 +812,145 @@ class Engine:
     # =============================================================================================
     # autoregressive inference: forward(teacher_forcing=False, max_len_override=N)  (model/tacotron2.py:262-325)
     # =============================================================================================
-    def infer(self, chars_idx, chars_len, max_len, speaker_id=None, description_embeddings=None, training=False,
-              prenet_masks=None, seed=0, check_every=32, controls=None):
-        """Returns (mels, mels_post, gates, alignments) exactly as the reference's non-teacher-forced forward.
-        prenet_masks: optional [n][2][B][P] scale masks (parity tests); otherwise Philox masks (AlwaysDropout)."""
+    def _infer_group(self, g, chars_idx, chars_len, Tcap, speaker_id, description_embeddings, training, prenet_masks, controls):
+        """Encoder, conditioning and decode-loop operands of one group of <= 64 utterances (workspaces prefixed inf<g>.)."""
         d, P, ps = self.d, self.ps.P, self.ps
         B, L = chars_idx.shape
-        assert B <= 64, "engine.infer handles up to 64 utterances per call (callers split larger batches)"
-        self.generation += 1          # the encoder / postnet workspaces are shared with forward_tf
         M, E, Pd, A, D, Ad = d["num_mels"], d["encoded_dim"], d["prenet_dim"], d["att_rnn_dim"], d["rnn_hidden_dim"], d["att_dim"]
         Ef = E + (128 if d.get("description_embeddings") else 0)
         F = d.get("loc_filters", 32)
         st = _stream()
-        ctx: dict = {}
+        pf = f"inf{g}."
         len32 = chars_len.to(torch.int32)
-        enc = self.encoder_fwd(chars_idx, len32, training, {}, ctx)
-        memory = self.buf("memory", B, L, Ef)
+        enc = self.encoder_fwd(chars_idx, len32, training, {}, {})
+        memory = self.buf(pf + "memory", B, L, Ef)
         desc = None
         if d.get("description_embeddings"):
-            desc = self.buf("desc", B, 128)
+            desc = self.buf(pf + "desc", B, 128)
             Dd = d["description_embeddings_dim"]
             gemm(description_embeddings, P["description_embeddings_linear.0.weight"], desc, B, 128, Dd, Dd, Dd, 128)
             call("t2_tanh_bias", desc, P["description_embeddings_linear.0.bias"], B, 128, st)
         spk32 = speaker_id.to(torch.int32) if d.get("speaker_tokens") else None
         call("t2_condition_fwd", enc, P["speaker_embedding.weight"] if d.get("speaker_tokens") else None, spk32, desc,
              memory, B, L, E, Ef, st)
-        pmT = self.buf("pmT", B, Ad, L)
+        pmT = self.buf(pf + "pmT", B, Ad, L)
         gemm(P["att_encoder.weight"], memory, pmT, Ad, L, Ef, Ef, Ef, L, batch=B, sA=0, sB=L * Ef, sC=Ad * L)
-        U = self.buf("U", Ad, 2, KL)
-        call("t2_attn_fold_location", P["decoder.attention.location_dense.weight"],
-             P["decoder.attention.location_conv.weight"], U, Ad, F, KL, st)
-
-        Tcap = int(max_len)
-        lda, ldd, ldp = A + Ef + Pd, A + Ef + D, D + Ef
+        ldp = D + Ef
         ldo = (M + 1 + 3) // 4 * 4
+        Bp = (B + 15) // 16 * 16
+        xs = self.buf(pf + "xs", 2, (Pd + A + Ef + D) // 16, Bp, 16, zero=True)
+        att_h = self.buf(pf + "att_h", B, A, zero=True)
+        att_c = self.buf(pf + "att_c", 2, B, A, zero=True)
+        dec_c = self.buf(pf + "dec_c", 2, B, D, zero=True)
+        cum = self.buf(pf + "cum", 2, B, L, zero=True)
+        xproj = self.buf(pf + "xproj", B, ldp)
+        p1 = self.buf(pf + "p1", B, Pd)
+        e_part = self.buf(pf + "e_part", B, Ad // 16, L)
+        proj = self.buf(pf + "proj", Tcap, B, ldo)
+        align = torch.zeros(B, Tcap, L, dtype=torch.float32, device=self.dev)
+        done = self.buf(pf + "done", B, dtype=torch.int32, zero=True)
+        state = self.buf(pf + "state", 2, dtype=torch.int32, zero=True)
+        _, cterm, cmel1 = self.controls_terms(controls, B)
+        row_comb = None
+        if cmel1 is not None:        # per-utterance controls term of the folded linear: [W_pre1 . cmel_b ; cmel_b ; 0]
+            row_comb = self.buf(pf + "row_comb", B, Pd + M + 1)
+            gemm(cmel1, P["prenet.0.weight"], row_comb, B, Pd, M, M + 1, M, Pd + M + 1)
+            row_comb[:, Pd:].copy_(cmel1)
+            cterm = cterm.clone()    # (controls_terms reuses one workspace per engine)
+        if prenet_masks is not None:
+            pm = prenet_masks
+        elif float(d["dropout"]) > 0.0:
+            pm = self.buf(pf + "pmask", Tcap, 2, B, Pd)
+        else:
+            pm = None
+        a = make("T2Infer", B=B, L=L, A=A, D=D, Ef=Ef, Ad=Ad, P=Pd, M=M, Kl=KL, Tcap=Tcap,
+                 W_comb=self._w_comb, b_comb=self._b_comb, row_comb=row_comb, W_pre2=P["prenet.3.weight"],
+                 wp_att=self._wp_att_inf, b_att_ih=P["decoder.att_rnn.bias_ih"], b_att_hh=P["decoder.att_rnn.bias_hh"],
+                 wp_dec=self._wp_dec_inf, b_dec_ih=P["decoder.lstm.bias_ih"], b_dec_hh=P["decoder.lstm.bias_hh"],
+                 Wq=P["decoder.attention.query_layer.weight"], U=self._U_inf, v=P["decoder.attention.v.weight"],
+                 pmT=pmT, memory=memory, len=len32, prenet_mask=pm, xs=xs, att_h=att_h, att_c=att_c, dec_c=dec_c, cum=cum,
+                 xproj=xproj, p1=p1, e_part=e_part, proj=proj, ld_proj=ldo, align=align, done=done, state=state, dec_pre=cterm)
+        return dict(a=a, B=B, proj=proj, align=align, state=state, pm=pm, philox=prenet_masks is None and pm is not None)
+
+    def infer(self, chars_idx, chars_len, max_len, speaker_id=None, description_embeddings=None, training=False,
+              prenet_masks=None, seed=0, check_every=32, controls=None):
+        """Returns (mels, mels_post, gates, alignments, lengths) exactly as the reference's non-teacher-forced forward: ONE loop
+        over the whole batch that ends when every utterance has produced a negative stop logit (model/tacotron2.py:319-322).
+        Batches above 64 utterances are decoded as groups of 64 in lock-step chunks of `check_every` frames; the break frame
+        and `lengths` are taken from the stored stop logits of all groups (t2_stop_scan).
+        prenet_masks: optional [n][2][B][P] scale masks (parity tests); otherwise Philox masks (AlwaysDropout)."""
+        d, P, ps = self.d, self.ps.P, self.ps
+        B, L = chars_idx.shape
+        assert B <= 512, "engine.infer handles up to 512 utterances per call"
+        self.generation += 1          # the encoder / postnet workspaces are shared with forward_tf
+        M, E, Pd, A, D = d["num_mels"], d["encoded_dim"], d["prenet_dim"], d["att_rnn_dim"], d["rnn_hidden_dim"]
+        Ef = E + (128 if d.get("description_embeddings") else 0)
+        F = d.get("loc_filters", 32)
+        st = _stream()
+        Tcap = int(max_len)
+        if prenet_masks is not None:
+            Tcap = min(Tcap, int(prenet_masks.shape[0]))     # only as many frames as masks were supplied
+        ldp = D + Ef
+        # ---- per-call operands shared by all groups ----
+        self._U_inf = self.buf("U", d["att_dim"], 2, KL)
+        call("t2_attn_fold_location", P["decoder.attention.location_dense.weight"],
+             P["decoder.attention.location_conv.weight"], self._U_inf, d["att_dim"], F, KL, st)
         Wih_a, Wih_d = P["decoder.att_rnn.weight_ih"], P["decoder.lstm.weight_ih"]
         # packed in the column order of the tiled state [prenet | att_h | ctx | dec_h] (csrc/t2_infer.hip)
-        wp_att = self.pack_fwd("inf.att", [(Wih_a, Pd + Ef, Pd), (P["decoder.att_rnn.weight_hh"], A, A),
-                                           (_ptr(Wih_a, Pd), Pd + Ef, Ef)], A)
-        wp_dec = self.pack_fwd("inf.dec", [(Wih_d, A + Ef, A), (_ptr(Wih_d, A), A + Ef, Ef),
-                                           (P["decoder.lstm.weight_hh"], D, D)], D)
-        Bp = (B + 15) // 16 * 16
-        xs = self.buf("inf.xs", 2, (Pd + A + Ef + D) // 16, Bp, 16, zero=True)
-        att_h = self.buf("inf.att_h", B, A, zero=True)
-        att_c = self.buf("inf.att_c", 2, B, A, zero=True)
-        dec_c = self.buf("inf.dec_c", 2, B, D, zero=True)
-        cum = self.buf("inf.cum", 2, B, L, zero=True)
-        xproj = self.buf("inf.xproj", B, ldp)
-        p1 = self.buf("inf.p1", B, Pd)
-        p2 = self.buf("inf.p2", B, Pd)
-        e_part = self.buf("e_part", B, Ad // 16, L)
-        proj = self.buf("inf.proj", Tcap, B, ldo, zero=True)     # the projection accumulates K slices atomically
-        _, cterm, cmel1 = self.controls_terms(controls, B)
-        if cmel1 is not None:                                    # ... on top of the per-utterance controls term
-            proj[:, :, :M + 1].copy_(cmel1.unsqueeze(0).expand(Tcap, B, M + 1))
-        align = torch.zeros(B, Tcap, L, dtype=torch.float32, device=self.dev)
-        zero_frame = self.buf("inf.zero", max(M, 64), zero=True)
-        done = self.buf("inf.done", B, dtype=torch.int32, zero=True)
-        lengths = self.buf("inf.lengths", B, dtype=torch.int64, zero=True)
-        state = self.buf("inf.state", 2, dtype=torch.int32, zero=True)
-        p = float(d["dropout"])
+        self._wp_att_inf = self.pack_fwd("inf.att", [(Wih_a, Pd + Ef, Pd), (P["decoder.att_rnn.weight_hh"], A, A),
+                                                     (_ptr(Wih_a, Pd), Pd + Ef, Ef)], A)
+        self._wp_dec_inf = self.pack_fwd("inf.dec", [(Wih_d, A + Ef, A), (_ptr(Wih_d, A), A + Ef, Ef),
+                                                     (P["decoder.lstm.weight_hh"], D, D)], D)
+        # first prenet layer folded onto the mel projection: W_comb = [W_pre1 . W_mel ; W_mel ; W_gate] (include/tacotron2_amd.h)
         wproj = ps.cat_view("decoder.mel_out.weight", M + 1, ldp)
         bproj = ps.cat_view("decoder.mel_out.bias", M + 1, 0)
+        self._w_comb = self.buf("inf.w_comb", Pd + M + 1, ldp)
+        self._b_comb = self.buf("inf.b_comb", Pd + M + 1)
+        gemm(P["prenet.0.weight"], wproj, self._w_comb, Pd, ldp, M, M, ldp, ldp, a_k=1, b_k=0)
+        gemm(P["prenet.0.weight"], bproj, self._b_comb, Pd, 1, M, M, 1, 1, a_k=1, b_k=0)
+        self._w_comb[Pd:].copy_(wproj); self._b_comb[Pd:].copy_(bproj)
+        groups = []
+        for g, b0 in enumerate(range(0, B, 64)):
+            sl = slice(b0, min(B, b0 + 64))
+            groups.append(self._infer_group(
+                g, chars_idx[sl].contiguous(), chars_len[sl], Tcap,
+                speaker_id[sl] if speaker_id is not None else None,
+                description_embeddings[sl].contiguous() if description_embeddings is not None else None, training,
+                prenet_masks[:, :, sl].contiguous() if (prenet_masks is not None and B > 64) else prenet_masks,
+                controls[sl] if controls is not None else None))
+        p = float(d["dropout"])
         t0 = 0
+        self.mark("inf.encoder")
         while t0 < Tcap:
             t1 = min(Tcap, t0 + check_every)
-            if prenet_masks is not None:
-                pm = prenet_masks
-                pm_ptr = pm.data_ptr()
-                assert pm.shape[0] >= t1 or pm.shape[0] >= 1
-            elif p > 0.0:
-                pm = self.buf("inf.pmask", Tcap, 2, B, Pd)
-                n = (t1 - t0) * 2 * B * Pd
-                call("t2_philox_mask", _ptr(pm, t0 * 2 * B * Pd), n, p, seed, 1000 + t0, st)
-                pm_ptr = pm.data_ptr()
-            else:
-                pm, pm_ptr = None, None
-            if prenet_masks is not None:
-                t1 = min(t1, int(prenet_masks.shape[0]))   # only as many frames as masks were supplied
-            a = make("T2Infer", B=B, L=L, A=A, D=D, Ef=Ef, Ad=Ad, P=Pd, M=M, Kl=KL, Tcap=Tcap,
-                     W_pre1=P["prenet.0.weight"], W_pre2=P["prenet.3.weight"], wp_att=wp_att,
-                     b_att_ih=P["decoder.att_rnn.bias_ih"], b_att_hh=P["decoder.att_rnn.bias_hh"], wp_dec=wp_dec,
-                     b_dec_ih=P["decoder.lstm.bias_ih"], b_dec_hh=P["decoder.lstm.bias_hh"],
-                     Wq=P["decoder.attention.query_layer.weight"], U=U, v=P["decoder.attention.v.weight"],
-                     W_proj=wproj, b_proj=bproj, pmT=pmT, memory=memory, len=len32, prenet_mask=pm_ptr,
-                     zero_frame=zero_frame, xs=xs, att_h=att_h, att_c=att_c, dec_c=dec_c, cum=cum, xproj=xproj, p1=p1, p2=p2,
-                     e_part=e_part, proj=proj, ld_proj=ldo, align=align, done=done, lengths=lengths, state=state,
-                     dec_pre=cterm)
-            call("t2_decoder_infer", a, t0, t1, st)
+            for gi, G in enumerate(groups):
+                if G["philox"]:
+                    Bg = G["B"]
+                    n = (t1 - t0) * 2 * Bg * Pd
+                    call("t2_philox_mask", _ptr(G["pm"], t0 * 2 * Bg * Pd), n, p, seed, 1000 + t0 + 100003 * gi, st)
+                call("t2_decoder_infer", G["a"], t0, t1, st)
             t0 = t1
-            stt = state.cpu()            # the only host synchronisation: once per `check_every` frames
-            if int(stt[0]) or (prenet_masks is not None and t0 >= int(prenet_masks.shape[0])):
+            flags = torch.stack([G["state"] for G in groups]).cpu()     # the only host synchronisation: once per chunk
+            if bool((flags[:, 0] != 0).all()):
                 break
-        n = int(state.cpu()[1])
-        n = max(n, 1)
+        self.mark("inf.frame_loop")
+        # exact break frame and lengths from the stored stop logits (model/tacotron2.py:319-322)
+        lengths = self.buf("inf.lengths", B, dtype=torch.int64)
+        nfr = self.buf("inf.nframes", 2, dtype=torch.int32)
+        ldo = (M + 1 + 3) // 4 * 4
+        scan = make("T2StopScan", proj=[G["proj"] for G in groups] + [0] * (8 - len(groups)),
+                    Bg=[G["B"] for G in groups] + [0] * (8 - len(groups)), ngroups=len(groups), ld_proj=ldo, M=M, nframes=t0)
+        call("t2_stop_scan", scan, lengths, nfr, st)
+        n = max(int(nfr.cpu()[0]), 1)
         # outputs: mask by the counted lengths, postnet on the unmasked mels (model/tacotron2.py:327-345)
         mlen32 = lengths.to(torch.int32)
         mels = torch.empty(B, n, M, dtype=torch.float32, device=self.dev)
         gates = torch.empty(B, n, 1, dtype=torch.float32, device=self.dev)
         post_in = self.buf("post.x0", B, n + 4, M)
-        call("t2_finalize_fwd", proj, ldo, mlen32, mels, gates, post_in, B, n, M, st)
+        for G, b0 in zip(groups, range(0, B, 64)):
+            Bg = G["B"]
+            call("t2_finalize_fwd", G["proj"], ldo, mlen32[b0:b0 + Bg], mels[b0:b0 + Bg], gates[b0:b0 + Bg],
+                 post_in[b0:b0 + Bg], Bg, n, M, st)
         Pn = d["postnet_dim"]
         chans = [M, Pn, Pn, Pn, Pn, M]
         x = post_in
@@ -1011,4 +963,5 @@ class Engine:
                                  training, pctx, y=post if last else None, Lp_y=n if last else None,
                                  pad_y=0 if last else 2, res=post_in if last else None, Lp_res=n + 4, pad_res=2,
                                  length=mlen32 if last else None, fill=0.0)
-        return mels, post, gates, align[:, :n].contiguous(), lengths.clone()
+        align = groups[0]["align"][:, :n] if len(groups) == 1 else torch.cat([G["align"][:, :n] for G in groups])
+        return mels, post, gates, align.contiguous(), lengths.clone()

@@ -181,25 +181,14 @@ class Tacotron2(nn.Module):
             named = dict(self.named_parameters())
             params = [named[n] for n in self._param_names]      # store order = order of the returned gradients
             return _TacotronFn.apply(self, batch, *params)
-        outs = []
-        with torch.no_grad():
-            for b0 in range(0, chars_idx.shape[0], 64):       # the stop logic runs per group of <= 64 utterances
-                sl = slice(b0, b0 + 64)
-                pm = dropout_masks.get("prenet_drop") if dropout_masks else None
-                o = self._engine.infer(chars_idx[sl].contiguous(), chars_idx_len[sl], int(max_len_override),
-                                       speaker_id=speaker_id[sl] if speaker_id is not None else None,
-                                       description_embeddings=description_embeddings[sl].contiguous().float()
-                                       if description_embeddings is not None else None,
-                                       training=self.training, prenet_masks=pm, seed=self._seed + self._calls,
-                                       controls=controls[sl] if controls is not None else None)
-                self._calls += 1
-                outs.append(o[:4])
-        if len(outs) == 1:
-            return outs[0]
-        n = max(o[0].shape[1] for o in outs)
-        pad = lambda t, fill: torch.nn.functional.pad(t, (0, 0, 0, n - t.shape[1]), value=fill)
-        return (torch.cat([pad(o[0], 0.0) for o in outs]), torch.cat([pad(o[1], 0.0) for o in outs]),
-                torch.cat([pad(o[2], -1000.0) for o in outs]), torch.cat([pad(o[3], 0.0) for o in outs]))
+        with torch.no_grad():     # ONE loop over the whole batch (groups of 64 in lock-step inside the engine)
+            pm = dropout_masks.get("prenet_drop") if dropout_masks else None
+            o = self._engine.infer(chars_idx.contiguous(), chars_idx_len, int(max_len_override), speaker_id=speaker_id,
+                                   description_embeddings=description_embeddings.contiguous().float()
+                                   if description_embeddings is not None else None,
+                                   training=self.training, prenet_masks=pm, seed=self._seed + self._calls, controls=controls)
+            self._calls += 1
+        return o[:4]
 
     def inference(self, chars_idx, chars_idx_len, max_len: int = 5000, **kw):
         """Alias of forward(teacher_forcing=False, max_len_override=max_len) (north_star's "inference() surface")."""

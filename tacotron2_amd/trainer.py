@@ -22,7 +22,7 @@ from .params import ParamStore
 
 class Trainer:
     def __init__(self, ps: ParamStore, lr: float, weight_decay: float, scheduler_milestones: Sequence[int] = (),
-                 max_norm: float = 1.0, seed: int = 1234):
+                 max_norm: float = 1.0, seed: int = 1234, sync_bn: bool = False):
         self.ps = ps
         self.engine = Engine(ps)
         self.base_lr, self.weight_decay, self.max_norm = lr, weight_decay, max_norm
@@ -32,6 +32,12 @@ class Trainer:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
         self.frozen: set = set()   # parameter names excluded from updates (fine-tuning, run/train.py:229-233)
+        # sync_bn: BatchNorm batch statistics (8 layers, forward and backward) over ALL ranks' shards - 16 all-reduces of
+        # 2C + 2 doubles per step - so that N x b utterances give the single-device result on the N*b batch (the reference's
+        # BN layers see the whole batch, model/encoder.py:41, model/postnet.py:16,30,44).  Off: per-shard statistics.
+        self.sync_bn = bool(sync_bn) and self.world > 1
+        if self.sync_bn:
+            self.engine.sync_bn_group = dist.group.WORLD
 
     def trainable_ranges(self):
         """[start, end) element ranges of the flat buffer that the optimizer updates: everything except the frozen tensors

@@ -1,0 +1,99 @@
+"""Data-parallel HIP training step against the single-process HIP step on the concatenated batch (run by
+tests/test_gpu_dp.py through torch.distributed.run, 2 ranks sharing cuda:0 over gloo; RCCL needs one GPU per rank).
+
+Each rank runs the PRODUCT path - Trainer.train_step on its shard of utterances: global (L, T) padding, forward, loss,
+backward with synchronised BatchNorm statistics, ONE all-reduce of the flat gradient buffer, clip + Adam with the 1/world
+scale - with the rows of one shared set of dropout masks.  Rank 0 then repeats the step in one process on the whole batch
+(same parameters, same masks) and compares: loss, every parameter gradient (3e-4 of the tensor's scale), the clip norm, the
+BatchNorm running statistics, and that both ranks hold bit-identical parameters after the update."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    from oracle import tacotron2_ref as R
+    from tacotron2_amd.engine import Engine
+    from tacotron2_amd.params import ParamStore
+    from tacotron2_amd.trainer import Trainer
+    from tests.test_gpu_model import masks_to_device, random_case
+    sync_bn = "--per-shard-bn" not in sys.argv
+    d = R.default_dims(num_chars=39, encoded_dim=128, prenet_dim=64, att_rnn_dim=256, att_dim=64, rnn_hidden_dim=256,
+                       postnet_dim=128, num_mels=80, dropout=0.5, speaker_tokens=True, num_speakers=4)
+    P = R.init_params(d, seed=12)
+    Bt, L, T = 6, 27, 22
+    ci, lens, mel, tl, gate, masks = random_case(d, Bt, L, T, 41, dev)
+    spk = torch.tensor([0, 3, 1, 1, 2, 0], dtype=torch.int32)
+    ps = ParamStore(d, dev); ps.load_state_dict(P)
+    tr = Trainer(ps, lr=1e-3, weight_decay=1e-6, max_norm=1.0, sync_bn=sync_bn)
+    assert tr.world == world and tr.sync_bn == sync_bn
+    per = Bt // world
+    sl = slice(rank * per, (rank + 1) * per)
+    Lr, Tr = int(lens[sl].max()), int(tl[sl].max())                 # the shard arrives padded to ITS OWN maxima
+    shard = dict(chars_idx=ci[sl, :Lr].contiguous().to(dev), chars_idx_len=lens[sl].to(dev),
+                 mel_spectrogram=mel[sl, :Tr].contiguous().to(dev), mel_spectrogram_len=tl[sl].to(dev),
+                 gate=gate[sl, :Tr].contiguous().to(dev), speaker_id=spk[sl].to(dev))
+    mfull = masks_to_device(masks, dev)
+    mrank = dict(enc_drop=[m[sl].contiguous() for m in mfull["enc_drop"]], post_drop=[m[sl].contiguous() for m in mfull["post_drop"]],
+                 prenet_drop=[m[:, sl].contiguous() for m in mfull["prenet_drop"]],
+                 att_drop=mfull["att_drop"][:, sl].contiguous(), dec_drop=mfull["dec_drop"][:, sl].contiguous())
+    loss3, _ = tr.train_step(shard, masks=mrank)
+    torch.cuda.synchronize()
+    lsum = loss3.sum().reshape(1).clone()
+    dist.all_reduce(lsum)                                            # mean of the per-rank loss means
+    gdp = (ps.grad / world).clone()                                  # train_step leaves the all-reduced SUM in ps.grad
+    flat_dp = ps.flat.clone()
+    other = flat_dp.cpu().clone()
+    gathered = [torch.zeros_like(other) for _ in range(world)]
+    dist.all_gather(gathered, other)
+    ok = True
+    msg = []
+    if rank == 0:
+        if not all(torch.equal(gathered[0], g) for g in gathered[1:]):
+            ok = False; msg.append("replicas diverged after the update")
+        ps1 = ParamStore(d, dev); ps1.load_state_dict(P)
+        eng = Engine(ps1)
+        outs, ctx = eng.forward_tf(ci.to(dev), lens.to(dev), mel.to(dev), tl.to(dev), speaker_id=spk.to(dev), training=True, masks=mfull)
+        ps1.grad.zero_()
+        l1 = eng.loss_and_grads(outs, ctx, mel.to(dev), gate.to(dev))
+        sumsq = eng.adam_step(1, 1e-3, 1e-6, max_norm=1.0)
+        torch.cuda.synchronize()
+        dl = abs(float(lsum) / world - float(l1.sum()))
+        if not dl < 2e-5 * max(1.0, float(l1.sum())):
+            ok = False; msg.append(f"loss differs by {dl}")
+        worst = ("", 0.0)
+        for name in ps1.P:
+            o, n = ps1.offsets[name], ps1.P[name].numel()
+            r = ps1.grad[o:o + n].double()
+            err = float((gdp[o:o + n].double() - r).abs().max()) / max(float(r.abs().max()), 1e-3)
+            if err > worst[1]:
+                worst = (name, err)
+        tol = 3e-4 if sync_bn else None
+        msg.append(f"worst gradient mismatch {worst[1]:.2e} at {worst[0]}")
+        if tol is not None and not worst[1] < tol:
+            ok = False
+        if sync_bn:
+            for k in ps1.Bf:
+                e = float((ps.Bf[k] - ps1.Bf[k]).abs().max())
+                if not e < 1e-5:
+                    ok = False; msg.append(f"running statistic {k} differs by {e}")
+            g1 = float(sumsq.sqrt()); gd = float((gdp.double() ** 2).sum().sqrt())
+            if not abs(g1 - gd) < 1e-3 * g1:
+                ok = False; msg.append(f"clip norm {gd} vs {g1}")
+        print(("DP_CHECK_OK " if ok else "DP_CHECK_FAIL ") + "; ".join(msg), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

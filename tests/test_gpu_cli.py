@@ -134,3 +134,68 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["value"] > 0 and d["scaling"] == "weak"
     assert all(np.isfinite(d["loss"]))
+
+
+def test_cli_vanilla_ljspeech_stop_config_batch2_ten_steps(tmp_path):
+    """BASELINE configs[0]: config/vanilla-ljspeech-stop.json at batch 2 for 10 train steps.  The reference runs this on
+    CPU; this package has no CPU product path by design (the oracle must not become one), so the configuration is
+    exercised on the GPU: the reference file's own values and STALE schema (`char_embedding_dim`, no
+    `extensions.descriptions`, speaker tokens inactive, a `test` manifest key; config/vanilla-ljspeech-stop.json:1-52,
+    run/train.py:70,87,118-122) at the full vanilla dims, synthetic LJSpeech-shaped batches, then `say` from the result."""
+    cfg = {"dataset": {"train": "data/ljspeech-train-v4.csv", "test": "data/ljspeech-test-v4.csv", "val": "data/ljspeech-val-v4.csv",
+                       "preprocessing": {"allowed_chars": ALLOWED, "expand_abbreviations": True, "end_token": "^", "silence": 512,
+                                         "trim": False, "num_mels": 80, "cache": False}},
+           "training": {"lr": 0.001, "batch_size": 2, "weight_decay": 0.000001, "precision": "16-mixed",
+                        "name": "vanilla-ljspeech-stop", "float32_matmul_precision": "high", "stopping_val_loss_threshold": None,
+                        "args": {"max_steps": 100000}},
+           "model": {"scheduler_milestones": [0.5, 0.75],
+                     "args": {"prenet_dim": 256, "att_rnn_dim": 1024, "att_dim": 128, "rnn_hidden_dim": 1024, "postnet_dim": 512,
+                              "dropout": 0.5, "char_embedding_dim": 512, "encoder_kernel_size": 5}},
+           "extensions": {"speaker_tokens": {"active": False}, "controls": {"active": False}}}
+    p = tmp_path / "vanilla-ljspeech-stop.json"
+    p.write_text(json.dumps(cfg))
+    res = tmp_path / "res"
+    out = _run(["--config", str(p), "--device", "0", "train", "--speech-dir", "unused", "--results-dir", str(res),
+                "--synthetic", "--max-steps", "10"])
+    losses = [float(l.split("training_loss ")[1].split()[0]) for l in out.splitlines() if "training_loss" in l]
+    assert len(losses) >= 2 and all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    ck = torch.load(res / "final.ckpt", map_location="cpu", weights_only=True)
+    assert ck["global_step"] == 10 and ck["hyper_parameters"]["encoded_dim"] == 512 and not ck["hyper_parameters"]["speaker_tokens"]
+    assert ck["state_dict"]["tacotron2.decoder.att_rnn.weight_ih"].shape == (4096, 256 + 512)
+    assert "tacotron2.speaker_embedding.weight" not in ck["state_dict"]
+    assert len(ck["optimizer_states"][0]["state"]) == 55 and ck["lr_schedulers"][0]["last_epoch"] == 10
+    npy = tmp_path / "say.npy"
+    _run(["--config", str(p), "--device", "0", "say", "--checkpoint", str(res / "final.ckpt"), "--text", "Hello there.",
+          "--out", str(npy), "--random-seed", "1"])
+    mel = np.load(npy)
+    assert mel.ndim == 2 and mel.shape[1] == 80 and mel.shape[0] >= 1 and np.isfinite(mel).all()
+
+
+def test_cli_finetune_runs_exactly_n_steps_with_frozen_encoder(tmp_path):
+    """run/train.py:109-113,229-233,245: --finetune resumes global_step / Adam / scheduler from the checkpoint, raises max_steps
+    by --finetune-steps (so exactly that many optimiser steps run), doubles the batch, freezes encoder + speaker embedding."""
+    cfg = _cfg(tmp_path)
+    c = json.loads(cfg.read_text()); c["training"]["args"]["max_steps"] = 4; cfg.write_text(json.dumps(c))
+    res = tmp_path / "res"
+    _run(["--config", str(cfg), "--device", "0", "train", "--speech-dir", "unused", "--results-dir", str(res), "--synthetic"])
+    ck0 = torch.load(res / "final.ckpt", map_location="cpu", weights_only=True)
+    assert ck0["global_step"] == 4 and sorted(ck0["lr_schedulers"][0]["milestones"].elements()) == [2, 3]
+    out = _run(["--config", str(cfg), "--device", "0", "train", "--speech-dir", "unused", "--results-dir", str(res), "--synthetic",
+                "--finetune", "--finetune-steps", "3", "--resume-ckpt", str(res / "final.ckpt")])
+    assert "(3 optimiser steps this run, global_step 7)" in out, out[-1500:]
+    assert "lr 1.00e-05" in out          # the restored scheduler state (both milestones passed) sets the rate, as in Lightning
+    ck1 = torch.load(res / "finetuned.ckpt", map_location="cpu", weights_only=True)
+    assert ck1["global_step"] == 7
+    sd0, sd1 = ck0["state_dict"], ck1["state_dict"]
+    for k in sd0:
+        frozen = k.startswith("tacotron2.encoder.") or k.startswith("tacotron2.speaker_embedding.")
+        same = torch.equal(sd0[k], sd1[k])
+        if frozen and not k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            assert same, k                                     # frozen tensors do not move (BN buffers still track batches)
+        if k in ("tacotron2.decoder.lstm.weight_hh", "tacotron2.prenet.0.weight", "tacotron2.postnet.postnet.0.weight"):
+            assert not same, k
+    # the frozen tensors' Adam moments are untouched as well (torch.optim.Adam skips parameters without a gradient)
+    from tacotron2_amd.checkpoint import reference_param_order
+    order = reference_param_order(dict(ck1["hyper_parameters"]))
+    i = order.index("encoder.convolutions.0.weight")
+    assert torch.equal(ck0["optimizer_states"][0]["state"][i]["exp_avg"], ck1["optimizer_states"][0]["state"][i]["exp_avg"])

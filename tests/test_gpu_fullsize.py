@@ -144,12 +144,13 @@ def _bn_ref64(x, gamma, beta, act, drop, eps=1e-5):
     """float64 BatchNorm1d (training statistics over all rows) + activation + dropout mask, with autograd."""
     mean = x.mean(0)
     var = x.var(0, unbiased=False)
-    y = (x - mean) / torch.sqrt(var + eps) * gamma + beta
+    pre = (x - mean) / torch.sqrt(var + eps) * gamma + beta
+    y = pre
     if act == 1:
-        y = torch.relu(y)
+        y = torch.relu(pre)
     elif act == 2:
-        y = torch.tanh(y)
-    return y * drop, mean, var
+        y = torch.tanh(pre)
+    return y * drop, mean, var, pre.detach()
 
 
 @pytest.mark.parametrize("act", [1, 2])
@@ -167,7 +168,9 @@ def test_batchnorm_28k_rows_offset_input_matches_float64(act):
     dy = torch.randn(B, L, C, generator=g) * 0.01
     x64 = x.double().reshape(B * L, C).requires_grad_(True)
     g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
-    y64, mean64, var64 = _bn_ref64(x64, g64, b64, act, drop.double().reshape(B * L, C))
+    y64, mean64, var64, pre64 = _bn_ref64(x64, g64, b64, act, drop.double().reshape(B * L, C))
+    if act == 1:      # ReLU'(0) is a jump: take the elements within fp32 rounding of the kink out of the backward comparison
+        dy = dy * (pre64.abs() > 1e-4).reshape(B, L, C).float()
     (y64 * dy.double().reshape(B * L, C)).sum().backward()
 
     Lp = L + 4
@@ -177,7 +180,7 @@ def test_batchnorm_28k_rows_offset_input_matches_float64(act):
         xp_rows[b * Lp: b * Lp + L] = x[b].to(dev)
     y = torch.empty(B, Lp, C, device=dev)
     mean = torch.empty(C, device=dev); invstd = torch.empty(C, device=dev)
-    sums = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+    sums = torch.zeros(2 * C + 2, dtype=torch.float64, device=dev)
     rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
     gam, bet, drp = gamma.to(dev), beta.to(dev), drop.to(dev).contiguous()
     st = torch.cuda.current_stream().cuda_stream
@@ -188,7 +191,7 @@ def test_batchnorm_28k_rows_offset_input_matches_float64(act):
     n = B * L
     assert mx(mean, mean64.detach()) < 2e-6
     rel_istd = ((invstd.double().cpu() - 1 / torch.sqrt(var64.detach() + 1e-5)).abs() * torch.sqrt(var64.detach() + 1e-5)).max()
-    assert float(rel_istd) < 2e-5, float(rel_istd)
+    assert float(rel_istd) < 2e-6, float(rel_istd)
     assert mx(rm, 0.1 * mean64.detach()) < 1e-6
     assert mx(rv, 0.9 + 0.1 * var64.detach() * n / (n - 1)) < 1e-6
     got = y[:, 2:2 + L].reshape(n, C)

@@ -21,9 +21,20 @@ def _rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
 
+@pytest.fixture(params=["split_bf16x3", "native_f32"])
+def gemm_kernel(request):
+    """Both GEMM kernels behind t2_gemm: the default (fp32 by error-free 3 x bf16 operand splitting on the bf16 matrix pipe)
+    and the f32-input MFMA kernel, held to the SAME fp32 tolerance against float64."""
+    from tacotron2_amd import engine
+    old = engine.GEMM_NATIVE_FP32[0]
+    engine.GEMM_NATIVE_FP32[0] = 1 if request.param == "native_f32" else 0
+    yield request.param
+    engine.GEMM_NATIVE_FP32[0] = old
+
+
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
-@pytest.mark.parametrize("shape", [(128, 128, 32), (200, 150, 72), (37, 300, 70), (1000, 81, 1536), (260, 4096, 96)])
-def test_gemm_layouts(dev, layout, shape):
+@pytest.mark.parametrize("shape", [(128, 128, 32), (200, 150, 72), (37, 300, 70), (1000, 81, 1536), (260, 4096, 96), (5, 3, 7)])
+def test_gemm_layouts(dev, gemm_kernel, layout, shape):
     from tacotron2_amd.engine import gemm
     M, N, K = shape
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
@@ -39,7 +50,7 @@ def test_gemm_layouts(dev, layout, shape):
     assert _rel(C, ref) < 2e-6
 
 
-def test_gemm_epilogues(dev):
+def test_gemm_epilogues(dev, gemm_kernel):
     from tacotron2_amd.engine import gemm
     M, N, K = 300, 200, 256
     g = torch.Generator().manual_seed(5)
@@ -70,7 +81,7 @@ def test_gemm_epilogues(dev):
     assert _rel(C3, torch.einsum("bmk,bnk->bmn", A3.double(), B3.double())) < 2e-6
 
 
-def test_gemm_overlapping_rows_is_conv1d(dev):
+def test_gemm_overlapping_rows_is_conv1d(dev, gemm_kernel):
     """lda < K: A rows overlap -> a k=5 'same' Conv1d on the padded channel-last layout."""
     from tacotron2_amd._lib import call
     from tacotron2_amd.engine import gemm
@@ -86,6 +97,45 @@ def test_gemm_overlapping_rows_is_conv1d(dev):
     gemm(xd, wp, raw, B * (L + 4) - 4, Co, 5 * Ci, Ci, 5 * Ci, Co, bias=bias.to(dev))
     got = raw.view(B, L + 4, Co)[:, :L]
     assert _rel(got, ref) < 2e-6
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+def test_split_gemm_is_as_accurate_as_f32_mfma(dev, layout):
+    """The bf16x3-split kernel against the f32-input MFMA kernel on a long reduction (K = 4096) with operands spanning many
+    binades and a large common offset (cancellation): both errors are measured against float64, per element relative to
+    sum_k |a||b| (the fp32 dot-product error scale); the split kernel must be within 2x of the native one and both far
+    below what ANY dropped significand bits would give (bf16x1 ~ 4e-3, bf16x2 ~ 1.5e-5)."""
+    from tacotron2_amd import engine
+    from tacotron2_amd.engine import gemm
+    M, N, K = 256, 384, 4096
+    g = torch.Generator().manual_seed(17)
+    A = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-12, 12, (M, K), generator=g).float()) + 3.0
+    B = torch.randn(K, N, generator=g) * torch.exp2(torch.randint(-12, 12, (K, N), generator=g).float()) - 1.5
+    ref = A.double() @ B.double()
+    scale = A.double().abs() @ B.double().abs()
+    a_k, b_k = {"nt": (1, 1), "nn": (1, 0), "tn": (0, 0)}[layout]
+    Ad = (A if a_k else A.t().contiguous()).to(dev)
+    Bd = (B.t().contiguous() if b_k else B).to(dev)
+    errs = {}
+    old = engine.GEMM_NATIVE_FP32[0]
+    try:
+        for name, native in (("split", 0), ("native", 1)):
+            engine.GEMM_NATIVE_FP32[0] = native
+            C = torch.empty(M, N, device=dev)
+            gemm(Ad, Bd, C, M, N, K, Ad.shape[1], Bd.shape[1], N, a_k=a_k, b_k=b_k)
+            torch.cuda.synchronize()
+            e = (C.double().cpu() - ref).abs() / scale
+            errs[name] = (float(e.max()), float(e.mean()))
+    finally:
+        engine.GEMM_NATIVE_FP32[0] = old
+    assert errs["native"][0] < 2e-6 and errs["split"][0] < 2e-6, errs
+    assert errs["split"][0] < 2.0 * errs["native"][0] + 1e-8 and errs["split"][1] < 2.0 * errs["native"][1] + 1e-9, errs
+    # special values propagate like fp32 arithmetic: zeros stay exact zeros, a NaN / Inf operand poisons its row
+    A2 = torch.zeros(64, 64); B2 = torch.randn(64, 64, generator=g); A2[3, 5] = float("inf"); A2[7, 1] = float("nan")
+    C2 = torch.empty(64, 64, device=dev)
+    gemm(A2.to(dev), B2.t().contiguous().to(dev), C2, 64, 64, 64, 64, 64, 64)
+    C2 = C2.cpu()
+    assert bool(torch.isnan(C2[7]).all()) and not bool(torch.isfinite(C2[3]).any()) and float(C2[0].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("B,H,Ks", [(3, 32, (16, 32)), (32, 1024, (512, 1024)), (64, 256, (256,)), (17, 64, (16, 32, 64))])

@@ -228,22 +228,17 @@ def test_train_step_midsize_matches_oracle():
         ps.load_state_dict({k: v.detach() for k, v in Pc.items()})
 
 
-@pytest.mark.parametrize("co_fwd,co_bwd,chunk,plans,co_host", [(True, True, 8, False, 1), (False, False, 8, True, 0),
-                                                                (True, False, 64, False, 0), (False, True, 5, False, 0),
-                                                                (True, False, 8, True, 0), (True, False, 8, False, 2),
-                                                                (True, False, 6, False, 12)])
-def test_pipeline_variants_match_oracle(co_fwd, co_bwd, chunk, plans, co_host):
-    """The frame loop's schedule (chunk size, decoder-LSTM steps co-scheduled inside attention launches or on the side
-    stream) must not change results: every variant against the CPU oracle on the same inputs."""
+@pytest.mark.parametrize("B,chunk,chunk_bwd", [(5, 8, 8), (5, 64, 5), (5, 6, 64), (35, 7, 9)])
+def test_pipeline_chunking_matches_oracle(B, chunk, chunk_bwd):
+    """The frame loop's schedule (chunk sizes; decoder-LSTM steps co-scheduled inside the attention-energies launches for
+    B <= 32, two-stream pipeline above) must not change results: every variant against the CPU oracle on the same inputs."""
     dev = _dev()
     d = R.default_dims(num_chars=39, encoded_dim=64, prenet_dim=32, att_rnn_dim=64, att_dim=32, rnn_hidden_dim=64,
                        postnet_dim=64, num_mels=16, dropout=0.5)
     P = R.init_params(d, seed=11)
     eng, ps = build_engine(d, P, dev)
-    eng.co_schedule, eng.co_schedule_bwd, eng.chunk, eng.chunk_bwd, eng.use_plans = co_fwd, co_bwd, chunk, chunk, plans
-    eng.co_host = co_host % 10
-    eng.fwd_lag = 2 if co_host >= 10 else 1      # co_host 12: energies/context split hosting + chunk GEMMs on the side stream
-    ci, lens, mel, tl, gate, masks = random_case(d, 5, 17, 23, 77, dev)
+    eng.chunk, eng.chunk_bwd = chunk, chunk_bwd
+    ci, lens, mel, tl, gate, masks = random_case(d, B, 17, 23, 77, dev)
     Pc = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not R.is_buffer(k)) else v.clone()) for k, v in P.items()}
     o = R.tacotron2_fwd(Pc, d, ci, lens, True, mel, tl, training=True, masks=masks, new_stats={})
     loss = R.tts_loss(o[0], o[1], o[2], mel, gate)[0]
@@ -555,3 +550,78 @@ def test_controls_train_step_midsize_and_module_api_match_oracle():
     gs = m.decoder(pre.to(dev), (ah.to(dev), ac.to(dev)), cx.to(dev), w0.to(dev), cum0.clone().to(dev), (dh.to(dev), dc.to(dev)),
                    mem.to(dev), pmem.to(dev), mask.to(dev), extra_decoder_in=ctl.to(dev))
     assert mx(gs[0], rs[0]) < 5e-5 and mx(gs[1], rs[1]) < 5e-5 and mx(gs[6][0], rs[7]) < 2e-5
+
+
+def test_finetune_step_with_frozen_encoder_matches_oracle():
+    """run/train.py:229-233 + Lightning gradient_clip_val: with encoder and speaker embedding frozen (requires_grad=False) the
+    global-norm clip is taken over the TRAINABLE gradients only, and frozen tensors (and their Adam moments) do not move -
+    not even by the L2 term.  One Trainer.train_step against the oracle's gradients + clip + Adam restatement."""
+    from tacotron2_amd.trainer import Trainer
+    dev = _dev()
+    d = R.default_dims(num_chars=39, encoded_dim=128, prenet_dim=64, att_rnn_dim=256, att_dim=64, rnn_hidden_dim=256,
+                       postnet_dim=128, num_mels=80, dropout=0.5, speaker_tokens=True, num_speakers=4)
+    P = R.init_params(d, seed=21)
+    eng, ps = build_engine(d, P, dev)
+    tr = Trainer(ps, lr=1e-3, weight_decay=1e-2, max_norm=1.0)           # large L2 term: a frozen tensor must ignore it too
+    tr.engine = eng
+    tr.frozen = {n for n in ps.P if n.startswith("encoder.") or n.startswith("speaker_embedding.")}
+    ci, lens, mel, tl, gate, masks = random_case(d, 4, 31, 26, 99, dev)
+    spk = torch.tensor([1, 3, 0, 1], dtype=torch.int32)
+    Pc = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not R.is_buffer(k)) else v.clone()) for k, v in P.items()}
+    o = R.tacotron2_fwd(Pc, d, ci, lens, True, mel, tl, training=True, masks=masks, speaker_id=spk, new_stats={})
+    loss = R.tts_loss(o[0], o[1], o[2], mel, gate)[0]
+    names = [k for k, v in Pc.items() if v.requires_grad]
+    grads = dict(zip(names, torch.autograd.grad(loss, [Pc[k] for k in names])))
+    trainable = [k for k in names if k not in tr.frozen]
+    coef, tot = R.clip_coef([grads[k] for k in trainable], 1.0)
+    coef_all, tot_all = R.clip_coef(list(grads.values()), 1.0)
+    assert tot_all > 1.02 * tot and coef < 1.0          # the frozen gradients would change the clip: the test can tell
+    batch = dict(chars_idx=ci.to(dev), chars_idx_len=lens.to(dev), mel_spectrogram=mel.to(dev), mel_spectrogram_len=tl.to(dev),
+                 gate=gate.to(dev), speaker_id=spk.to(dev))
+    tr.train_step(batch, masks=masks_to_device(masks, dev))
+    torch.cuda.synchronize()
+    worst = 0.0
+    for k in names:
+        got = ps.P[k].double().cpu()
+        if k in tr.frozen:
+            assert torch.equal(ps.P[k].cpu(), P[k]), k
+            o_, n_ = ps.offsets[k], ps.P[k].numel()
+            assert float(ps.exp_avg[o_:o_ + n_].abs().max()) == 0.0 and float(ps.exp_avg_sq[o_:o_ + n_].abs().max()) == 0.0, k
+            continue
+        g = grads[k]
+        p_new, _, _ = R.adam_l2_step(P[k], g * coef, torch.zeros_like(g), torch.zeros_like(g), 1, 1e-3, 1e-2)
+        well = (g * coef + 1e-2 * P[k]).abs() > 1e-4          # Adam's first step is ~lr*sign(g_total): skip ill-conditioned elements
+        if bool(well.any()):
+            worst = max(worst, float((got - p_new.double())[well].abs().max()))
+    assert worst < 2e-6, worst
+
+
+def test_inference_above_64_utterances_is_one_loop_like_the_reference():
+    """model/tacotron2.py:319-322 with B = 70 (two groups of the decode kernels) at vanilla dims: ONE loop over the whole batch -
+    it ends at the first frame where EVERY utterance has had a negative stop logit, `lengths` counts every emitted frame with
+    a non-negative logit, and all outputs share that frame count - against the oracle, which loops like the reference.  The
+    host looks at the flags only every 3 frames, so the groups are decoded past the break frame and cut back by t2_stop_scan."""
+    dev = _dev()
+    d = R.default_dims()
+    P = R.init_params(d, seed=70)
+    P["decoder.gate.weight"] = P["decoder.gate.weight"] * 8.0
+    P["decoder.gate.bias"] = P["decoder.gate.bias"] - 0.05          # oracle: breaks after 5 of 14 frames, min |logit| 1.6e-4
+    g = torch.Generator().manual_seed(70)
+    B, L, N = 70, 23, 14
+    lens = torch.randint(4, L + 1, (B,), generator=g); lens[0] = L
+    ci = torch.zeros(B, L, dtype=torch.int64)
+    for b in range(B):
+        ci[b, :lens[b]] = torch.randint(1, 40, (int(lens[b]),), generator=g)
+    pm = (torch.rand(N + 1, 2, B, 256, generator=g) >= 0.5).float() * 2
+    masks = dict(prenet_drop=[[pm[i, 0], pm[i, 1]] for i in range(N + 1)])
+    trace = {}
+    with torch.no_grad():
+        ref = R.tacotron2_fwd(P, d, ci, lens, False, max_len_override=N, training=False, masks=masks, trace=trace)
+    n_ref = ref[0].shape[1]
+    assert 2 < n_ref < N and len(set(trace["lengths"].tolist())) > 2, (n_ref, trace["lengths"])     # a real early, ragged stop
+    eng, ps = build_engine(d, P, dev)
+    mels, post, gates, al, lengths = eng.infer(ci.to(dev), lens.to(dev), N, prenet_masks=pm.to(dev).contiguous(), check_every=3)
+    torch.cuda.synchronize()
+    assert mels.shape == ref[0].shape and (lengths.cpu() == trace["lengths"]).all()
+    assert l1(mels, ref[0]) < MEL_L1_TOL and l1(post, ref[1]) < MEL_L1_TOL and mx(al, ref[3]) < 5e-5
+    assert ((gates.cpu() == -1000.0) == (ref[2] == -1000.0)).all()
