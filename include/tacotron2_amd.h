@@ -308,6 +308,10 @@ int t2_condition_fwd(const float* enc, const float* spk_table, const int32_t* sp
 int t2_condition_bwd(const float* dmem, const float* memory, const int32_t* spk, float* denc, float* dspk_table, float* ddesc,
                      int B, int L, int E, int Ef, void* stream);
 int t2_tanh_bias(float* x, const float* bias, int64_t rows, int C, void* stream);
+/* HiFi-GAN V1 generator glue (model/hifi_gan.py:89-97,139-144,198-216; every convolution of the generator is t2_gemm over
+ * overlapping / shifted channel-last rows): y = leaky_relu(scale * x, slope) and y += alpha * x */
+int t2_leaky_relu(const float* x, float* y, int64_t n, float scale, float slope, void* stream);
+int t2_axpy(const float* x, float* y, int64_t n, float alpha, void* stream);
 int t2_tanh_bwd(const float* g, const float* y, float* out, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

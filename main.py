@@ -51,7 +51,7 @@ def train(ctx, speech_dir, results_dir=None, resume_ckpt=None, prosody_model_che
 @click.option("--checkpoint", required=True, type=str, help="A trained Tacotron model checkpoint")
 @click.option("--text", required=True, type=str, help="Text to speak")
 @click.option("--out", required=False, type=str, default="out.npy", help="Output file (log-mel .npy). Default: out.npy")
-@click.option("--hifi-gan-checkpoint", required=False, type=str, default=None, help="(vocoding is out of scope)")
+@click.option("--hifi-gan-checkpoint", required=False, type=str, default=None, help="HiFi-GAN generator checkpoint (config.json next to it, UNIVERSAL_V1 values when absent)")
 @click.option("--random-seed", required=False, type=int, default=None, help="A random seed to use in generation.")
 @click.option("--speaker-id", required=False, type=int, default=None, help="Speaker ID for a multi-speaker model")
 @click.option("--controls", required=False, type=str, default=None, help="If controls are enabled, a comma-separated list of values to pass into the model. Defaults to all 0 values.")

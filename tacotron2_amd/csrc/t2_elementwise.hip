@@ -663,6 +663,30 @@ extern "C" int t2_condition_bwd(const float* dmem, const float* memory, const in
                        dspk_table, ddesc, B, L, E, Ef);
     T2_CHECK_LAUNCH(); return T2_OK;
 }
+// y = leaky_relu(scale * x, slope) and y += alpha * x (HiFi-GAN generator glue, model/hifi_gan.py:89-97,198-216)
+__global__ void leaky_relu_kernel(const float* x, float* y, long n, float scale, float slope) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = scale * x[i];
+        y[i] = v > 0.f ? v : slope * v;
+    }
+}
+__global__ void axpy_kernel(const float* x, float* y, long n, float alpha) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = fmaf(alpha, x[i], y[i]);
+}
+extern "C" int t2_leaky_relu(const float* x, float* y, int64_t n, float scale, float slope, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
+    T2_REQUIRE(x && y && n >= 0, "t2_leaky_relu: bad arguments");
+    if (n == 0) return T2_OK;
+    hipLaunchKernelGGL(leaky_relu_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, x, y, (long)n, scale, slope);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
+extern "C" int t2_axpy(const float* x, float* y, int64_t n, float alpha, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
+    T2_REQUIRE(x && y && n >= 0, "t2_axpy: bad arguments");
+    if (n == 0) return T2_OK;
+    hipLaunchKernelGGL(axpy_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, x, y, (long)n, alpha);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
 extern "C" int t2_tanh_bias(float* x, const float* bias, int64_t rows, int C, void* stream) {
     (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(x, "t2_tanh_bias: null");

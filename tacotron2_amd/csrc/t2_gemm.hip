@@ -227,8 +227,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(GemmK p) {
 // accuracy of an fp32 GEMM (tests/test_gpu_kernels.py compares both kernels with float64) at 16/6 = 2.7x the MFMA rate.
 //
 // Tile 128 x 128 x 16 per 256-thread workgroup (2 x 2 waves of 64 x 64, each 2 x 2 MFMA tiles of 32 x 32 and TWO
-// accumulator sets), two LDS stages of 36 KB (two workgroups per CU).  Operands are split once, on the way from the
-// fp32 global tile into LDS (global -> registers one stage ahead -> split -> three bf16 planes):
+// accumulator sets), two 36 KB LDS stages, two workgroups per CU = two waves per SIMD.  The split of the NEXT tile (VALU)
+// and its LDS stores are interleaved instruction by instruction with the 24 MFMAs per wave of the current tile
+// (sched_group_barrier), so a wave keeps the matrix pipe and the vector pipe busy at the same time, and the second wave
+// of the SIMD fills its stalls (LDS latency after the barrier).  Operands are split once, on the way from the fp32 global
+// tile into LDS (global -> registers two tiles ahead -> split -> three bf16 planes):
 //   k-major operand: plane[row][16 k] with 48-byte rows; a lane's fragment (8 consecutive k) is ONE ds_read_b128, the
 //     16 rows of a b128 lane group start 12 dwords apart: conflict-free.
 //   m-major operand (dgrad B, wgrad A and B): plane[k][128 rows] with 320-byte rows, written as it is read from global
@@ -245,18 +248,31 @@ constexpr int SBK = 16;
 constexpr int KM_ROW = 48, MM_ROW = 320;                   // bytes
 constexpr int KM_PLANE = BM * KM_ROW, MM_PLANE = SBK * MM_ROW;   // 6144, 5120 bytes
 constexpr int OP_BYTES = 3 * KM_PLANE;                     // one operand's three planes (the larger image)
-constexpr int STAGE_BYTES = 2 * OP_BYTES;                  // 36864
+constexpr int STAGE_BYTES = 2 * OP_BYTES;                  // 36864; two stages = 72 KB: two workgroups per CU
 
-__device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
-    h = __builtin_convertvector(v, bf16x4);
-    const f32x4 r = v - __builtin_convertvector(h, f32x4);      // exact
-    m = __builtin_convertvector(r, bf16x4);
-    const f32x4 r2 = r - __builtin_convertvector(m, f32x4);     // exact
-    l = __builtin_convertvector(r2, bf16x4);                    // exact (<= 8 significant bits are left)
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// two floats -> one dword of two bf16 (round to nearest even: v_cvt_pk_bf16_f32), and the two bf16 back as floats
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
+}
+__device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+// a = h + m + l exactly, h = bf16(a), m = bf16(a - h), l = bf16(a - h - m); four values at a time, packed results
+// (per 4 values: 6 v_cvt_pk + 8 unpack + 8 v_sub = 22 VALU instructions)
+struct Split3 { uint2 h, m, l; };
+__device__ __forceinline__ Split3 split3(const f32x4 v) {
+    Split3 s;
+    s.h.x = pk_bf16(v[0], v[1]); s.h.y = pk_bf16(v[2], v[3]);
+    const float r0 = v[0] - bf16_lo(s.h.x), r1 = v[1] - bf16_hi(s.h.x), r2 = v[2] - bf16_lo(s.h.y), r3 = v[3] - bf16_hi(s.h.y);   // exact
+    s.m.x = pk_bf16(r0, r1); s.m.y = pk_bf16(r2, r3);
+    const float q0 = r0 - bf16_lo(s.m.x), q1 = r1 - bf16_hi(s.m.x), q2 = r2 - bf16_lo(s.m.y), q3 = r3 - bf16_hi(s.m.y);           // exact
+    s.l.x = pk_bf16(q0, q1); s.l.y = pk_bf16(q2, q3);      // exact: <= 8 significant bits are left
+    return s;
 }
 
-// global -> 2 x f32x4 registers.  KMAJ: rows r0 + (idx>>2), k = k0 + 4*(idx&3); MMAJ: k = k0 + (idx>>5), rows r0 + 4*(idx&31)
-template <bool KMAJ>
+// global -> 2 x f32x4 registers.  KMAJ: rows r0 + (idx>>2), k = k0 + 4*(idx&3); MMAJ: k = k0 + (idx>>5), rows r0 + 4*(idx&31).
+// FULL (wave-uniform: the tile is interior and 16-byte loads are legal): plain vector loads, no guards.
+template <bool KMAJ, bool FULL>
 __device__ __forceinline__ void split_stage_load(f32x4 (&reg)[2], const float* __restrict__ base, long ld, int r0, int k0, int R,
                                                  int Kend, bool vec, int tid) {
 #pragma unroll
@@ -264,11 +280,13 @@ __device__ __forceinline__ void split_stage_load(f32x4 (&reg)[2], const float* _
         const int idx = tid + 256 * j;
         if (KMAJ) {
             const int r = r0 + (idx >> 2), k = k0 + ((idx & 3) << 2);
+            if (FULL) { reg[j] = *reinterpret_cast<const f32x4*>(base + (long)r * ld + k); continue; }
             int nv = (r < R) ? (Kend - k) : 0;
             nv = nv < 0 ? 0 : nv;
             reg[j] = load4(base + (long)r * ld + k, nv, vec);
         } else {
             const int k = k0 + (idx >> 5), r = r0 + ((idx & 31) << 2);
+            if (FULL) { reg[j] = *reinterpret_cast<const f32x4*>(base + (long)k * ld + r); continue; }
             int nv = (k < Kend) ? (R - r) : 0;
             nv = nv < 0 ? 0 : nv;
             reg[j] = load4(base + (long)k * ld + r, nv, vec);
@@ -276,19 +294,16 @@ __device__ __forceinline__ void split_stage_load(f32x4 (&reg)[2], const float* _
     }
 }
 
+// split register j of a staged tile and store its three planes (one "unit": ~22 VALU + 3 ds_write_b64)
 template <bool KMAJ>
-__device__ __forceinline__ void split_stage_store(const f32x4 (&reg)[2], char* op, int tid) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int idx = tid + 256 * j;
-        bf16x4 h, m, l;
-        split3(reg[j], h, m, l);
-        const int off = KMAJ ? (idx >> 2) * KM_ROW + (idx & 3) * 8 : (idx >> 5) * MM_ROW + (idx & 31) * 8;
-        constexpr int PL = KMAJ ? KM_PLANE : MM_PLANE;
-        *reinterpret_cast<bf16x4*>(op + off) = h;
-        *reinterpret_cast<bf16x4*>(op + PL + off) = m;
-        *reinterpret_cast<bf16x4*>(op + 2 * PL + off) = l;
-    }
+__device__ __forceinline__ void split_store_unit(const f32x4 v, char* op, int tid, int j) {
+    const int idx = tid + 256 * j;
+    const Split3 s = split3(v);
+    const int off = KMAJ ? (idx >> 2) * KM_ROW + (idx & 3) * 8 : (idx >> 5) * MM_ROW + (idx & 31) * 8;
+    constexpr int PL = KMAJ ? KM_PLANE : MM_PLANE;
+    *reinterpret_cast<uint2*>(op + off) = s.h;
+    *reinterpret_cast<uint2*>(op + PL + off) = s.m;
+    *reinterpret_cast<uint2*>(op + 2 * PL + off) = s.l;
 }
 
 // fragment of plane `pl` for the 32-row MFMA tile starting at tile row r0: element j = k offset 8*(lane>>5) + j
@@ -302,16 +317,21 @@ __device__ __forceinline__ bf16x8 split_frag(const char* op, int pl, int r0, int
         typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
         const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0));
         const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0 + 4 * MM_ROW));
-        bf16x8 f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { f[i] = __builtin_bit_cast(__bf16, t0[i]); f[4 + i] = __builtin_bit_cast(__bf16, t1[i]); }
-        return f;
+        // (whole-vector bit casts: element-wise bit_cast of the transposed read's result is miscompiled by ROCm 7.2's hipcc -
+        // element 0 is splatted into all four - tools/probe_mm.hip)
+        return __builtin_shufflevector(__builtin_bit_cast(bf16x4, t0), __builtin_bit_cast(bf16x4, t1), 0, 1, 2, 3, 4, 5, 6, 7);
     }
 }
 
+// One 16-deep k-step of the six-product scheme for this wave's 2 x 2 MFMA tiles: 24 MFMAs in 8 groups of 3; after group g the
+// caller's `unit(g)` (one split_store_unit of the NEXT tile) is issued, and sched_group_barriers pin the instruction order
+// MFMA, 4 x VALU, MFMA, ... : with one wave per SIMD the conversion of the next tile runs in the issue gaps of this tile's
+// MFMAs (a 32x32x16 MFMA occupies the matrix pipe for 32 cycles and the issue port for 8).
+#define T2_SPLIT_MFMA(ACC, I, J, PA, PB) ACC[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[I][PA], fb[J][PB], ACC[I][J], 0, 0, 0)
+
 template <bool AK, bool BKM>
 __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(GemmK p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 * STAGE_BYTES
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -343,6 +363,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(GemmK p) {
     const int kt1 = (kt0 + per) < nkt ? (kt0 + per) : nkt;
     if (kt0 >= kt1) return;
     const int Kend = (kt1 * SBK) < p.K ? (kt1 * SBK) : p.K;
+    // interior tiles take guard-free vector loads (wave-uniform decision per k-tile)
+    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && p.a_vec && p.b_vec;
 
     f32x16 hi[2][2], lo[2][2];
 #pragma unroll
@@ -352,22 +374,31 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(GemmK p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { hi[i][j][r] = 0.f; lo[i][j][r] = 0.f; }
 
-    f32x4 ra[2], rb[2];
-    split_stage_load<AK>(ra, A, p.lda, m0, kt0 * SBK, p.M, Kend, p.a_vec, tid);
-    split_stage_load<BKM>(rb, B, p.ldb, n0, kt0 * SBK, p.N, Kend, p.b_vec, tid);
-    split_stage_store<AK>(ra, smem, tid);
-    split_stage_store<BKM>(rb, smem + OP_BYTES, tid);
+    // Two register sets for the fp32 tiles in flight: while the set holding tile kt+1 is split and stored between this tile's
+    // MFMAs, the other set receives tile kt+2 (requested at the top of the iteration: a whole tile of MFMAs to land).
+    f32x4 ra[2], rb[2], na[2], nb[2];
+    auto load_tile = [&](f32x4 (&xa)[2], f32x4 (&xb)[2], int kt) {
+        if (interior && (kt + 1) * SBK <= Kend) {
+            split_stage_load<AK, true>(xa, A, p.lda, m0, kt * SBK, p.M, Kend, true, tid);
+            split_stage_load<BKM, true>(xb, B, p.ldb, n0, kt * SBK, p.N, Kend, true, tid);
+        } else {
+            split_stage_load<AK, false>(xa, A, p.lda, m0, kt * SBK, p.M, Kend, p.a_vec, tid);
+            split_stage_load<BKM, false>(xb, B, p.ldb, n0, kt * SBK, p.N, Kend, p.b_vec, tid);
+        }
+    };
+    // prologue: tile kt0 -> LDS stage 0, tile kt0+1 -> register set (ra, rb)
+    load_tile(ra, rb, kt0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { split_store_unit<AK>(ra[j], smem, tid, j); split_store_unit<BKM>(rb[j], smem + OP_BYTES, tid, j); }
+    if (kt0 + 1 < kt1) load_tile(ra, rb, kt0 + 1);
     __syncthreads();
 
-    int cur = 0;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const bool more = (kt + 1) < kt1;
-        if (more) {
-            split_stage_load<AK>(ra, A, p.lda, m0, (kt + 1) * SBK, p.M, Kend, p.a_vec, tid);
-            split_stage_load<BKM>(rb, B, p.ldb, n0, (kt + 1) * SBK, p.N, Kend, p.b_vec, tid);
-        }
+    // one 16-deep tile: 24 MFMAs on LDS stage `cur`; (xa, xb) hold tile kt+1 and go to stage cur^1; (ya, yb) receive tile kt+2
+    auto tile_step = [&](int kt, int cur, f32x4 (&xa)[2], f32x4 (&xb)[2], f32x4 (&ya)[2], f32x4 (&yb)[2]) {
         const char* As = smem + cur * STAGE_BYTES;
         const char* Bs = As + OP_BYTES;
+        char* An = smem + (cur ^ 1) * STAGE_BYTES;
+        if (kt + 2 < kt1) load_tile(ya, yb, kt + 2);
         bf16x8 fa[2][3], fb[2][3];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -376,38 +407,30 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(GemmK p) {
                 fa[i][pl] = split_frag<AK>(As, pl, wm * 64 + i * 32, lane);
                 fb[i][pl] = split_frag<BKM>(Bs, pl, wn * 64 + i * 32, lane);
             }
-        // small terms first into `lo`, the leading term into `hi`; the four output tiles are interleaved
+        // small terms first into `lo`, the leading term into `hi`; the next tile's four split units in between
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], lo[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], lo[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], lo[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], lo[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], lo[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], hi[i][j], 0, 0, 0);
-        if (more) {
-            char* An = smem + (cur ^ 1) * STAGE_BYTES;
-            split_stage_store<AK>(ra, An, tid);
-            split_stage_store<BKM>(rb, An + OP_BYTES, tid);
+        for (int g = 0; g < 4; ++g) {
+            const int i = g >> 1, j = g & 1;
+            T2_SPLIT_MFMA(lo, i, j, 2, 0); T2_SPLIT_MFMA(lo, i, j, 0, 2); T2_SPLIT_MFMA(lo, i, j, 1, 1);
+            // (unconditional: on the last tile the registers are stale and the stage they go to is never read)
+            if (g < 2) split_store_unit<AK>(xa[g], An, tid, g); else split_store_unit<BKM>(xb[g - 2], An + OP_BYTES, tid, g - 2);
+            T2_SPLIT_MFMA(lo, i, j, 1, 0); T2_SPLIT_MFMA(lo, i, j, 0, 1); T2_SPLIT_MFMA(hi, i, j, 0, 0);
         }
-        __syncthreads();
-        cur ^= 1;
+        // order pin, per group of 6 MFMAs + one split unit (22 VALU, 2-3 LDS stores): MFMA, 4 VALU, MFMA, ...
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+        }
+        __syncthreads();     // stage cur^1 is complete, stage cur is free
+    };
+    for (int kt = kt0; kt < kt1; kt += 2) {
+        tile_step(kt, 0, ra, rb, na, nb);
+        if (kt + 1 < kt1) tile_step(kt + 1, 1, na, nb, ra, rb);
     }
 
     // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
@@ -466,9 +489,12 @@ extern "C" int t2_gemm(const T2Gemm* g, void* stream) {
     // share_cu: 24 KB of (unused) dynamic LDS on top of the 73.7 KB static tile buffers -> a second workgroup no longer fits
     const size_t pad = g->share_cu ? 24 * 1024 : 0;
     if (!g->native_fp32) {
-        if (g->a_kmajor && g->b_kmajor) hipLaunchKernelGGL((gemm_f32_split_bf16<true, true>), grid, block, pad, s, p);
-        else if (g->a_kmajor && !g->b_kmajor) hipLaunchKernelGGL((gemm_f32_split_bf16<true, false>), grid, block, pad, s, p);
-        else hipLaunchKernelGGL((gemm_f32_split_bf16<false, false>), grid, block, pad, s, p);
+        const size_t lds = 2 * STAGE_BYTES + pad;    // 72 KB: two workgroups per CU (one with the share_cu padding)
+        T2_REQUIRE(t2_allow_lds(gemm_f32_split_bf16<true, true>, lds) && t2_allow_lds(gemm_f32_split_bf16<true, false>, lds) &&
+                   t2_allow_lds(gemm_f32_split_bf16<false, false>, lds), "t2_gemm: LDS budget");
+        if (g->a_kmajor && g->b_kmajor) hipLaunchKernelGGL((gemm_f32_split_bf16<true, true>), grid, block, lds, s, p);
+        else if (g->a_kmajor && !g->b_kmajor) hipLaunchKernelGGL((gemm_f32_split_bf16<true, false>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((gemm_f32_split_bf16<false, false>), grid, block, lds, s, p);
         T2_CHECK_LAUNCH();
         return T2_OK;
     }

@@ -634,8 +634,8 @@ class Engine:
                        c_cur=-B * D, dt=0, dgt=-Bp * 4 * D)
             return s, inc
 
-        def dxdec_gemm(hi, lo):
-            SHARE_CU[0] = self.share_cu
+        def dxdec_gemm(hi, lo, share_cu=0):
+            SHARE_CU[0] = share_cu
             gemm(_ptr(dgd, lo * B * 4 * D), P["decoder.lstm.weight_ih"], _ptr(dxdec, lo * B * ldx), (hi - lo) * B, ldx, 4 * D,
                  4 * D, ldx, ldx, a_k=1, b_k=0)
             SHARE_CU[0] = 0
@@ -657,11 +657,15 @@ class Engine:
                                 ctl.shape[1], B)
 
         chunks = [(hi, max(0, hi - CH)) for hi in range(T, 0, -CH)]
+        # Two-stream pipeline: decoder chain of chunk k+1 on the side stream next to the attention chain of chunk k.  Hosting the
+        # decoder BPTT steps inside attention launches instead measured slower both ways (inside the ds launch: round 1,
+        # profiles/r01_sweep_bwd_chunk_co.txt; as a second operand block of the cell-backward launch: 75.3 against 71.9 ms
+        # per step, profiles/r02_ab_bwd_schedule.txt) - those launches end when the hosted K = 4096 step ends.
         for hi, lo in chunks:
             with torch.cuda.stream(side):
                 s, inc = dec_bwd_chunk(hi, lo)
                 call("t2_lstm_seq_bwd", s, inc, 1, hi - lo, side.cuda_stream)
-                dxdec_gemm(hi, lo)
+                dxdec_gemm(hi, lo, self.share_cu)
                 ev = side.record_event()
             main.wait_event(ev)
             sb.t_hi, sb.t_lo = hi, lo

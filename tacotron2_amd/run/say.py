@@ -1,7 +1,8 @@
 """do_say (run/say.py:25-179): text -> ids -> checkpoint -> forward(teacher_forcing=False, max_len_override=5000) ON THE GPU
 (the reference runs this on CPU at batch 1; here any number of texts is decoded as one batch, up to 64 per group) ->
 log-mel written as .npy, or - when the output name ends in .wav - Griffin-Lim audio (tacotron2_amd/vocoder.py, the branch
-run/say.py:161-171 takes without a HiFi-GAN checkpoint).  HiFi-GAN is outside the scope."""
+run/say.py:161-171 takes without a HiFi-GAN checkpoint), or HiFi-GAN audio with --hifi-gan-checkpoint (tacotron2_amd/hifigan.py,
+run/say.py:66-86,153-159)."""
 from __future__ import annotations
 
 from typing import List, Optional, Union
@@ -18,8 +19,6 @@ def do_say(dataset_config: dict, training_config: dict, model_config: dict, exte
            checkpoint: str, text: Union[str, List[str]], output: str, hifi_gan_checkpoint: Optional[str] = None,
            random_seed: Optional[int] = None, speaker_id: Optional[int] = None, controls: Optional[str] = None,
            description: Optional[str] = None, max_len: int = 5000):
-    if hifi_gan_checkpoint is not None:
-        raise NotImplementedError("HiFi-GAN vocoding is out of scope for the hot-path build (SURVEY.md section 8f)")
     dev = torch.device("cuda", device)
     torch.cuda.set_device(dev)
     pre = dataset_config["preprocessing"]
@@ -56,6 +55,17 @@ def do_say(dataset_config: dict, training_config: dict, model_config: dict, exte
     valid = (gates.cpu().numpy()[:, :, 0] != -1000.0).sum(1)
     n_emitted = post.shape[1]
     mels = [post[b, :max(min(int(valid[b]), n_emitted - 1), 1)] for b in range(len(texts))]
+    if hifi_gan_checkpoint is not None:
+        # run/say.py:66-86,153-159: generator(mel_post[:, :-1].swapaxes(1, 2)) -> waveform, written as audio whatever the name
+        from ..hifigan import Generator
+        from ..vocoder import write_wav
+        sr = int(pre.get("sample_rate", 22050))
+        gen = Generator.from_checkpoint(hifi_gan_checkpoint, device=dev)
+        for i, m in enumerate(mels):
+            wav = gen(torch.from_numpy(np.ascontiguousarray(m.T)).to(dev))[0, 0].cpu()
+            name = output if isinstance(text, str) else f"{output.rsplit('.', 1)[0]}_{i}.wav"
+            write_wav(name, wav, sr)
+        return mels
     if output.endswith(".wav"):
         from ..vocoder import GriffinLim, write_wav
         sr = int(pre.get("sample_rate", 22050))

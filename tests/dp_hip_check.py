@@ -68,7 +68,7 @@ def main():
         sumsq = eng.adam_step(1, 1e-3, 1e-6, max_norm=1.0)
         torch.cuda.synchronize()
         dl = abs(float(lsum) / world - float(l1.sum()))
-        if not dl < 2e-5 * max(1.0, float(l1.sum())):
+        if sync_bn and not dl < 2e-5 * max(1.0, float(l1.sum())):     # (per-shard statistics change the loss by construction)
             ok = False; msg.append(f"loss differs by {dl}")
         worst = ("", 0.0)
         for name in ps1.P:

@@ -60,6 +60,34 @@ def test_cli_train_synthetic_then_say(tmp_path):
     import wave
     with wave.open(str(wav), "rb") as w:
         assert w.getframerate() == 22050 and w.getsampwidth() == 2 and w.getnframes() == 256 * (mel.shape[0] - 1)
+    # --hifi-gan-checkpoint (run/say.py:66-86,153-159): a generator checkpoint in the published layout ({"generator": weight-normed
+    # state_dict}, config.json next to it; UNIVERSAL_V1 strides 8*8*2*2 = 256 samples per frame, narrow channels for speed)
+    hdir = tmp_path / "hifi"
+    hdir.mkdir()
+    hcfg = dict(resblock="1", upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4], upsample_initial_channel=16,
+                resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]])
+    (hdir / "config.json").write_text(json.dumps(hcfg))
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    def wn(name, *shape):
+        sd[name + ".weight_v"] = torch.randn(*shape, generator=g) * 0.2
+        sd[name + ".weight_g"] = torch.rand(shape[0], 1, 1, generator=g) * 0.5 + 0.25
+        sd[name + ".bias"] = torch.zeros(shape[0] if "ups" not in name else shape[1])
+    wn("conv_pre", 16, 80, 7)
+    ch = 16
+    for i, k in enumerate(hcfg["upsample_kernel_sizes"]):
+        wn(f"ups.{i}", ch, ch // 2, k); ch //= 2
+        for j, kk in enumerate(hcfg["resblock_kernel_sizes"]):
+            for c in range(3):
+                wn(f"resblocks.{i * 3 + j}.convs1.{c}", ch, ch, kk); wn(f"resblocks.{i * 3 + j}.convs2.{c}", ch, ch, kk)
+    wn("conv_post", 1, ch, 7)
+    torch.save({"generator": sd}, hdir / "g_00000001")
+    hwav = tmp_path / "say_hifi.wav"
+    _run(["--config", str(cfg), "--device", "0", "say", "--checkpoint", str(res / "final.ckpt"), "--text",
+          "Hello, Mr. Smith-Jones!", "--out", str(hwav), "--random-seed", "3", "--speaker-id", "1", "--hifi-gan-checkpoint",
+          str(hdir / "g_00000001")])
+    with wave.open(str(hwav), "rb") as w:
+        assert w.getframerate() == 22050 and w.getnframes() == 256 * mel.shape[0]
 
 
 def test_cli_train_on_wav_manifest_resume(tmp_path):

@@ -230,8 +230,9 @@ def test_train_step_midsize_matches_oracle():
 
 @pytest.mark.parametrize("B,chunk,chunk_bwd", [(5, 8, 8), (5, 64, 5), (5, 6, 64), (35, 7, 9)])
 def test_pipeline_chunking_matches_oracle(B, chunk, chunk_bwd):
-    """The frame loop's schedule (chunk sizes; decoder-LSTM steps co-scheduled inside the attention-energies launches for
-    B <= 32, two-stream pipeline above) must not change results: every variant against the CPU oracle on the same inputs."""
+    """The frame loop's schedule (chunk sizes; forward: decoder-LSTM steps co-scheduled inside the attention-energies launches
+    for B <= 32, two-stream pipeline above; backward: two-stream pipeline) must not change results: every variant against the
+    CPU oracle on the same inputs."""
     dev = _dev()
     d = R.default_dims(num_chars=39, encoded_dim=64, prenet_dim=32, att_rnn_dim=64, att_dim=32, rnn_hidden_dim=64,
                        postnet_dim=64, num_mels=16, dropout=0.5)
