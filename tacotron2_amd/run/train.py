@@ -89,7 +89,9 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
                         features=df[extensions_config["controls"]["features"]].values.tolist() if kw.get("controls") else None,
                         cache_dir=os.path.join(results_dir, "mel_cache"), description_embeddings=desc, device=dev,
                         **dataset_config["preprocessing"])
-        loader = TTSDataLoader(ds, batch_size=training_config["batch_size"], shuffle=True, drop_last=True)
+        # training.bucket_window (not a reference key): batches of similar text length, see LengthBucketBatchSampler
+        loader = TTSDataLoader(ds, batch_size=training_config["batch_size"], shuffle=True, drop_last=True,
+                               bucket_window=int(training_config.get("bucket_window", 0)), seed=rank)
         def batches():
             while True:
                 for b in loader:

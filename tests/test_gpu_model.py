@@ -239,7 +239,9 @@ def test_pipeline_chunking_matches_oracle(B, chunk, chunk_bwd):
     P = R.init_params(d, seed=11)
     eng, ps = build_engine(d, P, dev)
     eng.chunk, eng.chunk_bwd = chunk, chunk_bwd
-    ci, lens, mel, tl, gate, masks = random_case(d, B, 17, 23, 77, dev)
+    # (seed 77 at B = 35 puts one encoder pre-activation within 1e-6 of the ReLU kink: fp32 kernels with different summation
+    # orders - the two GEMM kernels, the oracle - then legitimately disagree on that element's derivative; tools/debug_b35.py)
+    ci, lens, mel, tl, gate, masks = random_case(d, B, 17, 23, 77 if B != 35 else 79, dev)
     Pc = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not R.is_buffer(k)) else v.clone()) for k, v in P.items()}
     o = R.tacotron2_fwd(Pc, d, ci, lens, True, mel, tl, training=True, masks=masks, new_stats={})
     loss = R.tts_loss(o[0], o[1], o[2], mel, gate)[0]

@@ -89,3 +89,21 @@ def test_trim_and_wav_roundtrip(tmp_path):
     assert r == sr and np.abs(y - x).max() < 1e-4
     tr = trim_silence(y, top_db=40)
     assert 7000 < len(tr) < 12000
+
+
+def test_length_bucket_sampler_covers_every_utterance_and_cuts_padding():
+    """LengthBucketBatchSampler: a permutation of the data set every epoch (minus the dropped tail), different between epochs,
+    and a much smaller padded/valid ratio than random batches on LJSpeech-shaped lengths (SURVEY.md section 8d distribution)."""
+    import numpy as np
+    from tacotron2_amd.datasets.tts_dataset import LengthBucketBatchSampler
+    rng = np.random.default_rng(0)
+    lens = np.clip(np.round(rng.normal(101, 33.6, 4000)), 13, 188).astype(int).tolist()
+    s = LengthBucketBatchSampler(lens, batch_size=32, window=16, drop_last=True, seed=1)
+    e1, e2 = list(s), list(s)
+    flat = [i for b in e1 for i in b]
+    assert len(e1) == len(s) == 125 and len(set(flat)) == len(flat) == 4000 and all(len(b) == 32 for b in e1)
+    assert e1 != e2
+    ratio = lambda batches: sum(max(lens[i] for i in b) * len(b) for b in batches) / sum(lens[i] for b in batches for i in b)
+    perm = rng.permutation(4000).tolist()
+    random_batches = [perm[i:i + 32] for i in range(0, 4000, 32)]
+    assert ratio(random_batches) > 1.45 and ratio(e1) < 1.12, (ratio(random_batches), ratio(e1))

@@ -18,8 +18,9 @@ def timed(fn, n=5):
 
 def case(name, M, N, K, a_k, b_k, splitk=1):
     # A is [M][K] when a_k else [K][M]; B is [N][K] when b_k else [K][N]
-    A = torch.randn((M, K) if a_k else (K, M), device=dev)
-    B = torch.randn((N, K) if b_k else (K, N), device=dev)
+    mk = torch.zeros if os.environ.get("T2_BENCH_ZEROS") else torch.randn     # zeros: the clock the chip holds without data toggling
+    A = mk((M, K) if a_k else (K, M), device=dev)
+    B = mk((N, K) if b_k else (K, N), device=dev)
     C = torch.zeros(M, N, device=dev)
     lda = K if a_k else M
     ldb = K if b_k else N
