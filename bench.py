@@ -165,6 +165,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     tr.engine.profile = False
+    tr.engine.check_persistent_kernels()     # (after the timed region: a host read of the persistent launches' timeout flag)
     seg = tr.engine.segment_times_ms()       # last timed step (events recorded inside the timed region)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:

@@ -191,6 +191,159 @@ int launch_fwd(const T2LstmStep* steps, int n, hipStream_t st) {
     return T2_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Persistent, weight-stationary recurrence: S consecutive steps of ONE cell in ONE launch.
+//
+// Each workgroup keeps its 16 gate columns x K weights (K = 1024: 64 KB) in LDS for the whole launch, so a step streams no
+// weights at all; what a step needs from the other workgroups is h_{s-1} (B x H floats = 128 KB at B = 32, H = 1024), which
+// they exchange through the x16-tiled h stash itself:
+//   producer: h goes out with write-through (sc1) stores, every storing wave drains them (s_waitcnt vmcnt(0)), the
+//             workgroup's barrier, then ONE lane adds 1 to the workgroup's shard of an arrival counter (8 shards, 64 bytes
+//             apart, agent-scope atomics);
+//   consumer: the 8 lanes of one wave poll the 8 shards (relaxed sc1 loads, s_sleep in between) until shard i shows
+//             n_i * s arrivals, the workgroup's barrier, then EVERY load of h is an sc1 buffer load to registers (no
+//             cache-wide acquire: a buffer_inv would also throw out the L1 lines of the attention kernels that share the CU).
+// (MI355X_MICROARCH.md, inter-workgroup visibility: the `sc1 stores + sc1 loads + drained counter add` form.)
+// The launch runs on its own stream NEXT to the attention chain (one workgroup per CU: 4 waves, 72 KB of LDS), where the same
+// steps hosted inside the attention-energies launches stretch every frame of the chain (energies 7.5 -> 11 us).
+// Safety: every spin is bounded; a timeout raises a flag that ends every workgroup (checked by the host at its next
+// synchronisation point); the counters are zeroed by the launch function; progress needs all H/4 workgroups resident, which
+// holds for H/4 <= 256 once the kernels of the other streams drain (they never wait for this one).
+// ---------------------------------------------------------------------------------------------------------
+struct PersistK {
+    LstmK s;                 // operand block of step 0
+    long i_pre, i_drop, i_h_out, i_c_out, i_gates, i_xt, i_ht;    // element increments per step
+    int i_dt, steps;
+    unsigned* sync;          // [8 shards] x 16 words (room for 16), then at word 256: the timeout flag
+    int spin_limit;
+};
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// (Measured alternatives, profiles/r02_ab_fwd_dec_chain.txt: the two 16-row groups of a batch as two interleaved pipelines
+// inside one workgroup - no faster, a step is a chain of four dependent memory round trips (drain, counter, poll, sc1 loads)
+// either way; one workgroup per group, two per CU - the 136 KB of LDS lock the attention kernels out of the CUs, the whole
+// forward gets 6 ms slower.)
+template <int MT>
+__global__ __launch_bounds__(256, 1) void lstm_seq_persist_fwd_kernel(PersistK pp) {
+    extern __shared__ __attribute__((aligned(16))) float plds[];
+    const LstmK& p = pp.s;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int bx = blockIdx.x, u0 = bx * 4, H = p.H;
+    const int NT = p.seg[0].K >> 4, NTpad = (NT + 15) & ~15;
+    float* wl = plds;                        // [NTpad][64 lanes][4]: this workgroup's slice of the packed stream
+    float* red = plds + (long)NTpad * 256;   // [4 waves][MT][16][16] + 1 word for the wait's verdict
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.wpacked + (long)bx * NTpad * 256);
+        f32x4* dst = reinterpret_cast<f32x4*>(wl);
+        for (int i = tid; i < NTpad * 64; i += 256) dst[i] = src[i];
+    }
+    const int nwg = gridDim.x;
+    unsigned* my_shard = pp.sync + (bx & 7) * 16;
+    unsigned* tmo = pp.sync + 16 * 16;
+    const unsigned want_per_step = lane < 8 ? (unsigned)((nwg + 7 - lane) >> 3) : 0u;     // workgroups that add to shard `lane`
+    const int eb = tid >> 2, euu = tid & 3, eu = u0 + euu;
+    const long ebc = eb < p.B ? eb : p.B - 1;
+    float c_reg = (p.c_prev && tid < MT * 64) ? p.c_prev[ebc * p.ldc_prev + eu] : 0.f;
+    const int e_len = p.len ? p.len[ebc] : 0x7fffffff;
+    __syncthreads();
+    const long xt_bytes = (long)NT * p.xt_cs * 4;      // one tiled slot of h
+    bool alive = true;
+    for (int s = 0; s < pp.steps && alive; ++s) {
+        // epilogue operands of this step: independent of the other workgroups, requested before the wait
+        float e_pre[4] = {0.f, 0.f, 0.f, 0.f}, e_drop = 1.f;
+        if (tid < MT * 64) {
+            const float* pre = p.pre + (long)s * pp.i_pre;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) e_pre[g] = pre[ebc * p.ldpre + g * H + eu];
+            if (p.drop) e_drop = (p.drop + (long)s * pp.i_drop)[ebc * p.lddrop + eu];
+        }
+        if (s > 0) {       // h_{s-1}: every workgroup has published it when shard i shows want_i * s arrivals
+            if (w == 0) {
+                int spins = 0;
+                bool ok = false;
+                while (true) {
+                    unsigned got = 0xffffffffu;
+                    if (lane < 8) got = __hip_atomic_load(pp.sync + lane * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned bad = __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = __all(lane >= 8 || got >= want_per_step * (unsigned)s);
+                    if (ok || bad) { ok = ok && !bad; break; }
+                    if (++spins > pp.spin_limit) {
+                        if (lane == 0) __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (lane == 0) red[4 * MT * 256] = ok ? 1.f : 0.f;
+            }
+            __syncthreads();
+            alive = red[4 * MT * 256] != 0.f;
+            if (!alive) break;
+        }
+        // gates = W . h_{s-1}: weights from LDS, activations by sc1 buffer loads (all issued before the first MFMA)
+        const float* xt = p.xt + (long)s * pp.i_xt;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xt, 0, (int)xt_bytes, 0x00020000);
+        f32x4 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int c0 = w; c0 < NT; c0 += 4 * 8) {
+            f32x4 ax[8][MT], bw[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = (c0 + 4 * j) < NT ? (c0 + 4 * j) : NT - 1;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const unsigned off = (unsigned)((((long)c * p.xt_cs) + (m * 16 + r) * 16 + 4 * q) * 4);
+                    ax[j][m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
+                }
+                bw[j] = *reinterpret_cast<const f32x4*>(wl + ((long)c * 64 + lane) * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float okf = (c0 + 4 * j) < NT ? 1.f : 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[j][m][k], okf * bw[j][k], acc[m], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) red[((w * MT + m) * 16 + (q * 4 + g)) * 16 + r] = acc[m][g];
+        __syncthreads();
+        if (tid < MT * 64 && eb < p.B) {
+            float gsum[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) sacc += red[((ww * MT + (eb >> 4)) * 16 + (eb & 15)) * 16 + g * 4 + euu];
+                gsum[g] = sacc + e_pre[g] + (p.bias1 ? p.bias1[g * H + eu] : 0.f) + (p.bias2 ? p.bias2[g * H + eu] : 0.f);
+            }
+            const bool active = (p.t + s * pp.i_dt) < e_len;
+            float gi = t2_sigmoid(gsum[0]), gf = t2_sigmoid(gsum[1]), gg = t2_tanh(gsum[2]), go = t2_sigmoid(gsum[3]);
+            float cn = gf * c_reg + gi * gg;
+            float hn = go * t2_tanh(cn) * e_drop;
+            if (!active) { hn = 0.f; cn = 0.f; gi = gf = gg = go = 0.f; }
+            c_reg = cn;
+            (p.h_out + (long)s * pp.i_h_out)[(long)eb * p.ldh + eu] = hn;
+            {   // the exchanged copy: write-through
+                float* ht = p.ht_out + (long)s * pp.i_ht;
+                const int col = p.ht_col0 + eu;
+                __hip_atomic_store(ht + (long)(col >> 4) * p.xt_cs + eb * 16 + (col & 15), hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (p.c_out) (p.c_out + (long)s * pp.i_c_out)[(long)eb * p.ldc_out + eu] = cn;
+            if (p.gates_out) *reinterpret_cast<f32x4*>(p.gates_out + (long)s * pp.i_gates + (long)eb * p.ldg + 4 * eu) = (f32x4){gi, gf, gg, go};
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores ...
+        __syncthreads();                                        // ... before the workgroup signals (also frees `red`)
+        if (tid == 0) __hip_atomic_fetch_add(my_shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
@@ -439,6 +592,35 @@ extern "C" int t2_lstm_seq_bwd(const T2LstmBwdStep* base, const T2LstmBwdStride*
         T2_TRY(launch_bwd(cur, n, (hipStream_t)stream));
         for (int i = 0; i < n; ++i) t2_lstm_bwd_advance(cur[i], inc[i]);
     }
+    return T2_OK;
+}
+
+extern "C" int t2_lstm_seq_fwd_persist(const T2LstmStep* base, const T2LstmStride* inc, int S, uint32_t* sync, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
+    T2_REQUIRE(base && inc && sync && S >= 0, "t2_lstm_seq_fwd_persist: bad arguments");
+    if (S == 0) return T2_OK;
+    T2_TRY(t2_lstm_check_step(*base));
+    const T2LstmStep& b = *base;
+    T2_REQUIRE(b.wpacked && b.nseg == 1 && b.xt && b.ht_out && b.B <= 32 && b.pre && b.H % 4 == 0,
+               "t2_lstm_seq_fwd_persist: needs the packed single-segment path with x16-tiled h exchange and B <= 32");
+    T2_REQUIRE(b.seg[0].K == b.H && b.ht_col0 == 0 && inc->xt == inc->ht_out && b.ht_out == b.xt + inc->xt,
+               "t2_lstm_seq_fwd_persist: the input of step s+1 must be the tiled h of step s (K = H)");
+    T2_REQUIRE(b.H / 4 <= 256 && !b.h_out2, "t2_lstm_seq_fwd_persist: at most 256 workgroups (one per CU), no second h copy");
+    const int MT = b.B <= 16 ? 1 : 2;
+    const int NT = b.seg[0].K >> 4, NTpad = (NT + 15) & ~15;
+    const size_t lds = ((size_t)NTpad * 256 + (size_t)4 * MT * 256 + 4) * sizeof(float);
+    T2_REQUIRE(t2_allow_lds(lstm_seq_persist_fwd_kernel<1>, lds) && t2_allow_lds(lstm_seq_persist_fwd_kernel<2>, lds),
+               "t2_lstm_seq_fwd_persist: weight slice does not fit the LDS");
+    PersistK k;
+    t2_lstm_to_k(b, k.s, 0, b.B);
+    k.i_pre = inc->pre; k.i_drop = inc->drop; k.i_h_out = inc->h_out; k.i_c_out = inc->c_out; k.i_gates = inc->gates_out;
+    k.i_xt = inc->xt; k.i_ht = inc->ht_out; k.i_dt = inc->dt; k.steps = S; k.sync = sync; k.spin_limit = 1 << 21;
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(sync, 0, 17 * 16 * sizeof(uint32_t), st);
+    dim3 grid(b.H / 4), block(256);
+    if (MT == 1) hipLaunchKernelGGL((lstm_seq_persist_fwd_kernel<1>), grid, block, lds, st, k);
+    else hipLaunchKernelGGL((lstm_seq_persist_fwd_kernel<2>), grid, block, lds, st, k);
+    T2_CHECK_LAUNCH();
     return T2_OK;
 }
 

@@ -75,6 +75,11 @@ class Engine:
         self._side = None
         self.chunk = 64               # frames per pipeline chunk of the forward frame loop
         self.chunk_bwd = 80           # frames per chunk of the backward pipeline (80*32 rows = 240 tiles of the dxdec GEMM)
+        self.dec_chain = "persistent" # forward decoder-LSTM chain: "persistent" (one weight-stationary launch per chunk on the side
+                                      # stream) or "hosted" (its steps ride in the attention-energies launches)
+        self.persist_gemm_side = True    # the hoisted pre_dec GEMM of a chunk runs on the side stream too, in front of the chunk's
+                                         # persistent launch (70.0 against 71.3 ms per step on the main stream, profiles/r02_ab_fwd_dec_chain.txt)
+        self._persist_sync = None
         self.share_cu = 1             # side-stream GEMMs next to the chains at ONE workgroup per CU: two 73 KB-LDS workgroups
                                       # per CU lock the attention kernels out (84.3 -> 83.2 ms)
         self.sync_bn_group = None     # torch.distributed group: BatchNorm statistics over all ranks' shards (Trainer(sync_bn=True))
@@ -82,6 +87,12 @@ class Engine:
                                       # so only the LATEST forward can be back-propagated (checked in backward_tf)
         self.profile = False          # when True, mark() records HIP events at segment boundaries
         self.marks = []; self.spans = []               # [(name, event)] of the current step
+
+    def check_persistent_kernels(self):
+        """Host-synchronising check of the persistent launches' timeout flag (bounded spins end the launch early instead of
+        hanging): raises if a wait timed out.  Tests and the bench call it after a step."""
+        if self._persist_sync is not None and int(self._persist_sync[256].item()) != 0:
+            raise _lib.T2Error("t2_lstm_seq_fwd_persist: an inter-workgroup wait timed out (outputs of that forward are invalid)")
 
     def side_stream(self):
         if self._side is None:
@@ -427,8 +438,33 @@ class Engine:
         side.wait_stream(main)
         import ctypes as _C
         chunks = [(c0, min(T, c0 + CH)) for c0 in range(0, T, CH)]
-        co = B <= 32                            # the hosted cell needs <= 32 batch rows (register budget of the host kernel)
-        for i, (c0, c1) in enumerate(chunks):
+        co = B <= 32 and self.dec_chain == "hosted"     # the hosted cell needs <= 32 rows (register budget of the host kernel)
+        persist = B <= 32 and self.dec_chain == "persistent" and D // 4 <= 256
+        if persist:
+            # The decoder-LSTM chain of a chunk as ONE persistent, weight-stationary launch on the side stream
+            # (t2_lstm_seq_fwd_persist): W_hh stays in LDS, the workgroups exchange h through the tiled stash, and the
+            # attention chain on the main stream runs without hosted cells (energies launch 11 -> 7.5 us per frame).
+            sync = self.buf("persist.sync", 320, dtype=torch.int32)
+            self._persist_sync = sync
+            for i, (c0, c1) in enumerate(chunks):
+                seq.t_begin, seq.t_end = c0, c1
+                seq.co_step, seq.co_inc, seq.co_steps = None, None, 0
+                call("t2_attn_seq_fwd", seq, st)
+                if not self.persist_gemm_side:
+                    pre_dec_gemm(c0, c1)
+                ev = main.record_event()
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    if self.persist_gemm_side:
+                        SHARE_CU[0] = self.share_cu
+                        pre_dec_gemm(c0, c1)
+                        SHARE_CU[0] = 0
+                    stp, inc = dec_chunk(c0, c1)
+                    call("t2_lstm_seq_fwd_persist", stp, inc, c1 - c0, sync, side.cuda_stream)
+            chunks_done = True
+        else:
+            chunks_done = False
+        for i, (c0, c1) in enumerate([] if chunks_done else chunks):
             seq.t_begin, seq.t_end = c0, c1
             if co and i >= 1:
                 stp, inc = dec_chunk(*chunks[i - 1])

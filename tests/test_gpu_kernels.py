@@ -234,6 +234,61 @@ def test_lstm_step_fwd_packed_tiled(dev, B, H, Ks, col0):
     assert torch.equal(h2, h)
 
 
+@pytest.mark.parametrize("B,H,S", [(32, 1024, 9), (5, 64, 6), (17, 128, 4)])
+def test_lstm_seq_fwd_persistent_matches_step_launches(dev, B, H, S):
+    """t2_lstm_seq_fwd_persist (ONE weight-stationary launch, workgroups exchanging h through the tiled stash) against the same
+    S steps as dependent launches (t2_lstm_seq_fwd) and against float64; the timeout flag must stay clear."""
+    from tacotron2_amd import _lib
+    g = torch.Generator().manual_seed(B + H + S)
+    Bp = (B + 15) // 16 * 16
+    W = torch.randn(4 * H, H, generator=g) / (H ** 0.5)
+    pre = torch.randn(S, B, 4 * H, generator=g)
+    drop = (torch.rand(S, B, H, generator=g) > 0.1).float() / 0.9
+    h0, c0 = torch.randn(B, H, generator=g) * 0.5, torch.randn(B, H, generator=g) * 0.5
+    # float64 reference
+    h, c = h0.double(), c0.double()
+    hs_ref = []
+    for s in range(S):
+        h, c = R.lstm_cell(pre[s].double() + h @ W.double().t(), c)
+        h = h * drop[s].double()
+        hs_ref.append(h)
+    st = torch.cuda.current_stream().cuda_stream
+    Wd = W.to(dev)
+    seg = (_lib.S["T2Seg"] * 1)()
+    seg[0].w = Wd.data_ptr(); seg[0].ldw = H; seg[0].K = H
+    ntpad = (H // 16 + 15) // 16 * 16
+    wp = torch.empty(H // 4 * ntpad * 256, device=dev)
+    _lib.call("t2_lstm_pack_fwd", seg, 1, H, wp, st)
+    outs = {}
+    for mode in ("launches", "persistent"):
+        ht = torch.zeros(S + 1, H // 16, Bp, 16, device=dev)
+        ht[0] = _tile16(h0, Bp).to(dev)
+        hrow = torch.zeros(S + 1, B, H, device=dev); hrow[0] = h0.to(dev)
+        cs = torch.zeros(S + 1, B, H, device=dev); cs[0] = c0.to(dev)
+        gs = torch.zeros(S, B, 4 * H, device=dev)
+        pd, dd = pre.to(dev), drop.to(dev)
+        stp = _lib.make("T2LstmStep", B=B, H=H, nseg=1, wpacked=wp, pre=pd, ldpre=4 * H, c_prev=cs, ldc_prev=H, drop=dd, lddrop=H,
+                        h_out=hrow[1], ldh=H, c_out=cs[1], ldc_out=H, gates_out=gs, ldg=4 * H, xt=ht, ht_out=ht[1], ht_col0=0)
+        stp.seg[0].x = hrow.data_ptr(); stp.seg[0].ldx = H; stp.seg[0].w = Wd.data_ptr(); stp.seg[0].ldw = H; stp.seg[0].K = H
+        inc = _lib.make("T2LstmStride", pre=B * 4 * H, c_prev=B * H, drop=B * H, h_out=B * H, c_out=B * H, gates_out=B * 4 * H,
+                        dt=0, xt=H * Bp, ht_out=H * Bp)
+        inc.seg_x[0] = B * H
+        if mode == "launches":
+            _lib.call("t2_lstm_seq_fwd", stp, inc, 1, S, st)
+        else:
+            sync = torch.full((320,), 7, dtype=torch.int32, device=dev)         # the call must zero what it polls
+            _lib.call("t2_lstm_seq_fwd_persist", stp, inc, S, sync, st)
+            torch.cuda.synchronize()
+            assert int(sync[256]) == 0, "an inter-workgroup wait timed out"
+        torch.cuda.synchronize()
+        outs[mode] = (hrow.clone(), cs.clone(), gs.clone(), ht.clone())
+    for a, b in zip(outs["launches"], outs["persistent"]):
+        assert _rel(a, b) < 2e-6
+    for s in range(S):
+        assert _rel(outs["persistent"][0][s + 1], hs_ref[s]) < 2e-5
+        assert _rel(_untile16(outs["persistent"][3][s + 1].cpu(), B), hs_ref[s]) < 2e-5
+
+
 @pytest.mark.parametrize("B,H,N4", [(32, 1024, 4096), (7, 48, 192), (33, 64, 256)])
 def test_lstm_step_bwd_packed_tiled(dev, B, H, N4):
     """dx = dgates . W + pointwise cell backward on the packed path with x16-tiled gradients in and out, against the same

@@ -228,17 +228,18 @@ def test_train_step_midsize_matches_oracle():
         ps.load_state_dict({k: v.detach() for k, v in Pc.items()})
 
 
-@pytest.mark.parametrize("B,chunk,chunk_bwd", [(5, 8, 8), (5, 64, 5), (5, 6, 64), (35, 7, 9)])
-def test_pipeline_chunking_matches_oracle(B, chunk, chunk_bwd):
-    """The frame loop's schedule (chunk sizes; forward: decoder-LSTM steps co-scheduled inside the attention-energies launches
-    for B <= 32, two-stream pipeline above; backward: two-stream pipeline) must not change results: every variant against the
+@pytest.mark.parametrize("B,chunk,chunk_bwd,dec_chain", [(5, 8, 8, "persistent"), (5, 64, 5, "hosted"), (5, 6, 64, "persistent"),
+                                                           (35, 7, 9, "persistent"), (5, 8, 8, "hosted")])
+def test_pipeline_chunking_matches_oracle(B, chunk, chunk_bwd, dec_chain):
+    """The frame loop's schedule (chunk sizes; forward: decoder-LSTM chain as persistent launches on the side stream or hosted inside the
+    attention-energies launches for B <= 32, two-stream pipeline above; backward: two-stream pipeline) must not change results: every variant against the
     CPU oracle on the same inputs."""
     dev = _dev()
     d = R.default_dims(num_chars=39, encoded_dim=64, prenet_dim=32, att_rnn_dim=64, att_dim=32, rnn_hidden_dim=64,
                        postnet_dim=64, num_mels=16, dropout=0.5)
     P = R.init_params(d, seed=11)
     eng, ps = build_engine(d, P, dev)
-    eng.chunk, eng.chunk_bwd = chunk, chunk_bwd
+    eng.chunk, eng.chunk_bwd, eng.dec_chain = chunk, chunk_bwd, dec_chain
     # (seed 77 at B = 35 puts one encoder pre-activation within 1e-6 of the ReLU kink: fp32 kernels with different summation
     # orders - the two GEMM kernels, the oracle - then legitimately disagree on that element's derivative; tools/debug_b35.py)
     ci, lens, mel, tl, gate, masks = random_case(d, B, 17, 23, 77 if B != 35 else 79, dev)
@@ -251,6 +252,7 @@ def test_pipeline_chunking_matches_oracle(B, chunk, chunk_bwd):
     ps.grad.zero_()
     loss3 = eng.loss_and_grads(outs, ctx, mel.to(dev), gate.to(dev))
     torch.cuda.synchronize()
+    eng.check_persistent_kernels()
     assert float((outs[1].cpu() - o[1].detach()).abs().mean()) < 1e-4          # mel L1 (north_star tolerance)
     assert float((outs[3].cpu() - o[3].detach()).abs().max()) < 1e-5          # alignments
     assert abs(float(loss3.sum()) - float(loss)) < 2e-5 * max(1.0, abs(float(loss)))
