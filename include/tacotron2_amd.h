@@ -350,6 +350,11 @@ typedef struct {
     int B, L, A, D, Ef, Ad, P, M, Kl, Tcap;
     const float* W_comb; const float* b_comb; const float* row_comb;
     const float* W_pre2;
+    /* optional x16-tiled copies (layout of T2LstmStep.xt: [K/16][rows padded to 16][16]) of the two small linears' operands:
+     * W_comb_t [(Ef+D)/16][Npad][16] with the K chunks in the order [ctx | dec_h] (the order of the tiled state), Npad =
+     * round_up(P+M+1, 16); W_pre2_t [P/16][P][16]; p1_t [P/16][Bp][16] scratch.  With them every wave-load of these launches is
+     * one contiguous 1 KB block (NULL: row-major operands, 16 half cache lines per wave-load). */
+    const float* W_comb_t; const float* W_pre2_t; float* p1_t;
     const float* wp_att; const float* b_att_ih; const float* b_att_hh;
     const float* wp_dec; const float* b_dec_ih; const float* b_dec_hh;
     const float* Wq; const float* U; const float* v;

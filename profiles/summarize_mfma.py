@@ -10,7 +10,7 @@ import csv
 import statistics
 import sys
 
-KEYS = ["gemm_f32_split_bf16", "gemm_f32_mfma", "lstm_step_fwd_fast", "lstm_step_bwd_fast", "lstm_step_fwd", "lstm_step_bwd",
+KEYS = ["gemm_f32_split_bf16", "gemm_f32_mfma", "lstm_seq_persist_fwd", "lstm_step_fwd_fast", "lstm_step_bwd_fast", "lstm_step_fwd", "lstm_step_bwd",
         "attn_energy_co", "attn_energy", "attn_context", "attn_bwd_dw", "attn_bwd_ds", "linear_rows", "bn_", "adam", "sumsq", "colsum"]
 
 

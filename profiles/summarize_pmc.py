@@ -8,10 +8,11 @@ import csv
 import statistics
 import sys
 
-KEYS = ["lstm_step_fwd_fast", "lstm_step_bwd_fast", "attn_energy", "attn_context_co", "attn_context", "attn_bwd_dw", "attn_bwd_ds",
-        "gemm_f32_mfma"]
-# kernels of the teacher-forced forward frame loop (the BiLSTM uses lstm_step_fwd_fast with a different grid)
-FWD_LOOP = ("lstm_step_fwd_fast grid=65536", "attn_energy", "attn_context", "attn_context_co")
+KEYS = ["lstm_seq_persist_fwd", "lstm_step_fwd_fast", "lstm_step_bwd_fast", "attn_energy", "attn_context", "attn_bwd_dw", "attn_bwd_ds",
+        "gemm_f32_split_bf16", "gemm_f32_mfma"]
+# kernels of the teacher-forced forward frame loop (the BiLSTM uses lstm_step_fwd_fast with a different grid; the decoder-LSTM
+# chain is the persistent launch, one per chunk of frames)
+FWD_LOOP = ("lstm_step_fwd_fast grid=65536", "attn_energy", "attn_context", "lstm_seq_persist_fwd")
 
 
 def main(argv):
@@ -36,8 +37,8 @@ def main(argv):
                 total += sum(v) * 1024 * (2 if c == "FETCH_SIZE" else 1)
     if total:
         per_step = total / (n_steps * T)
-        print(f"\nHBM-side traffic of the forward frame-loop kernels (attention cell, energies, context [+ co-scheduled decoder "
-              f"cell], decoder cell) per decoder step, FETCH x2 corrected + WRITE, {n_steps} training steps x T={T}: "
+        print(f"\nHBM-side traffic of the forward frame-loop kernels (attention cell, energies, context, persistent decoder-LSTM "
+              f"chain) per decoder step, FETCH x2 corrected + WRITE, {n_steps} training steps x T={T}: "
               f"{per_step / 1e6:.1f} MB   (algorithmic bytes/step 89.1 MB at B=32, L=188)")
 
 

@@ -40,6 +40,11 @@ struct LinK {
     float* out; long ldo;          // may be null when only the tiled copy is wanted
     float* out2; long ldo2;        // column n lands at out2[b*ldo2 + n - split_n]
     float* out_t; int out_col0; long out_cs;   // optional x16-tiled copy of the `out` columns (chunk stride out_cs floats)
+    // optional x16-tiled operands (one 16 x 16 MFMA operand tile = ONE contiguous 1 KB block, as in the LSTM step kernels;
+    // row-major rows make every wave-load 16 half cache lines, 3-4x slower through the vector memory pipe):
+    const float* wt; long wt_cs;               // weights [K/16][Npad][16], chunk stride wt_cs = Npad*16 floats
+    const float* xt0; int nch0;                // activations, chunks [0, nch0): tiled [.][Bp][16] from xt0 ...
+    const float* xt1; long xt_cs;              // ... chunks [nch0, K/16): from xt1; chunk stride xt_cs = Bp*16 floats
     // optional stop logic of the PREVIOUS frame, run by one extra workgroup next to the linear (saves one dependent launch per frame)
     const float* stop_proj; long stop_ldp; int stop_M, stop_t;
     int32_t* stop_done; int32_t* stop_state;
@@ -81,26 +86,37 @@ __global__ __launch_bounds__(256, 1) void linear_rows_kernel(LinK p) {
     const int r = lane & 15, q = lane >> 4;
     const int n0 = blockIdx.x * 16, b0 = blockIdx.y * (MT * 16);
     const int nrow = (n0 + r) < p.N ? (n0 + r) : p.N - 1;
-    const float* wb = p.w + (long)nrow * p.ldw + 4 * q;
+    const bool tiled = p.wt != nullptr;
+    // tiled: chunk c of the weights at wb + c*wcs, of the activations at (c < nch0 ? xb : xb1) + c'*xcs
+    const float* wb = tiled ? p.wt + (long)nrow * 16 + 4 * q : p.w + (long)nrow * p.ldw + 4 * q;
+    const long wcs = tiled ? p.wt_cs : 16;
     const float* xb[MT];
+    const float* xb1[MT];
+    const long xcs = tiled ? p.xt_cs : 16;
+    const int nch0 = tiled ? p.nch0 : (p.K >> 4);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int row = b0 + m * 16 + r;
-        xb[m] = p.x + (long)(row < p.B ? row : 0) * p.ldx + 4 * q;
+        xb[m] = tiled ? p.xt0 + (long)row * 16 + 4 * q : p.x + (long)(row < p.B ? row : 0) * p.ldx + 4 * q;
+        xb1[m] = tiled ? p.xt1 + (long)row * 16 + 4 * q : xb[m];
     }
     f32x4 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int NT = p.K >> 4;
-    constexpr int U = 4;
+    // 12 chunks per wave and round: every load of a K <= 768 slice - for the K = 1536 combined linear two rounds - is in
+    // flight before the first MFMA waits (these launches are a handful of workgroups deep: latency, not bandwidth; with 4
+    // chunks per round the K = 1536 launch took six dependent round trips, 8.7 us)
+    constexpr int U = 12;
     for (int c0 = w; c0 < NT; c0 += 4 * U) {
         f32x4 bw[U], ax[U][MT];
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int c = c0 + 4 * j < NT ? c0 + 4 * j : NT - 1;
-            bw[j] = *reinterpret_cast<const f32x4*>(wb + 16 * c);
+            bw[j] = *reinterpret_cast<const f32x4*>(wb + wcs * c);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) ax[j][m] = *reinterpret_cast<const f32x4*>(xb[m] + 16 * c);
+            for (int m = 0; m < MT; ++m)
+                ax[j][m] = *reinterpret_cast<const f32x4*>(c < nch0 ? xb[m] + xcs * c : xb1[m] + xcs * (c - nch0));
         }
 #pragma unroll
         for (int j = 0; j < U; ++j) {
@@ -135,8 +151,10 @@ __global__ __launch_bounds__(256, 1) void linear_rows_kernel(LinK p) {
 }
 
 int launch_linear(const LinK& k, hipStream_t st) {
-    T2_REQUIRE(k.K % 16 == 0 && k.ldx % 4 == 0 && k.ldw % 4 == 0 && t2_aligned16(k.x) && t2_aligned16(k.w),
+    T2_REQUIRE(k.K % 16 == 0 && (k.wt || (k.ldx % 4 == 0 && k.ldw % 4 == 0 && t2_aligned16(k.x) && t2_aligned16(k.w))),
                "linear rows: K % 16 == 0 and 16-byte aligned operands required");
+    T2_REQUIRE(!k.wt || (k.xt0 && k.xt1 && t2_aligned16(k.wt) && t2_aligned16(k.xt0) && t2_aligned16(k.xt1) && k.nch0 >= 0 &&
+                         k.nch0 <= (k.K >> 4)), "linear rows: tiled operands");
     T2_REQUIRE(k.B >= 1 && k.B <= 64, "linear rows: 1 <= B <= 64");
     T2_REQUIRE(k.split_n >= k.N || k.out2 != nullptr, "linear rows: out2 required for columns >= split_n");
     T2_REQUIRE(k.out || k.out_t || k.split_n <= 0, "linear rows: no destination for the activated columns");
@@ -236,10 +254,19 @@ extern "C" int t2_decoder_infer(const T2Infer* a, int t0, int t1, void* stream) 
         LinK k;
         memset(&k, 0, sizeof(k));
         k.B = B; k.N = P + M + 1; k.K = (int)ldp; k.x = a->xproj; k.ldx = ldp; k.w = a->W_comb; k.ldw = ldp; k.bias = a->b_comb;
+        if (a->W_comb_t) {
+            // tiled operands: weights [ (Ef + D)/16 ][Npad][16] in the K order [ctx | dec_h]; ctx_{t-1} sits in slot t&1 of the tiled
+            // state (written by the context kernel of frame t-1), dec_h_{t-1} in slot (t+1)&1 (written by its decoder cell)
+            const int Npad = (k.N + 15) / 16 * 16;
+            k.wt = a->W_comb_t; k.wt_cs = (long)Npad * 16;
+            k.xt0 = a->xs + (long)(t & 1) * slot + (long)((P + A) / 16) * cs; k.nch0 = Ef / 16;
+            k.xt1 = a->xs + (long)((t + 1) & 1) * slot + (long)((P + A + Ef) / 16) * cs; k.xt_cs = cs;
+        }
         k.rowterm = a->row_comb; k.ldrt = P + M + 1;
         k.mask = (with_mask && a->prenet_mask) ? a->prenet_mask + ((long)t * 2 + 0) * B * P : nullptr;
         k.ldmask = P; k.relu = 1; k.split_n = P;
         k.out = a->p1; k.ldo = P; k.out2 = a->proj + (long)(t - 1) * B * ldo; k.ldo2 = ldo;
+        if (a->p1_t) { k.out_t = a->p1_t; k.out_col0 = 0; k.out_cs = cs; }
         return launch_linear(k, st);
     };
     for (int t = t0; t < t1; ++t) {
@@ -250,6 +277,7 @@ extern "C" int t2_decoder_infer(const T2Infer* a, int t0, int t1, void* stream) 
             LinK k;     // second prenet layer -> tiled state; one extra workgroup: stop logic of frame t-1 (frames of this call only)
             memset(&k, 0, sizeof(k));
             k.B = B; k.N = P; k.K = P; k.x = a->p1; k.ldx = P; k.w = a->W_pre2; k.ldw = P;
+            if (a->W_pre2_t && a->p1_t) { k.wt = a->W_pre2_t; k.wt_cs = (long)P * 16; k.xt0 = a->p1_t; k.nch0 = P / 16; k.xt1 = a->p1_t; k.xt_cs = cs; }
             k.mask = a->prenet_mask ? a->prenet_mask + ((long)t * 2 + 1) * B * P : nullptr;
             k.ldmask = P; k.relu = 1; k.split_n = P;
             k.out_t = xs_cur; k.out_col0 = 0; k.out_cs = cs;

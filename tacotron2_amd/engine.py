@@ -905,6 +905,7 @@ class Engine:
             pm = None
         a = make("T2Infer", B=B, L=L, A=A, D=D, Ef=Ef, Ad=Ad, P=Pd, M=M, Kl=KL, Tcap=Tcap,
                  W_comb=self._w_comb, b_comb=self._b_comb, row_comb=row_comb, W_pre2=P["prenet.3.weight"],
+                 W_comb_t=self._w_comb_t, W_pre2_t=self._w_pre2_t, p1_t=self.buf(pf + "p1_t", Pd // 16, Bp, 16, zero=True),
                  wp_att=self._wp_att_inf, b_att_ih=P["decoder.att_rnn.bias_ih"], b_att_hh=P["decoder.att_rnn.bias_hh"],
                  wp_dec=self._wp_dec_inf, b_dec_ih=P["decoder.lstm.bias_ih"], b_dec_hh=P["decoder.lstm.bias_hh"],
                  Wq=P["decoder.attention.query_layer.weight"], U=self._U_inf, v=P["decoder.attention.v.weight"],
@@ -949,6 +950,14 @@ class Engine:
         gemm(P["prenet.0.weight"], wproj, self._w_comb, Pd, ldp, M, M, ldp, ldp, a_k=1, b_k=0)
         gemm(P["prenet.0.weight"], bproj, self._b_comb, Pd, 1, M, M, 1, 1, a_k=1, b_k=0)
         self._w_comb[Pd:].copy_(wproj); self._b_comb[Pd:].copy_(bproj)
+        # x16-tiled copies of the two small linears' weights (data movement only): [K/16][rows padded to 16][16], the combined
+        # linear's K chunks in the order [ctx | dec_h] of the tiled state
+        Nc = Pd + M + 1
+        Ncp = (Nc + 15) // 16 * 16
+        wc = torch.zeros(Ncp, ldp, device=self.dev)
+        wc[:Nc, :Ef] = self._w_comb[:, D:]; wc[:Nc, Ef:] = self._w_comb[:, :D]
+        self._w_comb_t = wc.view(Ncp, ldp // 16, 16).permute(1, 0, 2).contiguous()
+        self._w_pre2_t = P["prenet.3.weight"].view(Pd, Pd // 16, 16).permute(1, 0, 2).contiguous()
         groups = []
         for g, b0 in enumerate(range(0, B, 64)):
             sl = slice(b0, min(B, b0 + 64))

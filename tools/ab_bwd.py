@@ -1,5 +1,5 @@
-"""A/B of the backward schedule on the bench batch (GPU box): decoder BPTT hosted in the attention cell-backward launches vs
-on the side stream; prints step time and the backward segments for both."""
+"""A/B of the backward schedule on the bench batch (GPU box): chunk size of the two-stream backward pipeline (round 2 also ran
+this script with the decoder BPTT hosted in the attention cell-backward launches: profiles/r02_ab_bwd_schedule.txt)."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import VANILLA
@@ -12,8 +12,8 @@ ps = ParamStore(VANILLA, dev); init_parameters(ps, 0)
 tr = Trainer(ps, lr=1e-3, weight_decay=1e-6)
 batch = {k: v.to(dev) for k, v in ljspeech_batch(32, seed=1234, num_speakers=4).items()}
 for rep in range(2):
-    for co, chunk in ((True, 80), (False, 80), (True, 40), (True, 160)):
-        tr.engine.co_schedule_bwd, tr.engine.chunk_bwd = co, chunk
+    for co, chunk in ((False, 80), (False, 48), (False, 64), (False, 112), (False, 160), (False, 218)):
+        tr.engine.chunk_bwd = chunk
         for _ in range(3):
             tr.train_step(batch)
         torch.cuda.synchronize()
