@@ -3,8 +3,9 @@
 
     python main.py --config C --device N train --speech-dir S [--results-dir R] [--resume-ckpt K] [--finetune --finetune-steps n]
     python main.py --config C --device N say --checkpoint K --text "..." [--out out.npy] [--random-seed s] [--speaker-id i]
+    python main.py --config C --device N test --speech-dir S --checkpoint K [--hifi-gan-checkpoint G] [--results-dir R]
 
-Other reference sub-commands (test, test_correlation, train_mel_export, preprocess, server) are evaluation / demo tooling
+Other reference sub-commands (test_correlation, train_mel_export, preprocess, server) are evaluation / demo tooling
 outside the hot-path scope.  Multi-GPU training: `python -m torch.distributed.run --nproc-per-node N
 main.py --config C train ...` (one process per GPU, RCCL gradient all-reduce)."""
 import click
@@ -65,6 +66,26 @@ def say(ctx, checkpoint, text, out, speaker_id, hifi_gan_checkpoint, random_seed
            extensions_config=c["extensions"], device=ctx.obj["device"], checkpoint=checkpoint, text=text, output=out,
            speaker_id=speaker_id, hifi_gan_checkpoint=hifi_gan_checkpoint, random_seed=random_seed, controls=controls,
            description=description)
+
+
+@main.command()
+@click.pass_context
+@click.option("--speech-dir", required=True, type=str, help="A directory containing audio files from the dataset.")
+@click.option("--checkpoint", required=True, type=str, help="A trained Tacotron model checkpoint")
+@click.option("--hifi-gan-checkpoint", required=False, type=str, default=None, help="A HiFi-GAN generator checkpoint. If not given, Griffin-Lim is used.")
+@click.option("--results-dir", required=False, type=str, default=None, help="The directory to save results.")
+@click.option("--batch-size", required=False, type=int, default=8, help="Utterances decoded together (reference: 8; up to 64 per decode group).")
+@click.option("--max-len", required=False, type=int, default=5000, help="Frame cap per utterance (reference: 5000).")
+@click.option("--limit", required=False, type=int, default=None, help="Only the first n utterances of the test manifest.")
+def test(ctx, speech_dir, checkpoint, hifi_gan_checkpoint, results_dir, batch_size, max_len, limit):
+    """Synthesise the test manifest (run/test.py of the reference): one wav per utterance + failures.csv."""
+    if ctx.obj["config"] is None:
+        raise Exception("Configuration required for testing!")
+    from tacotron2_amd.run.test import do_test
+    c = ctx.obj["config"]
+    do_test(dataset_config=c["dataset"], training_config=c["training"], model_config=c["model"],
+            extensions_config=c["extensions"], device=ctx.obj["device"], speech_dir=speech_dir, checkpoint=checkpoint,
+            hifi_gan_checkpoint=hifi_gan_checkpoint, results_dir=results_dir, batch_size=batch_size, max_len=max_len, limit=limit)
 
 
 if __name__ == "__main__":

@@ -168,3 +168,67 @@ def TTSDataLoader(dataset, batch_size=1, num_workers=0, shuffle=None, drop_last=
         return torch.utils.data.DataLoader(dataset, batch_sampler=sampler, collate_fn=collate, num_workers=0)
     return torch.utils.data.DataLoader(dataset, batch_size=batch_size, collate_fn=collate if batch_size > 1 else None,
                                        num_workers=0, shuffle=shuffle, drop_last=drop_last)
+
+
+class DevicePrefetcher:
+    """Batches of `loader`, ready on the device `depth` steps ahead of the training loop.
+
+    A background thread walks the loader - wav decode and trim on the host, the log-mel kernels of cache misses, collate -
+    and moves each batch to the device (`to_device(batch, dev)`) on ITS OWN HIP stream, so host-side item work and the
+    host->device copies of batch k+1 run while the training step of batch k occupies the main stream (the reference gets
+    the same overlap from DataLoader worker processes + pin_memory, run/train.py:140-158).  ctypes calls and torch copies
+    release the GIL.  The consumer's stream waits for the batch's event and the tensors are re-registered with it
+    (`record_stream`), so the caching allocator does not hand their memory back to the copy stream while they are in use."""
+
+    _END = object()
+
+    def __init__(self, loader, to_device, device, depth: int = 2):
+        self.loader, self.to_device, self.device, self.depth = loader, to_device, torch.device(device), max(1, depth)
+        self.stream = None
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _work(self, q, stop):
+        try:
+            torch.cuda.set_device(self.device)
+            with torch.cuda.stream(self.stream):
+                for b in self.loader:
+                    if stop.is_set():
+                        return
+                    out = self.to_device(b, self.device)
+                    ev = torch.cuda.Event()
+                    ev.record(self.stream)
+                    q.put((out, ev))
+            q.put((self._END, None))
+        except BaseException as e:      # surfaces in the consumer
+            q.put((e, None))
+
+    def __iter__(self):
+        import queue
+        import threading
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=self.device)
+        q, stop = queue.Queue(maxsize=self.depth), threading.Event()
+        th = threading.Thread(target=self._work, args=(q, stop), daemon=True)
+        th.start()
+        try:
+            while True:
+                out, ev = q.get()
+                if out is self._END:
+                    return
+                if isinstance(out, BaseException):
+                    raise out
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                for v in (out.values() if isinstance(out, dict) else out):
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(cur)
+                yield out
+        finally:
+            stop.set()
+            while th.is_alive():        # unblock a producer waiting on the full queue
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    th.join(timeout=0.05)

@@ -35,7 +35,7 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
              speech_dir: str, results_dir: Optional[str], resume_ckpt: Optional[str], finetune: bool = False,
              finetune_steps: Optional[int] = None, max_steps_override: Optional[int] = None, synthetic: bool = False):
     import pandas as pd
-    from ..datasets.tts_dataset import TTSDataLoader, TTSDataset
+    from ..datasets.tts_dataset import DevicePrefetcher, TTSDataLoader, TTSDataset
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
     if world > 1 and not dist.is_initialized():
         device = int(os.environ.get("LOCAL_RANK", device))
@@ -92,10 +92,12 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
         # training.bucket_window (not a reference key): batches of similar text length, see LengthBucketBatchSampler
         loader = TTSDataLoader(ds, batch_size=training_config["batch_size"], shuffle=True, drop_last=True,
                                bucket_window=int(training_config.get("bucket_window", 0)), seed=rank)
+        # items and host->device copies of the next batches are prepared by a background thread on its own stream
+        prefetch = DevicePrefetcher(loader, _to_dev, dev, depth=int(training_config.get("prefetch_batches", 2)))
         def batches():
             while True:
-                for b in loader:
-                    yield _to_dev(b, dev)
+                for b in prefetch:
+                    yield b
 
     val_loader = None
     if not synthetic and dataset_config.get("val") and os.path.exists(dataset_config["val"]):

@@ -32,3 +32,32 @@ def tf_masks_from(z, dtype=torch.float32):
         att_drop=t(z["m.att_drop"]), dec_drop=t(z["m.dec_drop"]),
         post_drop=[t(z[f"m.post_drop.{i}"]) for i in range(5)],
     )
+
+
+def write_hifigan_checkpoint(hdir, n_mels=80, ch0=16, seed=0):
+    """A generator checkpoint in the published layout ({"generator": weight-normed state_dict}, config.json next to it):
+    UNIVERSAL_V1 strides 8*8*2*2 = 256 samples per frame, narrow channels for speed.  Returns the checkpoint path."""
+    import json
+    os.makedirs(hdir, exist_ok=True)
+    hcfg = dict(resblock="1", upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4], upsample_initial_channel=ch0,
+                resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]])
+    with open(os.path.join(hdir, "config.json"), "w") as f:
+        json.dump(hcfg, f)
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def wn(name, *shape):
+        sd[name + ".weight_v"] = torch.randn(*shape, generator=g) * 0.2
+        sd[name + ".weight_g"] = torch.rand(shape[0], 1, 1, generator=g) * 0.5 + 0.25
+        sd[name + ".bias"] = torch.zeros(shape[0] if "ups" not in name else shape[1])
+    wn("conv_pre", ch0, n_mels, 7)
+    ch = ch0
+    for i, k in enumerate(hcfg["upsample_kernel_sizes"]):
+        wn(f"ups.{i}", ch, ch // 2, k); ch //= 2
+        for j, kk in enumerate(hcfg["resblock_kernel_sizes"]):
+            for c in range(3):
+                wn(f"resblocks.{i * 3 + j}.convs1.{c}", ch, ch, kk); wn(f"resblocks.{i * 3 + j}.convs2.{c}", ch, ch, kk)
+    wn("conv_post", 1, ch, 7)
+    path = os.path.join(hdir, "g_00000001")
+    torch.save({"generator": sd}, path)
+    return path

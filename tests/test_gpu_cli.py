@@ -62,30 +62,11 @@ def test_cli_train_synthetic_then_say(tmp_path):
         assert w.getframerate() == 22050 and w.getsampwidth() == 2 and w.getnframes() == 256 * (mel.shape[0] - 1)
     # --hifi-gan-checkpoint (run/say.py:66-86,153-159): a generator checkpoint in the published layout ({"generator": weight-normed
     # state_dict}, config.json next to it; UNIVERSAL_V1 strides 8*8*2*2 = 256 samples per frame, narrow channels for speed)
-    hdir = tmp_path / "hifi"
-    hdir.mkdir()
-    hcfg = dict(resblock="1", upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4], upsample_initial_channel=16,
-                resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]])
-    (hdir / "config.json").write_text(json.dumps(hcfg))
-    g = torch.Generator().manual_seed(0)
-    sd = {}
-    def wn(name, *shape):
-        sd[name + ".weight_v"] = torch.randn(*shape, generator=g) * 0.2
-        sd[name + ".weight_g"] = torch.rand(shape[0], 1, 1, generator=g) * 0.5 + 0.25
-        sd[name + ".bias"] = torch.zeros(shape[0] if "ups" not in name else shape[1])
-    wn("conv_pre", 16, 80, 7)
-    ch = 16
-    for i, k in enumerate(hcfg["upsample_kernel_sizes"]):
-        wn(f"ups.{i}", ch, ch // 2, k); ch //= 2
-        for j, kk in enumerate(hcfg["resblock_kernel_sizes"]):
-            for c in range(3):
-                wn(f"resblocks.{i * 3 + j}.convs1.{c}", ch, ch, kk); wn(f"resblocks.{i * 3 + j}.convs2.{c}", ch, ch, kk)
-    wn("conv_post", 1, ch, 7)
-    torch.save({"generator": sd}, hdir / "g_00000001")
+    from helpers import write_hifigan_checkpoint
+    gck = write_hifigan_checkpoint(str(tmp_path / "hifi"))
     hwav = tmp_path / "say_hifi.wav"
     _run(["--config", str(cfg), "--device", "0", "say", "--checkpoint", str(res / "final.ckpt"), "--text",
-          "Hello, Mr. Smith-Jones!", "--out", str(hwav), "--random-seed", "3", "--speaker-id", "1", "--hifi-gan-checkpoint",
-          str(hdir / "g_00000001")])
+          "Hello, Mr. Smith-Jones!", "--out", str(hwav), "--random-seed", "3", "--speaker-id", "1", "--hifi-gan-checkpoint", gck])
     with wave.open(str(hwav), "rb") as w:
         assert w.getframerate() == 22050 and w.getnframes() == 256 * mel.shape[0]
 
@@ -227,3 +208,70 @@ def test_cli_finetune_runs_exactly_n_steps_with_frozen_encoder(tmp_path):
     order = reference_param_order(dict(ck1["hyper_parameters"]))
     i = order.index("encoder.convolutions.0.weight")
     assert torch.equal(ck0["optimizer_states"][0]["state"][i]["exp_avg"], ck1["optimizer_states"][0]["state"][i]["exp_avg"])
+
+
+def test_cli_test_command_writes_one_wav_per_manifest_row(tmp_path):
+    """`main.py test` (run/test.py:29-227): the test manifest through the batched decode path, then HiFi-GAN or Griffin-Lim.
+    The weights are those of the reference-generated `infer` fixture (small dims, stops after a few frames), so utterances DO
+    stop; numbering, lengths (`(gate < 0).argmax` frames x 256 samples) and failures.csv follow the reference."""
+    import wave
+    from helpers import load_golden, params_from, write_hifigan_checkpoint
+    z = load_golden("infer")
+    sd = {"tacotron2." + k: v for k, v in params_from(z).items()}
+    hp = dict(lr=1e-3, weight_decay=1e-6, num_chars=39, encoded_dim=32, num_mels=16, prenet_dim=16, att_rnn_dim=32, att_dim=16,
+              rnn_hidden_dim=32, postnet_dim=32, dropout=0.5)
+    ck = tmp_path / "m.ckpt"
+    torch.save({"state_dict": sd, "hyper_parameters": hp, "global_step": 0, "epoch": 0}, ck)
+    rows = ["text|wav|speaker_id"] + [f"{t}|none{i}.wav|0" for i, t in enumerate(
+        ["Hi there.", "A somewhat longer sentence, Dr. Who!", "ok", "Testing: one; two? three.", "The end"])]
+    csvp = tmp_path / "test.csv"
+    csvp.write_text("\n".join(rows) + "\n")
+    cfg = {"dataset": {"train": "none.csv", "val": "none.csv", "test": str(csvp),
+                       "preprocessing": {"allowed_chars": ALLOWED, "expand_abbreviations": True, "end_token": "^", "num_mels": 16}},
+           "training": {"lr": 1e-3, "batch_size": 4, "weight_decay": 1e-6, "name": "tiny", "args": {"max_steps": 6}},
+           "model": {"scheduler_milestones": [], "args": {"prenet_dim": 16, "att_rnn_dim": 32, "att_dim": 16, "rnn_hidden_dim": 32,
+                                                          "postnet_dim": 32, "dropout": 0.5, "char_embedding_dim": 32}},
+           "extensions": {"speaker_tokens": {"active": False}, "controls": {"active": False}}}
+    cfgp = tmp_path / "cfg.json"
+    cfgp.write_text(json.dumps(cfg))
+    gck = write_hifigan_checkpoint(str(tmp_path / "hifi"), n_mels=16)
+    for name, extra in (("hifi", ["--hifi-gan-checkpoint", gck]), ("gl", [])):
+        res = tmp_path / f"res_{name}"
+        _run(["--config", str(cfgp), "--device", "0", "test", "--speech-dir", "unused", "--checkpoint", str(ck), "--results-dir",
+              str(res), "--batch-size", "3", "--max-len", "40"] + extra)
+        fails = set()
+        if os.path.exists(res / "failures.csv"):
+            fails = {int(l.split("|")[0]) for l in open(res / "failures.csv").read().splitlines()}
+        n_ok = 0
+        for i in range(1, 6):
+            p = res / f"{i}.wav"
+            if i in fails and name == "gl":
+                assert not os.path.exists(p)
+                continue
+            with wave.open(str(p), "rb") as w:
+                assert w.getframerate() == 22050 and w.getsampwidth() == 2
+                if i not in fails:      # HiFi-GAN: 256 samples per frame; Griffin-Lim (centred frames): 256 * (frames - 1)
+                    assert w.getnframes() % 256 == 0 and w.getnframes() <= 40 * 256 and (name == "gl" or w.getnframes() > 0)
+                    n_ok += 1
+        assert n_ok >= 3, (name, fails)       # the fixture's stop logit falls below zero within a few frames
+
+
+def test_device_prefetcher_yields_the_loader_batches_in_order():
+    """DevicePrefetcher (background thread + copy stream in front of the training loop): same batches, same order, every epoch;
+    a failing item surfaces in the consumer; leaving the loop early stops the thread."""
+    from tacotron2_amd.datasets.tts_dataset import DevicePrefetcher
+    dev = torch.device("cuda:0")
+    batches = [{"a": torch.full((4, 1000), float(i)), "n": torch.tensor([i])} for i in range(7)]
+    to_dev = lambda b, d: {k: v.to(d) for k, v in b.items()}
+    pf = DevicePrefetcher(batches, to_dev, dev, depth=2)
+    for _ in range(2):
+        got = [(float(b["a"].sum()), int(b["n"]), b["a"].device.type) for b in pf]
+        assert got == [(4000.0 * i, i, "cuda") for i in range(7)]
+
+    def bad(b, d):
+        raise ValueError("boom")
+    with pytest.raises(ValueError):
+        next(iter(DevicePrefetcher(batches, bad, dev)))
+    it = iter(pf)
+    assert int(next(it)["n"]) == 0
+    it.close()
