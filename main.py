@@ -4,8 +4,9 @@
     python main.py --config C --device N train --speech-dir S [--results-dir R] [--resume-ckpt K] [--finetune --finetune-steps n]
     python main.py --config C --device N say --checkpoint K --text "..." [--out out.npy] [--random-seed s] [--speaker-id i]
     python main.py --config C --device N test --speech-dir S --checkpoint K [--hifi-gan-checkpoint G] [--results-dir R]
+    python main.py --config C --device N train-mel-export --speech-dir S --checkpoint K [--results-dir R]
 
-Other reference sub-commands (test_correlation, train_mel_export, preprocess, server) are evaluation / demo tooling
+Other reference sub-commands (test_correlation, preprocess, server) are evaluation / demo tooling
 outside the hot-path scope.  Multi-GPU training: `python -m torch.distributed.run --nproc-per-node N
 main.py --config C train ...` (one process per GPU, RCCL gradient all-reduce)."""
 import click
@@ -86,6 +87,22 @@ def test(ctx, speech_dir, checkpoint, hifi_gan_checkpoint, results_dir, batch_si
     do_test(dataset_config=c["dataset"], training_config=c["training"], model_config=c["model"],
             extensions_config=c["extensions"], device=ctx.obj["device"], speech_dir=speech_dir, checkpoint=checkpoint,
             hifi_gan_checkpoint=hifi_gan_checkpoint, results_dir=results_dir, batch_size=batch_size, max_len=max_len, limit=limit)
+
+
+@main.command()
+@click.pass_context
+@click.option("--speech-dir", required=True, type=str, help="A directory containing audio files from the dataset.")
+@click.option("--checkpoint", required=True, type=str, help="A trained Tacotron model checkpoint")
+@click.option("--results-dir", required=False, type=str, default=None, help="The directory to save results. Defaults to the model configuration name with a timestamp.")
+def train_mel_export(ctx, speech_dir, checkpoint, results_dir=None):
+    """Teacher-forced post-net mels of the train + val manifests (run/train_mel_export.py of the reference)."""
+    if ctx.obj["config"] is None:
+        raise Exception("Configuration required!")
+    from tacotron2_amd.run.train_mel_export import do_train_mel_export
+    c = ctx.obj["config"]
+    do_train_mel_export(dataset_config=c["dataset"], training_config=c["training"], model_config=c["model"],
+                        extensions_config=c["extensions"], device=ctx.obj["device"], speech_dir=speech_dir, checkpoint=checkpoint,
+                        results_dir=results_dir)
 
 
 if __name__ == "__main__":

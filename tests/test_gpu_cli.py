@@ -92,6 +92,14 @@ def test_cli_train_on_wav_manifest_resume(tmp_path):
     out = _run(["--config", str(cfg), "train", "--speech-dir", str(speech), "--results-dir", str(res), "--max-steps", "4",
                 "--resume-ckpt", str(res / "final.ckpt")])
     assert "step 3/4" in out or "step 4/4" in out
+    # train-mel-export (run/train_mel_export.py): teacher-forced post-net mels of train + val manifests, one file per wav
+    exp = tmp_path / "export"
+    _run(["--config", str(cfg), "train-mel-export", "--speech-dir", str(speech), "--checkpoint", str(res / "final.ckpt"),
+          "--results-dir", str(exp)])
+    for i in range(6):
+        m = np.load(exp / f"u{i}.wav.np.npy")
+        n = sr // 2 + 997 * i + 512                        # samples after the configured silence pad
+        assert m.shape == (1 + n // 256, 80) and np.isfinite(m).all()
 
 
 def test_cli_controls_extension_train_then_say(tmp_path):
