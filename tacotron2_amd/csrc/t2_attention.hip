@@ -303,6 +303,7 @@ __device__ __forceinline__ void attn_energy_body(const AttnK& p, const int b, co
 }
 
 __global__ __launch_bounds__(ENT, 2) void attn_energy_kernel(AttnK p) {
+    T2_CHAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) float sm[];
     attn_energy_body(p, blockIdx.x, blockIdx.y, sm);
 }
@@ -409,6 +410,7 @@ __device__ __forceinline__ void attn_context_body(const AttnK& p, const int b, c
 }
 
 __global__ __launch_bounds__(256, 1) void attn_context_kernel(AttnK p) {
+    T2_CHAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) float sm[];
     attn_context_body(p, blockIdx.x, blockIdx.y * 32, sm);
 }
@@ -450,6 +452,7 @@ void to_ak(const T2AttnStep& s, AttnK& k) {
 // registers), so an energies workgroup (2 waves per SIMD) and a cell workgroup (1 wave per SIMD) share a CU at <= 168 VGPRs.
 template <int MT>
 __global__ __launch_bounds__(ENT, 3) void attn_energy_co_kernel(AttnK p, LstmK c, int nE) {
+    T2_CHAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int bid = blockIdx.x;
     if (bid < nE) { attn_energy_body(p, bid % p.B, bid / p.B, sm); return; }
@@ -612,6 +615,7 @@ struct AttnBwdK {
 namespace {
 
 __global__ __launch_bounds__(256, 1) void attn_bwd_dw_kernel(AttnBwdK p) {
+    T2_CHAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x, l0 = blockIdx.y * 32, tid = threadIdx.x;
     const int L = p.L, Ef = p.Ef, NA = p.Ad >> 4;
@@ -926,6 +930,7 @@ __device__ __forceinline__ void attn_bwd_ds_body(const AttnBwdK& p, const int b,
 }
 
 __global__ __launch_bounds__(ENT, 2) void attn_bwd_ds_kernel(AttnBwdK p) {
+    T2_CHAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) float sm[];
     attn_bwd_ds_body(p, blockIdx.x, blockIdx.y, sm);
 }

@@ -43,6 +43,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void t2_set_error(const char* msg, const char* file, int line);
 
+// First statement of every kernel of the latency-bound frame chains (cell steps, attention kernels, decode linears): their
+// waves win instruction-issue arbitration against the GEMM waves of the other stream that share the SIMD (default priority 0).
+// 70.35 -> 69.47 ms per training step in one session (profiles/r02_ab_wave_priority.txt); no effect without a second stream.
+#define T2_CHAIN_PRIO() __builtin_amdgcn_s_setprio(3)
+
 static inline int t2_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool t2_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 

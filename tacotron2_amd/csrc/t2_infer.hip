@@ -75,6 +75,7 @@ __device__ __forceinline__ void stop_logic(const float* proj, long ldp, int M, i
 // (K % 16 == 0), all loads of a group issued before the first MFMA wait; partial tiles are summed in fixed wave order.
 template <int MT>
 __global__ __launch_bounds__(256, 1) void linear_rows_kernel(LinK p) {
+    T2_CHAIN_PRIO();
     __shared__ float red[4 * MT * 256];
     __shared__ int notdone;
     if (p.stop_proj && blockIdx.x == gridDim.x - 1) {   // one extra workgroup: the stop logic runs next to the linear, not in front

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmK2 pp) {
 // ---------------------------------------------------------------------------------------------------------
 template <int MT, int U>
 __global__ __launch_bounds__(256, 1) void lstm_step_fwd_fast_kernel(LstmK2 pp) {
+    T2_CHAIN_PRIO();
     __shared__ float red[4 * MT * 256];
     const bool stamp = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && g_t2_clk_enable;
     if (stamp) { g_t2_clk[0] = __builtin_amdgcn_s_memtime(); g_t2_clk[1] = __builtin_amdgcn_s_memrealtime(); }
@@ -225,6 +226,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // forward gets 6 ms slower.)
 template <int MT>
 __global__ __launch_bounds__(256, 1) void lstm_seq_persist_fwd_kernel(PersistK pp) {
+    T2_CHAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) float plds[];
     const LstmK& p = pp.s;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -463,6 +465,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(BwdK2 pp) {
 // Fast path of the backward step: ONE contiguous gradient row block dg[b][0:K) (K = N4 + N2) against the packed,
 // zero-padded transposed weight stream; same branch-free double-buffered structure as the forward fast path.
 __global__ __launch_bounds__(256, 1) void lstm_step_bwd_fast_kernel(BwdK2 pp) {
+    T2_CHAIN_PRIO();
     __shared__ float red[4 * 256];
     t2_lstm_bwd_fast_body<4, 4>(pp.s[blockIdx.z], blockIdx.x, blockIdx.y, red);
 }
