@@ -175,7 +175,7 @@ def main():
     # secondary metric of BASELINE.json ("decode steps/sec"): batched autoregressive inference, 64 utterances (configs[4]),
     # fixed 860 frames with the stop checks live (random weights never emit a stop), rank 0 only, outside the timed region
     decode = None
-    if rank == 0 and not args.no_decode:
+    if rank == 0 and world == 1 and not args.no_decode:      # (reported by the N = 1 run only: the other ranks would idle)
         ib = ljspeech_batch(64, seed=4321, num_speakers=4)
         eng = tr.engine
         ci, cl, spk = ib["chars_idx"].to(dev), ib["chars_idx_len"].to(dev), ib["speaker_id"].to(dev)
@@ -241,6 +241,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(dims, cpu_batch, t_cap=400, b_cap=32)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()                       # every rank leaves together
         dist.destroy_process_group()
 
 
