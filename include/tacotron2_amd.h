@@ -64,6 +64,10 @@ typedef struct {
     int native_fp32;                 /* 0 (default): fp32 result on the bf16 matrix pipe by error-free 3-way operand splitting
                                         (6 exact bf16 products per element pair, two fp32 accumulators; csrc/t2_gemm.hip);
                                         1: v_mfma_f32_32x32x2_f32 (f32-input MFMA, 1/16 of the bf16 rate) */
+    int precision;                   /* the reference's training.float32_matmul_precision (run/train.py:170), split kernel only:
+                                        0 = "highest" (default): six bf16 products per element pair, fp32-exact operands;
+                                        1 = "high": three products (a1b1 + a1b2 + a2b1, "bf16x3" in torch's terms, ~16
+                                            significand bits); 2 = "medium": one bf16 product */
 } T2Gemm;
 int t2_gemm(const T2Gemm* g, void* stream);
 

@@ -295,15 +295,16 @@ __device__ __forceinline__ void split_stage_load(f32x4 (&reg)[2], const float* _
 }
 
 // split register j of a staged tile and store its three planes (one "unit": ~22 VALU + 3 ds_write_b64)
-template <bool KMAJ>
+// NP = number of planes kept: 3 (six products, fp32-exact operands), 2 (three products: torch's "high" = bf16x3), 1 (bf16)
+template <bool KMAJ, int NP>
 __device__ __forceinline__ void split_store_unit(const f32x4 v, char* op, int tid, int j) {
     const int idx = tid + 256 * j;
-    const Split3 s = split3(v);
+    const Split3 s = split3(v);          // (unused planes are dead code after inlining)
     const int off = KMAJ ? (idx >> 2) * KM_ROW + (idx & 3) * 8 : (idx >> 5) * MM_ROW + (idx & 31) * 8;
     constexpr int PL = KMAJ ? KM_PLANE : MM_PLANE;
     *reinterpret_cast<uint2*>(op + off) = s.h;
-    *reinterpret_cast<uint2*>(op + PL + off) = s.m;
-    *reinterpret_cast<uint2*>(op + 2 * PL + off) = s.l;
+    if (NP >= 2) *reinterpret_cast<uint2*>(op + PL + off) = s.m;
+    if (NP >= 3) *reinterpret_cast<uint2*>(op + 2 * PL + off) = s.l;
 }
 
 // fragment of plane `pl` for the 32-row MFMA tile starting at tile row r0: element j = k offset 8*(lane>>5) + j
@@ -318,7 +319,7 @@ __device__ __forceinline__ bf16x8 split_frag(const char* op, int pl, int r0, int
         const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0));
         const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a0 + 4 * MM_ROW));
         // (whole-vector bit casts: element-wise bit_cast of the transposed read's result is miscompiled by ROCm 7.2's hipcc -
-        // element 0 is splatted into all four - tools/probe_mm.hip)
+        // element 0 is splatted into all four - tools/probe_tr16.hip)
         return __builtin_shufflevector(__builtin_bit_cast(bf16x4, t0), __builtin_bit_cast(bf16x4, t1), 0, 1, 2, 3, 4, 5, 6, 7);
     }
 }
@@ -329,7 +330,7 @@ __device__ __forceinline__ bf16x8 split_frag(const char* op, int pl, int r0, int
 // MFMAs (a 32x32x16 MFMA occupies the matrix pipe for 32 cycles and the issue port for 8).
 #define T2_SPLIT_MFMA(ACC, I, J, PA, PB) ACC[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[I][PA], fb[J][PB], ACC[I][J], 0, 0, 0)
 
-template <bool AK, bool BKM>
+template <bool AK, bool BKM, int NP>
 __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(GemmK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 * STAGE_BYTES
     const int tid = threadIdx.x;
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(GemmK p) {
     // prologue: tile kt0 -> LDS stage 0, tile kt0+1 -> register set (ra, rb)
     load_tile(ra, rb, kt0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { split_store_unit<AK>(ra[j], smem, tid, j); split_store_unit<BKM>(rb[j], smem + OP_BYTES, tid, j); }
+    for (int j = 0; j < 2; ++j) { split_store_unit<AK, NP>(ra[j], smem, tid, j); split_store_unit<BKM, NP>(rb[j], smem + OP_BYTES, tid, j); }
     if (kt0 + 1 < kt1) load_tile(ra, rb, kt0 + 1);
     __syncthreads();
 
@@ -399,11 +400,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(GemmK p) {
         const char* Bs = As + OP_BYTES;
         char* An = smem + (cur ^ 1) * STAGE_BYTES;
         if (kt + 2 < kt1) load_tile(ya, yb, kt + 2);
-        bf16x8 fa[2][3], fb[2][3];
+        bf16x8 fa[2][NP], fb[2][NP];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < NP; ++pl) {
                 fa[i][pl] = split_frag<AK>(As, pl, wm * 64 + i * 32, lane);
                 fb[i][pl] = split_frag<BKM>(Bs, pl, wn * 64 + i * 32, lane);
             }
@@ -411,20 +412,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(GemmK p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int i = g >> 1, j = g & 1;
-            T2_SPLIT_MFMA(lo, i, j, 2, 0); T2_SPLIT_MFMA(lo, i, j, 0, 2); T2_SPLIT_MFMA(lo, i, j, 1, 1);
+            if constexpr (NP == 3) { T2_SPLIT_MFMA(lo, i, j, 2, 0); T2_SPLIT_MFMA(lo, i, j, 0, 2); T2_SPLIT_MFMA(lo, i, j, 1, 1); }
+            if constexpr (NP == 2) { T2_SPLIT_MFMA(lo, i, j, 1, 0); }
             // (unconditional: on the last tile the registers are stale and the stage they go to is never read)
-            if (g < 2) split_store_unit<AK>(xa[g], An, tid, g); else split_store_unit<BKM>(xb[g - 2], An + OP_BYTES, tid, g - 2);
-            T2_SPLIT_MFMA(lo, i, j, 1, 0); T2_SPLIT_MFMA(lo, i, j, 0, 1); T2_SPLIT_MFMA(hi, i, j, 0, 0);
+            if (g < 2) split_store_unit<AK, NP>(xa[g], An, tid, g); else split_store_unit<BKM, NP>(xb[g - 2], An + OP_BYTES, tid, g - 2);
+            if constexpr (NP == 3) { T2_SPLIT_MFMA(lo, i, j, 1, 0); T2_SPLIT_MFMA(lo, i, j, 0, 1); }
+            if constexpr (NP == 2) { T2_SPLIT_MFMA(lo, i, j, 0, 1); }
+            T2_SPLIT_MFMA(hi, i, j, 0, 0);
         }
-        // order pin, per group of 6 MFMAs + one split unit (22 VALU, 2-3 LDS stores): MFMA, 4 VALU, MFMA, ...
+        // order pin, per group of MFMAs + one split unit (NP = 3: 6 MFMAs, 22 VALU, 3 LDS stores): MFMA, a few VALU, MFMA, ...
+        constexpr int NMF = NP == 3 ? 6 : NP == 2 ? 3 : 1, NVA = NP == 3 ? 4 : NP == 2 ? 5 : 4;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
 #pragma unroll
-            for (int m = 0; m < 6; ++m) {
+            for (int m = 0; m < NMF; ++m) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, NVA, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, NP, 0);
         }
         __syncthreads();     // stage cur^1 is complete, stage cur is free
     };
@@ -447,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(GemmK p) {
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row >= p.M) continue;
-                float v = p.alpha * (hi[i][j][r] + lo[i][j][r]) + badd;
+                float v = p.alpha * (NP == 1 ? hi[i][j][r] : hi[i][j][r] + lo[i][j][r]) + badd;
                 float* cp = C + (long)row * p.ldc + col;
                 if (p.accumulate == 2) {
                     atomicAdd(cp, v);
@@ -490,11 +495,19 @@ extern "C" int t2_gemm(const T2Gemm* g, void* stream) {
     const size_t pad = g->share_cu ? 24 * 1024 : 0;
     if (!g->native_fp32) {
         const size_t lds = 2 * STAGE_BYTES + pad;    // 72 KB: two workgroups per CU (one with the share_cu padding)
-        T2_REQUIRE(t2_allow_lds(gemm_f32_split_bf16<true, true>, lds) && t2_allow_lds(gemm_f32_split_bf16<true, false>, lds) &&
-                   t2_allow_lds(gemm_f32_split_bf16<false, false>, lds), "t2_gemm: LDS budget");
-        if (g->a_kmajor && g->b_kmajor) hipLaunchKernelGGL((gemm_f32_split_bf16<true, true>), grid, block, lds, s, p);
-        else if (g->a_kmajor && !g->b_kmajor) hipLaunchKernelGGL((gemm_f32_split_bf16<true, false>), grid, block, lds, s, p);
-        else hipLaunchKernelGGL((gemm_f32_split_bf16<false, false>), grid, block, lds, s, p);
+        T2_REQUIRE(g->precision >= 0 && g->precision <= 2, "t2_gemm: precision must be 0 (highest), 1 (high) or 2 (medium)");
+#define T2_GEMM_LAUNCH(NP)                                                                                                       \
+        do {                                                                                                                     \
+            T2_REQUIRE(t2_allow_lds(gemm_f32_split_bf16<true, true, NP>, lds) && t2_allow_lds(gemm_f32_split_bf16<true, false, NP>, lds) && \
+                       t2_allow_lds(gemm_f32_split_bf16<false, false, NP>, lds), "t2_gemm: LDS budget");                          \
+            if (g->a_kmajor && g->b_kmajor) hipLaunchKernelGGL((gemm_f32_split_bf16<true, true, NP>), grid, block, lds, s, p);    \
+            else if (g->a_kmajor && !g->b_kmajor) hipLaunchKernelGGL((gemm_f32_split_bf16<true, false, NP>), grid, block, lds, s, p); \
+            else hipLaunchKernelGGL((gemm_f32_split_bf16<false, false, NP>), grid, block, lds, s, p);                             \
+        } while (0)
+        if (g->precision == 0) T2_GEMM_LAUNCH(3);
+        else if (g->precision == 1) T2_GEMM_LAUNCH(2);
+        else T2_GEMM_LAUNCH(1);
+#undef T2_GEMM_LAUNCH
         T2_CHECK_LAUNCH();
         return T2_OK;
     }

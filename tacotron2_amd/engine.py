@@ -33,6 +33,16 @@ SHARE_CU = [0]     # set to [1] while enqueuing GEMMs that run next to a latency
 # rate); 1: f32-input MFMA.  One process-wide switch for A/B measurements and the kernel tests.
 import os as _os
 GEMM_NATIVE_FP32 = [int(_os.environ.get("T2_GEMM_NATIVE_FP32", "0"))]
+# torch.set_float32_matmul_precision of the reference (run/train.py:170, every shipped config says "high"): how many of the bf16
+# partial products the GEMMs issue.  "highest" (default here; what bench.py and the parity tests measure) = fp32-exact operands.
+MATMUL_PRECISION = {"highest": 0, "high": 1, "medium": 2}
+GEMM_PRECISION = [0]
+
+
+def set_float32_matmul_precision(name: str) -> None:
+    if name not in MATMUL_PRECISION:
+        raise ValueError(f"float32_matmul_precision must be one of {sorted(MATMUL_PRECISION)}, got {name!r}")
+    GEMM_PRECISION[0] = MATMUL_PRECISION[name]
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_k=1, b_k=1, alpha=1.0, bias=None, bias2=None, mulmask=None, ldmask=0,
@@ -40,7 +50,7 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_k=1, b_k=1, alpha=1.0, bias=None, bi
     """C-ABI t2_gemm on raw pointers (ints) or tensors."""
     g = make("T2Gemm", A=A, B=B, C=C, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, a_kmajor=a_k, b_kmajor=b_k,
              alpha=alpha, bias=bias, bias2=bias2, mulmask=mulmask, ldmask=ldmask, relu=relu, accumulate=accumulate,
-             splitk=splitk, batch=batch, sA=sA, sB=sB, sC=sC, share_cu=SHARE_CU[0], native_fp32=GEMM_NATIVE_FP32[0])
+             splitk=splitk, batch=batch, sA=sA, sB=sB, sC=sC, share_cu=SHARE_CU[0], native_fp32=GEMM_NATIVE_FP32[0], precision=GEMM_PRECISION[0])
     call("t2_gemm", g, _stream())
 
 

@@ -53,6 +53,10 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
         training_config["lr"] /= 10
         training_config["batch_size"] *= 2
     kw = model_kwargs(cfg)
+    # run/train.py:170: torch.set_float32_matmul_precision(training_config["float32_matmul_precision"]) - here the number of bf16
+    # partial products the GEMM kernel issues ("highest" when the key is absent; every shipped reference config says "high")
+    from ..engine import set_float32_matmul_precision
+    set_float32_matmul_precision(training_config.get("float32_matmul_precision", "highest"))
     max_steps = max_steps_override or training_config["args"]["max_steps"]
     model = TTSModel(device=dev, **kw)
     start_step = 0

@@ -67,6 +67,35 @@ def test_vanilla_dims_train_step_matches_oracle(B, L, T):
     _hip_train_and_compare(d, P, case, dev, kw_cpu=dict(speaker_id=spk), kw_dev=dict(speaker_id=spk.to(dev)))
 
 
+def test_vanilla_dims_train_step_at_matmul_precision_high():
+    """training.float32_matmul_precision = "high" (run/train.py:170; what every shipped reference config sets): the GEMMs issue
+    three of the six bf16 partial products.  Same production-dims step against the fp32 oracle at that precision class: the
+    outputs stay inside the north-star mel tolerance, loss to 1e-4 relative, gradients to 3e-3 of each tensor's scale."""
+    from tacotron2_amd import engine
+    dev = _dev()
+    d = R.default_dims(speaker_tokens=True, num_speakers=4)
+    B, L, T = 3, 32, 16
+    P = R.init_params(d, seed=40 + B)
+    ci, lens, mel, tl, gate, masks = _ragged_case(d, B, L, T, 500 + B, dev)
+    spk = torch.randint(0, 4, (B,), generator=torch.Generator().manual_seed(B), dtype=torch.int32)
+    ref, loss, grads, _ = _oracle_train(P, d, ci, lens, mel, tl, gate, masks, speaker_id=spk)
+    try:
+        engine.set_float32_matmul_precision("high")
+        eng, ps = build_engine(d, P, dev)
+        outs, ctx = eng.forward_tf(ci.to(dev), lens.to(dev), mel.to(dev), tl.to(dev), training=True,
+                                   masks=masks_to_device(masks, dev), speaker_id=spk.to(dev))
+        ps.grad.zero_()
+        loss3 = eng.loss_and_grads(outs, ctx, mel.to(dev), gate.to(dev))
+        torch.cuda.synchronize()
+    finally:
+        engine.set_float32_matmul_precision("highest")
+    e0, e1 = l1(outs[0], ref[0]), l1(outs[1], ref[1])
+    print(f"matmul precision high: mel L1 {e0:.2e} / {e1:.2e}, loss rel {abs(float(loss3.sum()) - loss) / abs(loss):.2e}")
+    assert e0 < MEL_L1_TOL and e1 < MEL_L1_TOL, (e0, e1)
+    assert abs(float(loss3.sum()) - loss) < 1e-4 * max(1.0, abs(loss))
+    _grad_check(ps, grads, tol=3e-3)
+
+
 def test_descriptions_libritts_dims_train_step_matches_oracle():
     """configs[3] dims: description embeddings (768 -> 128, E' = 640) + 562 speaker tokens."""
     dev = _dev()

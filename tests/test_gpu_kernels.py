@@ -33,6 +33,37 @@ def gemm_kernel(request):
 
 
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+def test_gemm_matmul_precision_levels(dev, layout):
+    """T2Gemm.precision = the reference's float32_matmul_precision (run/train.py:170): "highest" keeps all six bf16 partial
+    products (fp32-exact operands), "high" three (torch's bf16x3: ~16 significand bits), "medium" one (bf16 operands).  Each
+    level is held to its own error class against float64, and the levels must be ordered."""
+    from tacotron2_amd import engine
+    from tacotron2_amd.engine import gemm
+    M, N, K = 300, 260, 1000
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(K, N, generator=g)
+    ref = (A.double() @ B.double())
+    a_k, b_k = {"nt": (1, 1), "nn": (1, 0), "tn": (0, 0)}[layout]
+    Ad = (A if a_k else A.t().contiguous()).to(dev)
+    Bd = (B.t().contiguous() if b_k else B).to(dev)
+    errs = {}
+    try:
+        for name in ("highest", "high", "medium"):
+            engine.set_float32_matmul_precision(name)
+            C = torch.full((M, N), float("nan"), device=dev)
+            gemm(Ad, Bd, C, M, N, K, Ad.shape[1], Bd.shape[1], N, a_k=a_k, b_k=b_k)
+            torch.cuda.synchronize()
+            errs[name] = _rel(C, ref)
+    finally:
+        engine.set_float32_matmul_precision("highest")
+    assert errs["highest"] < 2e-6 and errs["high"] < 5e-5 and errs["medium"] < 2e-2, errs
+    assert errs["highest"] < errs["high"] < errs["medium"], errs
+    with pytest.raises(ValueError):
+        engine.set_float32_matmul_precision("lowest")
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
 @pytest.mark.parametrize("shape", [(128, 128, 32), (200, 150, 72), (37, 300, 70), (1000, 81, 1536), (260, 4096, 96), (5, 3, 7)])
 def test_gemm_layouts(dev, gemm_kernel, layout, shape):
     from tacotron2_amd.engine import gemm

@@ -1,7 +1,8 @@
 """Standalone throughput of t2_gemm on the shapes of one training step (GPU box only)."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tacotron2_amd.engine import gemm, splitk_for
+from tacotron2_amd.engine import gemm, splitk_for, set_float32_matmul_precision
+set_float32_matmul_precision(os.environ.get("T2_MATMUL_PRECISION", "highest"))     # "high": three of the six bf16 products
 
 dev = torch.device("cuda:0")
 
