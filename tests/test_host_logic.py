@@ -107,3 +107,39 @@ def test_length_bucket_sampler_covers_every_utterance_and_cuts_padding():
     perm = rng.permutation(4000).tolist()
     random_batches = [perm[i:i + 32] for i in range(0, 4000, 32)]
     assert ratio(random_batches) > 1.45 and ratio(e1) < 1.12, (ratio(random_batches), ratio(e1))
+
+
+def test_mel_filterbank_known_answers_of_the_slaney_scale():
+    """The product's mel filterbank (tacotron2_amd/datasets/logmel.py) against facts that do not come from its own formula or
+    from oracle/logmel_ref.py (which restates the same definition): the published constants of the Slaney / Auditory-Toolbox
+    scale that torchaudio's mel_scale="slaney" implements (linear below 1 kHz at 200/3 Hz per mel, so 1 kHz = mel 15; above it
+    27 mels per factor 6.4) and the properties of norm="slaney" triangles (unit area, peak at the centre frequency, support
+    between the neighbouring centres).  The reference's own numbers stay unpinned (speech_utils / torchaudio absent)."""
+    import math
+    from tacotron2_amd.datasets.logmel import TacotronMelSpectrogram
+    fe = TacotronMelSpectrogram(device="cpu")
+    nb = 513
+    fb = fe.fb[:, :nb].double().numpy()
+    assert fb.shape == (80, nb) and float(fe.fb[:, nb:].abs().max()) == 0.0 and (fb >= 0).all()
+    df = 11025.0 / (nb - 1)                                   # torchaudio: all_freqs = linspace(0, sr // 2, n_freqs)
+    freqs = np.arange(nb) * df
+    # centre frequencies from the published scale: 82 points equally spaced in mel between 0 Hz (mel 0) and 8 kHz
+    mel_8k = 15.0 + 27.0 * math.log(8.0) / math.log(6.4)      # = 45.2457...
+    assert abs(mel_8k - 45.2457) < 1e-3
+    m = np.linspace(0.0, mel_8k, 82)
+    f = np.where(m < 15.0, m * 200.0 / 3.0, 1000.0 * np.exp((m - 15.0) * math.log(6.4) / 27.0))
+    assert abs(f[-1] - 8000.0) < 1e-6
+    for k in range(80):
+        lo, c, hi = f[k], f[k + 1], f[k + 2]
+        row = fb[k]
+        nz = np.nonzero(row)[0]
+        assert freqs[nz[0]] > lo - 1e-9 and freqs[nz[-1]] < hi + 1e-9, k            # support between the neighbouring centres
+        assert abs(freqs[int(row.argmax())] - c) <= df, k                            # peak at the centre (to one bin)
+        peak = 2.0 / (hi - lo)                                                       # unit-area triangle of base hi - lo
+        inside = (freqs > lo) & (freqs < hi)
+        tri = np.where(freqs <= c, (freqs - lo) / (c - lo), (hi - freqs) / (hi - c)) * peak
+        assert np.allclose(row[inside], tri[inside], rtol=1e-6, atol=1e-12), k        # exact triangle values at the bins
+    wide = [k for k in range(80) if f[k + 2] - f[k] > 12 * df]
+    areas = fb[wide].sum(1) * df
+    assert len(wide) > 20 and np.abs(areas - 1.0).max() < 0.02                        # unit area once a filter spans enough bins
+    assert float(fb[:, freqs > 8000.0 + df].max()) == 0.0                            # nothing above f_max
