@@ -25,5 +25,5 @@ for rep in range(2):
         dt = (time.perf_counter() - t0) / 8 * 1e3
         tr.engine.profile = False
         seg = tr.engine.segment_times_ms()
-        print(f"co_schedule_bwd={co} chunk_bwd={chunk}: {dt:.2f} ms/step  bwd.dec.chains {seg.get('bwd.dec.chains', 0):.2f}  "
+        print(f"chunk_bwd={chunk}: {dt:.2f} ms/step  bwd.dec.chains {seg.get('bwd.dec.chains', 0):.2f}  "
               f"attn_gemms {seg.get('bwd.dec.attn_gemms', 0):.2f}  bilstm {seg.get('bwd.bilstm', 0):.2f}", flush=True)
