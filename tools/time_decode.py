@@ -1,4 +1,4 @@
-"""Frame-loop time of the autoregressive decode at 64 utterances (GPU box): python tools/time_decode.py [frames]."""
+"""Frame-loop time of the autoregressive decode (GPU box): python tools/time_decode.py [frames] [batch sizes...]."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import VANILLA
@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 ps = ParamStore(VANILLA, dev); init_parameters(ps, 0)
 eng = Engine(ps)
-for B in (64, 32):
+for B in ([int(x) for x in sys.argv[2:]] or [64, 32]):
     ib = ljspeech_batch(B, seed=4321, num_speakers=4)
     ci, cl, spk = ib["chars_idx"].to(dev), ib["chars_idx_len"].to(dev), ib["speaker_id"].to(dev)
     eng.infer(ci, cl, 32, speaker_id=spk, training=False, seed=1)
