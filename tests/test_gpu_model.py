@@ -384,9 +384,9 @@ def test_edge_shapes_match_oracle(B, L, T, lens, tls):
     assert torch.isfinite(ps.grad).all() and torch.isfinite(loss3).all()
 
 
-@pytest.mark.parametrize("L", [300, 700])
+@pytest.mark.parametrize("L", [300, 700, 768])
 def test_long_text_forward_backward_match_oracle(L):
-    """Texts longer than one 256-position round of the attention kernels (and, at 700, dynamic LDS above 64 KB): outputs
+    """Texts longer than one 256-position round of the attention kernels (at 700 dynamic LDS above 64 KB; 768 = the maximum): outputs
     and every parameter gradient against the CPU oracle."""
     dev = _dev()
     d = R.default_dims(num_chars=39, encoded_dim=64, prenet_dim=32, att_rnn_dim=64, att_dim=32, rnn_hidden_dim=64,
