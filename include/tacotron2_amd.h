@@ -126,10 +126,12 @@ int t2_lstm_seq_fwd(const T2LstmStep* base, const T2LstmStride* inc, int n, int 
 /* The same S steps of ONE cell as ONE persistent, weight-stationary launch (csrc/t2_lstm.hip): every workgroup keeps its
  * weight slice in LDS and the workgroups exchange h_s through the x16-tiled stash (write-through stores, sharded arrival
  * counters, sc1 loads), so the launch can run on its own stream next to other work without streaming weights every step.
- * Needs: packed single-segment path with K = H, `pre` (hoisted input projection), B <= 32, H/4 <= 256 workgroups,
- * base->ht_out == base->xt + inc->xt (step s+1 reads the tiled h of step s), inc->xt == inc->ht_out.
- * sync: >= 272 device words of scratch (zeroed by the call); sync[256] != 0 afterwards = a wait timed out (bounded spins:
- * the launch then ends early, its outputs are unusable). */
+ * Needs: packed single-segment path with K = H, `pre` (hoisted input projection), B <= 64 (rows are independent: blocks of
+ * 32 rows run as consecutive launches), H/4 <= 256 workgroups, base->ht_out == base->xt + inc->xt (step s+1 reads the tiled h
+ * of step s), inc->xt == inc->ht_out.
+ * sync: >= 272 device words of scratch; words [0, 256) are the arrival counters (zeroed by every launch), word 256 is the
+ * timeout flag: zeroed by the CALLER before first use and sticky - a wait that timed out (bounded spins) sets it, every launch
+ * that sees it ends early (outputs unusable) until the caller has read and cleared it. */
 int t2_lstm_seq_fwd_persist(const T2LstmStep* base, const T2LstmStride* inc, int S, uint32_t* sync, void* stream);
 /* One step of back-propagation through time for an LSTM cell (autograd of the cells above):
  *   dx[b][u] = sum_n dg_next[b][n] * W[n*ldw + u]          (n over N4 = 4H' rows of the producing cell)

@@ -604,25 +604,29 @@ extern "C" int t2_lstm_seq_fwd_persist(const T2LstmStep* base, const T2LstmStrid
     if (S == 0) return T2_OK;
     T2_TRY(t2_lstm_check_step(*base));
     const T2LstmStep& b = *base;
-    T2_REQUIRE(b.wpacked && b.nseg == 1 && b.xt && b.ht_out && b.B <= 32 && b.pre && b.H % 4 == 0,
-               "t2_lstm_seq_fwd_persist: needs the packed single-segment path with x16-tiled h exchange and B <= 32");
+    T2_REQUIRE(b.wpacked && b.nseg == 1 && b.xt && b.ht_out && b.B <= 64 && b.pre && b.H % 4 == 0,
+               "t2_lstm_seq_fwd_persist: needs the packed single-segment path with x16-tiled h exchange and B <= 64");
     T2_REQUIRE(b.seg[0].K == b.H && b.ht_col0 == 0 && inc->xt == inc->ht_out && b.ht_out == b.xt + inc->xt,
                "t2_lstm_seq_fwd_persist: the input of step s+1 must be the tiled h of step s (K = H)");
     T2_REQUIRE(b.H / 4 <= 256 && !b.h_out2, "t2_lstm_seq_fwd_persist: at most 256 workgroups (one per CU), no second h copy");
-    const int MT = b.B <= 16 ? 1 : 2;
     const int NT = b.seg[0].K >> 4, NTpad = (NT + 15) & ~15;
-    const size_t lds = ((size_t)NTpad * 256 + (size_t)4 * MT * 256 + 4) * sizeof(float);
+    const size_t lds = ((size_t)NTpad * 256 + (size_t)4 * 2 * 256 + 4) * sizeof(float);
     T2_REQUIRE(t2_allow_lds(lstm_seq_persist_fwd_kernel<1>, lds) && t2_allow_lds(lstm_seq_persist_fwd_kernel<2>, lds),
                "t2_lstm_seq_fwd_persist: weight slice does not fit the LDS");
-    PersistK k;
-    t2_lstm_to_k(b, k.s, 0, b.B);
-    k.i_pre = inc->pre; k.i_drop = inc->drop; k.i_h_out = inc->h_out; k.i_c_out = inc->c_out; k.i_gates = inc->gates_out;
-    k.i_xt = inc->xt; k.i_ht = inc->ht_out; k.i_dt = inc->dt; k.steps = S; k.sync = sync; k.spin_limit = 1 << 21;
     hipStream_t st = (hipStream_t)stream;
-    (void)hipMemsetAsync(sync, 0, 17 * 16 * sizeof(uint32_t), st);
-    dim3 grid(b.H / 4), block(256);
-    if (MT == 1) hipLaunchKernelGGL((lstm_seq_persist_fwd_kernel<1>), grid, block, lds, st, k);
-    else hipLaunchKernelGGL((lstm_seq_persist_fwd_kernel<2>), grid, block, lds, st, k);
+    // Rows are independent: blocks of up to 32 rows (two 16-row tiles) run as consecutive launches of the same chunk.  Each
+    // launch zeroes the arrival counters; the timeout flag (word 256) is sticky - only the host clears it.
+    for (int b0 = 0; b0 < b.B; b0 += 32) {
+        const int bn = (b.B - b0) < 32 ? (b.B - b0) : 32;
+        PersistK k;
+        t2_lstm_to_k(b, k.s, b0, bn);
+        k.i_pre = inc->pre; k.i_drop = inc->drop; k.i_h_out = inc->h_out; k.i_c_out = inc->c_out; k.i_gates = inc->gates_out;
+        k.i_xt = inc->xt; k.i_ht = inc->ht_out; k.i_dt = inc->dt; k.steps = S; k.sync = sync; k.spin_limit = 1 << 21;
+        (void)hipMemsetAsync(sync, 0, 16 * 16 * sizeof(uint32_t), st);
+        dim3 grid(b.H / 4), block(256);
+        if (bn <= 16) hipLaunchKernelGGL((lstm_seq_persist_fwd_kernel<1>), grid, block, lds, st, k);
+        else hipLaunchKernelGGL((lstm_seq_persist_fwd_kernel<2>), grid, block, lds, st, k);
+    }
     T2_CHECK_LAUNCH();
     return T2_OK;
 }

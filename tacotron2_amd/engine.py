@@ -102,6 +102,7 @@ class Engine:
         """Host-synchronising check of the persistent launches' timeout flag (bounded spins end the launch early instead of
         hanging): raises if a wait timed out.  Tests and the bench call it after a step."""
         if self._persist_sync is not None and int(self._persist_sync[256].item()) != 0:
+            self._persist_sync[256:272].zero_()       # the flag is sticky on the device: cleared here, reported once
             raise _lib.T2Error("t2_lstm_seq_fwd_persist: an inter-workgroup wait timed out (outputs of that forward are invalid)")
 
     def side_stream(self):
@@ -449,13 +450,14 @@ class Engine:
         import ctypes as _C
         chunks = [(c0, min(T, c0 + CH)) for c0 in range(0, T, CH)]
         co = B <= 32 and self.dec_chain == "hosted"     # the hosted cell needs <= 32 rows (register budget of the host kernel)
-        persist = B <= 32 and self.dec_chain == "persistent" and D // 4 <= 256
+        persist = B <= 64 and self.dec_chain == "persistent" and D // 4 <= 256
         if persist:
             # The decoder-LSTM chain of a chunk as ONE persistent, weight-stationary launch on the side stream
             # (t2_lstm_seq_fwd_persist): W_hh stays in LDS, the workgroups exchange h through the tiled stash, and the
             # attention chain on the main stream runs without hosted cells (energies launch 11 -> 7.5 us per frame).
-            sync = self.buf("persist.sync", 320, dtype=torch.int32)
-            self._persist_sync = sync
+            if self._persist_sync is None:
+                self._persist_sync = torch.zeros(320, dtype=torch.int32, device=self.dev)   # (word 256: sticky timeout flag)
+            sync = self._persist_sync
             for i, (c0, c1) in enumerate(chunks):
                 seq.t_begin, seq.t_end = c0, c1
                 seq.co_step, seq.co_inc, seq.co_steps = None, None, 0

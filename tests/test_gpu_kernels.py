@@ -265,10 +265,11 @@ def test_lstm_step_fwd_packed_tiled(dev, B, H, Ks, col0):
     assert torch.equal(h2, h)
 
 
-@pytest.mark.parametrize("B,H,S", [(32, 1024, 9), (5, 64, 6), (17, 128, 4)])
+@pytest.mark.parametrize("B,H,S", [(32, 1024, 9), (5, 64, 6), (17, 128, 4), (64, 1024, 5), (35, 128, 4)])
 def test_lstm_seq_fwd_persistent_matches_step_launches(dev, B, H, S):
     """t2_lstm_seq_fwd_persist (ONE weight-stationary launch, workgroups exchanging h through the tiled stash) against the same
-    S steps as dependent launches (t2_lstm_seq_fwd) and against float64; the timeout flag must stay clear."""
+    S steps as dependent launches (t2_lstm_seq_fwd) and against float64; the timeout flag must stay clear.  Above 32 rows the
+    call runs one launch per block of 32 rows (B = 64: two full blocks; B = 35: a 32-row and a 3-row block)."""
     from tacotron2_amd import _lib
     g = torch.Generator().manual_seed(B + H + S)
     Bp = (B + 15) // 16 * 16
@@ -307,7 +308,8 @@ def test_lstm_seq_fwd_persistent_matches_step_launches(dev, B, H, S):
         if mode == "launches":
             _lib.call("t2_lstm_seq_fwd", stp, inc, 1, S, st)
         else:
-            sync = torch.full((320,), 7, dtype=torch.int32, device=dev)         # the call must zero what it polls
+            sync = torch.full((320,), 7, dtype=torch.int32, device=dev)         # the call must zero what it polls ...
+            sync[256:272] = 0                                                   # ... the sticky timeout flag is the caller's
             _lib.call("t2_lstm_seq_fwd_persist", stp, inc, S, sync, st)
             torch.cuda.synchronize()
             assert int(sync[256]) == 0, "an inter-workgroup wait timed out"
