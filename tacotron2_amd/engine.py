@@ -74,6 +74,17 @@ def splitk_for(M: int, N: int, K: int) -> int:
     return best
 
 
+def _chunk_sizes(T: int, CH: int, ramp_at_end: bool = True):
+    """Frame counts of the pipeline chunks in time order: CH each, and - with the ramp - the last CH frames as CH/2, CH/4, CH/8,
+    CH/8 (so the pipeline's fill / drain, which is not overlapped, is an eighth of a chunk)."""
+    if not ramp_at_end or CH < 16 or T <= CH:
+        return [min(CH, T - c0) for c0 in range(0, T, CH)]
+    tail = [CH // 2, CH // 4, CH // 8, CH - CH // 2 - CH // 4 - CH // 8]
+    body = T - CH
+    sizes = [min(CH, body - c0) for c0 in range(0, body, CH)]
+    return sizes + tail
+
+
 class Engine:
     """Forward/backward of the whole model on one device.  `ps` is the ParamStore."""
 
@@ -90,6 +101,7 @@ class Engine:
         self.persist_gemm_side = True    # the hoisted pre_dec GEMM of a chunk runs on the side stream too, in front of the chunk's
                                          # persistent launch (70.0 against 71.3 ms per step on the main stream, profiles/r02_ab_fwd_dec_chain.txt)
         self._persist_sync = None
+        self.ramp_chunks = True       # short chunks at the un-overlapped end of the forward / start of the backward pipeline
         self.share_cu = 1             # side-stream GEMMs next to the chains at ONE workgroup per CU: two 73 KB-LDS workgroups
                                       # per CU lock the attention kernels out (84.3 -> 83.2 ms)
         self.sync_bn_group = None     # torch.distributed group: BatchNorm statistics over all ranks' shards (Trainer(sync_bn=True))
@@ -448,7 +460,12 @@ class Engine:
         main, side = torch.cuda.current_stream(), self.side_stream()
         side.wait_stream(main)
         import ctypes as _C
-        chunks = [(c0, min(T, c0 + CH)) for c0 in range(0, T, CH)]
+        # Pipeline chunks; the LAST ones shrink (CH/2, CH/4, CH/8, CH/8): what follows the attention chain's end on the side stream
+        # (the decoder-LSTM frames of the final chunk) is exposed time, proportional to that chunk's length.
+        sizes = _chunk_sizes(T, CH, ramp_at_end=self.ramp_chunks)
+        chunks, c0 = [], 0
+        for n in sizes:
+            chunks.append((c0, c0 + n)); c0 += n
         co = B <= 32 and self.dec_chain == "hosted"     # the hosted cell needs <= 32 rows (register budget of the host kernel)
         persist = B <= 64 and self.dec_chain == "persistent" and D // 4 <= 256
         if persist:
@@ -704,7 +721,11 @@ class Engine:
                     self._wgrad(s_dgd, 4 * D, ctl, ctl.shape[1], G["decoder.lstm.weight_ih#controls"], ctl.shape[1], 4 * D,
                                 ctl.shape[1], B)
 
-        chunks = [(hi, max(0, hi - CH)) for hi in range(T, 0, -CH)]
+        # (time-descending) the FIRST chunks are short: the attention chain cannot start before the decoder-LSTM BPTT of its first
+        # chunk and that chunk's GEMM are done on the side stream
+        chunks, hi = [], T
+        for n in reversed(_chunk_sizes(T, CH, ramp_at_end=self.ramp_chunks)):
+            chunks.append((hi, hi - n)); hi -= n
         # Two-stream pipeline: decoder chain of chunk k+1 on the side stream next to the attention chain of chunk k.  Hosting the
         # decoder BPTT steps inside attention launches instead measured slower both ways (inside the ds launch: round 1,
         # profiles/r01_sweep_bwd_chunk_co.txt; as a second operand block of the cell-backward launch: 75.3 against 71.9 ms
