@@ -101,6 +101,7 @@ class Engine:
         self.persist_gemm_side = True    # the hoisted pre_dec GEMM of a chunk runs on the side stream too, in front of the chunk's
                                          # persistent launch (70.0 against 71.3 ms per step on the main stream, profiles/r02_ab_fwd_dec_chain.txt)
         self._persist_sync = None
+        self.defer_wgrads = True      # weight-gradient GEMMs of postnet, projection and encoder leave the main stream (-1.4 ms per step)
         self.ramp_chunks = True       # short chunks at the un-overlapped end of the forward / start of the backward pipeline
         self.share_cu = 1             # side-stream GEMMs next to the chains at ONE workgroup per CU: two 73 KB-LDS workgroups
                                       # per CU lock the attention kernels out (84.3 -> 83.2 ms)
@@ -559,7 +560,8 @@ class Engine:
         """Cgrad[Mout, Nin] += dY[R, Mout]^T @ X[R, Nin]  (split-K, fp32 atomics into the zero-initialised grad buffer)."""
         gemm(dY, X, Cgrad, Mout, Nin, R, ldy, ldx, ldc, a_k=0, b_k=0, accumulate=2, splitk=splitk_for(Mout, Nin, R))
 
-    def conv_bn_bwd(self, tag, ctx, dy, Lp_dy, pad_dy, w, gw, gbias, bn_prefix, B, L, Ci, Co, act, training, need_dx=True):
+    def conv_bn_bwd(self, tag, ctx, dy, Lp_dy, pad_dy, w, gw, gbias, bn_prefix, B, L, Ci, Co, act, training, need_dx=True,
+                    defer=None, wgrad_stream=None):
         """Backward of conv_bn_fwd.  dy: gradient w.r.t. the layer output.  Returns dX in shifted rows (B*(L+4), Ci)."""
         P, G = self.ps.P, self.ps.G
         c = ctx[tag]
@@ -582,9 +584,19 @@ class Engine:
         R = B * Lp - 4
         if gbias is not None:
             call("t2_colsum", draw, Co, B * Lp, Co, gbias, st)
-        dwp = self.buf(f"{tag}.dwp", Co, 5 * Ci, zero=True)
-        self._wgrad(_ptr(draw, 2 * Co), Co, c["x_pad"], Ci, dwp, 5 * Ci, Co, 5 * Ci, R)
-        call("t2_unpack_conv_wgrad", dwp, gw, Co, Ci, 5, st)
+        def wgrad():     # not on the critical path: with `defer` it is run later, on whatever stream is current then
+            dwp = self.buf(f"{tag}.dwp", Co, 5 * Ci, zero=True)
+            self._wgrad(_ptr(draw, 2 * Co), Co, c["x_pad"], Ci, dwp, 5 * Ci, Co, 5 * Ci, R)
+            call("t2_unpack_conv_wgrad", dwp, gw, Co, Ci, 5, _stream())
+        if defer is not None:
+            defer.append(wgrad)
+        elif wgrad_stream is not None:      # at once, but on another stream (behind everything enqueued here so far)
+            ev = torch.cuda.current_stream().record_event()
+            with torch.cuda.stream(wgrad_stream):
+                wgrad_stream.wait_event(ev)
+                wgrad()
+        else:
+            wgrad()
         if not need_dx:
             return None
         wf = self.buf(f"{tag}.wf", Ci, 5 * Co)
@@ -615,11 +627,15 @@ class Engine:
         # ---- postnet --------------------------------------------------------------------------------
         chans = [M, Pn, Pn, Pn, Pn, M]
         dy, Lp_dy = d_post, T
+        # the five weight-gradient GEMMs of the postnet (1.5 ms) leave the critical path: they run on the side stream between the
+        # chunks of the backward frame loop, where the decoder-LSTM chain has slack
+        post_wgrads = [] if self.defer_wgrads else None
         for li in range(4, -1, -1):
             dy = self.conv_bn_bwd(f"post.conv{li}", ctx, dy, Lp_dy, 0, P[f"postnet.postnet.{4 * li}.weight"],
                                   G[f"postnet.postnet.{4 * li}.weight"], None, f"postnet.postnet.{4 * li + 1}", B, T,
-                                  chans[li], chans[li + 1], 0 if li == 4 else 2, training)
+                                  chans[li], chans[li + 1], 0 if li == 4 else 2, training, defer=post_wgrads)
             Lp_dy = T + 4
+        post_wgrads = post_wgrads or []
         call("t2_finalize_bwd", dy, dproj, B, T, M, st)
         self.mark("bwd.postnet")
 
@@ -628,15 +644,21 @@ class Engine:
         wproj = ps.cat_view("decoder.mel_out.weight", M + 1, ldp)
         dxproj = self.buf("dxproj", T, B, ldp)
         gemm(dproj, wproj, dxproj, R, ldp, M + 1, M + 1, ldp, ldp, a_k=1, b_k=0)
-        self._wgrad(dproj, M + 1, _ptr(xproj, B * ldp), ldp, ps.cat_view("decoder.mel_out.weight", M + 1, ldp, grad=True),
-                    ldp, M + 1, ldp, R)
-        call("t2_colsum", dproj, M + 1, R, M + 1, ps.cat_view("decoder.mel_out.bias", M + 1, 0, grad=True), st)
         ctl = ctx.get("controls")
-        if ctl is not None:       # controls columns: sum the gradient over frames per utterance, then (M, B) x (B, C)
-            C = ctl.shape[1]
-            s_proj = self.buf("ctl.dproj_sum", B, M + 1, zero=True)
-            call("t2_colsum", dproj, B * (M + 1), T, B * (M + 1), s_proj, st)
-            self._wgrad(s_proj, M + 1, ctl, C, G["decoder.mel_out.weight#controls"], C, M, C, B)
+
+        def proj_wgrads():       # weight / bias gradients of the projection: off the critical path (deferred with the postnet's)
+            self._wgrad(dproj, M + 1, _ptr(xproj, B * ldp), ldp, ps.cat_view("decoder.mel_out.weight", M + 1, ldp, grad=True),
+                        ldp, M + 1, ldp, R)
+            call("t2_colsum", dproj, M + 1, R, M + 1, ps.cat_view("decoder.mel_out.bias", M + 1, 0, grad=True), _stream())
+            if ctl is not None:       # controls columns: sum the gradient over frames per utterance, then (M, B) x (B, C)
+                C = ctl.shape[1]
+                s_proj = self.buf("ctl.dproj_sum", B, M + 1, zero=True)
+                call("t2_colsum", dproj, B * (M + 1), T, B * (M + 1), s_proj, _stream())
+                self._wgrad(s_proj, M + 1, ctl, C, G["decoder.mel_out.weight#controls"], C, M, C, B)
+        if self.defer_wgrads:
+            post_wgrads.append(proj_wgrads)
+        else:
+            proj_wgrads()
 
         # ---- both recurrences, back-propagation through time, as a two-stream pipeline over chunks of frames -----------
         # side stream: decoder-LSTM BPTT of chunk k (1 launch / frame) + the GEMM that turns its gate gradients into
@@ -730,15 +752,22 @@ class Engine:
         # decoder BPTT steps inside attention launches instead measured slower both ways (inside the ds launch: round 1,
         # profiles/r01_sweep_bwd_chunk_co.txt; as a second operand block of the cell-backward launch: 75.3 against 71.9 ms
         # per step, profiles/r02_ab_bwd_schedule.txt) - those launches end when the hosted K = 4096 step ends.
-        for hi, lo in chunks:
+        for ci_, (hi, lo) in enumerate(chunks):
             with torch.cuda.stream(side):
                 s, inc = dec_bwd_chunk(hi, lo)
                 call("t2_lstm_seq_bwd", s, inc, 1, hi - lo, side.cuda_stream)
                 dxdec_gemm(hi, lo, self.share_cu)
                 ev = side.record_event()
+                if post_wgrads and ci_ >= 4:        # behind the event: the attention chain does not wait for it
+                    SHARE_CU[0] = self.share_cu
+                    post_wgrads.pop(0)()
+                    SHARE_CU[0] = 0
             main.wait_event(ev)
             sb.t_hi, sb.t_lo = hi, lo
             call("t2_attn_seq_bwd", sb, st)
+        with torch.cuda.stream(side):
+            while post_wgrads:                      # (short sequences: fewer chunks than deferred GEMMs)
+                post_wgrads.pop(0)()
         dec_wgrads()
         self.mark("bwd.dec.chains")
 
@@ -832,15 +861,25 @@ class Engine:
             ic.dg = sg * B * 4 * H; ic.dg2 = sg * 8 * H; ic.ext1 = sg * E; ic.gates = sg * B * 4 * H
             ic.c_prev = sg * B * H; ic.c_cur = sg * B * H; ic.dt = sg
         call("t2_lstm_seq_bwd", steps, incs, 2, S, st)
-        for dr in range(2):
-            nm = "encoder.lstm.weight_hh_l0" + ("" if dr == 0 else "_reverse")
-            hprev = hs[0, 0] if dr == 0 else hs[1, 1]
-            self._wgrad(_ptr(dgt[dr, 0 if dr == 0 else 1]), 4 * H, hprev, H, G[nm], H, 4 * H, H, S * B)
         Rr = B * Lp - 4
         x3 = e["x3"]
-        self._wgrad(dpre, 8 * H, _ptr(x3, 2 * E), E, ps.cat_view("encoder.lstm.weight_ih_l0", 8 * H, E, grad=True), E, 8 * H, E, Rr)
-        call("t2_colsum", dpre, 8 * H, B * Lp, 8 * H, ps.cat_view("encoder.lstm.bias_ih_l0", 8 * H, 0, grad=True), st)
-        call("t2_colsum", dpre, 8 * H, B * Lp, 8 * H, ps.cat_view("encoder.lstm.bias_hh_l0", 8 * H, 0, grad=True), st)
+
+        def bilstm_wgrads():
+            for dr in range(2):
+                nm = "encoder.lstm.weight_hh_l0" + ("" if dr == 0 else "_reverse")
+                hprev = hs[0, 0] if dr == 0 else hs[1, 1]
+                self._wgrad(_ptr(dgt[dr, 0 if dr == 0 else 1]), 4 * H, hprev, H, G[nm], H, 4 * H, H, S * B)
+            self._wgrad(dpre, 8 * H, _ptr(x3, 2 * E), E, ps.cat_view("encoder.lstm.weight_ih_l0", 8 * H, E, grad=True), E, 8 * H, E, Rr)
+            call("t2_colsum", dpre, 8 * H, B * Lp, 8 * H, ps.cat_view("encoder.lstm.bias_ih_l0", 8 * H, 0, grad=True), _stream())
+            call("t2_colsum", dpre, 8 * H, B * Lp, 8 * H, ps.cat_view("encoder.lstm.bias_hh_l0", 8 * H, 0, grad=True), _stream())
+        enc_wgrad_stream = side if self.defer_wgrads else None
+        if enc_wgrad_stream is not None:     # the encoder's weight gradients leave the main stream too (it keeps the dgrad chain)
+            ev = main.record_event()
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                bilstm_wgrads()
+        else:
+            bilstm_wgrads()
         dx = self.buf("enc.dx3", B * Lp, E)
         gemm(dpre, ps.cat_view("encoder.lstm.weight_ih_l0", 8 * H, E), dx, Rr, E, 8 * H, 8 * H, E, E, a_k=1, b_k=0)
 
@@ -849,7 +888,7 @@ class Engine:
         for li, i in reversed(list(enumerate((0, 4, 8)))):
             dx = self.conv_bn_bwd(f"enc.conv{li}", ctx, dx, Lp, 0, P[f"encoder.convolutions.{i}.weight"],
                                   G[f"encoder.convolutions.{i}.weight"], G[f"encoder.convolutions.{i}.bias"],
-                                  f"encoder.convolutions.{i + 1}", B, L, E, E, 1, training)
+                                  f"encoder.convolutions.{i + 1}", B, L, E, E, 1, training, wgrad_stream=enc_wgrad_stream)
         call("t2_embedding_bwd", ctx["chars_idx"], dx, G["encoder.embedding.weight"], B, L, E, Lp, 0, st)
         torch.cuda.current_stream().wait_stream(self.side_stream())
         self.mark("bwd.encoder_convs")

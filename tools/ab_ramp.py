@@ -1,4 +1,4 @@
-"""A/B on the bench batch (GPU box): pipeline chunks of equal size against chunks that shrink towards the un-overlapped end."""
+"""A/B of one boolean engine attribute on the bench batch (GPU box): python tools/ab_ramp.py [attribute, default ramp_chunks]."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import VANILLA
@@ -10,9 +10,10 @@ dev = torch.device("cuda:0")
 ps = ParamStore(VANILLA, dev); init_parameters(ps, 0)
 tr = Trainer(ps, lr=1e-3, weight_decay=1e-6)
 batch = {k: v.to(dev) for k, v in ljspeech_batch(32, seed=1234, num_speakers=4).items()}
+ATTR = sys.argv[1] if len(sys.argv) > 1 else "ramp_chunks"
 for rep in range(3):
     for ramp in (True, False):
-        tr.engine.ramp_chunks = ramp
+        setattr(tr.engine, ATTR, ramp)
         for _ in range(3):
             tr.train_step(batch)
         torch.cuda.synchronize()
@@ -25,5 +26,5 @@ for rep in range(3):
         tr.engine.profile = False
         seg = tr.engine.segment_times_ms()
         tr.engine.check_persistent_kernels()
-        print(f"ramp_chunks={ramp}: {dt:.2f} ms/step  fwd chain {seg['fwd.dec.attn_chain']:.2f} tail {seg['fwd.dec.lstm_chain_tail']:.2f}  "
+        print(f"{ATTR}={ramp}: {dt:.2f} ms/step  bwd.postnet {seg['bwd.postnet']:.2f}  bilstm {seg['bwd.bilstm']:.2f}  fwd chain {seg['fwd.dec.attn_chain']:.2f} tail {seg['fwd.dec.lstm_chain_tail']:.2f}  "
               f"bwd chains {seg['bwd.dec.chains']:.2f}", flush=True)
