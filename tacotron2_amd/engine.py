@@ -102,6 +102,8 @@ class Engine:
                                          # persistent launch (70.0 against 71.3 ms per step on the main stream, profiles/r02_ab_fwd_dec_chain.txt)
         self._persist_sync = None
         self.defer_wgrads = True      # weight-gradient GEMMs of postnet, projection and encoder leave the main stream (-1.4 ms per step)
+        self.wgrad_group = 4          # pipeline chunks per weight-gradient GEMM call (profiles/r02_ab_wgrad_pipeline.txt)
+        self.chunk_att_wgrads = True  # attention-chain weight gradients per pipeline chunk, behind the chain, instead of all at its end
         self.ramp_chunks = True       # short chunks at the un-overlapped end of the forward / start of the backward pipeline
         self.share_cu = 1             # side-stream GEMMs next to the chains at ONE workgroup per CU: two 73 KB-LDS workgroups
                                       # per CU lock the attention kernels out (84.3 -> 83.2 ms)
@@ -727,12 +729,18 @@ class Engine:
                  4 * D, ldx, ldx, a_k=1, b_k=0)
             SHARE_CU[0] = 0
 
+        def dec_wgrads_chunk(hi, lo):    # decoder-LSTM weight gradients over frames [lo, hi) (accumulating)
+            n = (hi - lo) * B
+            g0 = _ptr(dgd, lo * B * 4 * D)
+            self._wgrad(g0, 4 * D, _ptr(xdec, (lo + 1) * B * ldx), ldx, G["decoder.lstm.weight_ih"], ldx, 4 * D, ldx, n)
+            self._wgrad(g0, 4 * D, _ptr(xproj, lo * B * ldp), ldp, G["decoder.lstm.weight_hh"], D, 4 * D, D, n)
+
         def dec_wgrads():   # decoder-LSTM weight gradients, on the side stream next to the attention chain's tail
             with torch.cuda.stream(side):
-                SHARE_CU[0] = self.share_cu
-                self._wgrad(dgd, 4 * D, _ptr(xdec, B * ldx), ldx, G["decoder.lstm.weight_ih"], ldx, 4 * D, ldx, R)
-                self._wgrad(dgd, 4 * D, xproj, ldp, G["decoder.lstm.weight_hh"], D, 4 * D, D, R)
-                SHARE_CU[0] = 0
+                if not self.chunk_att_wgrads:
+                    SHARE_CU[0] = self.share_cu
+                    dec_wgrads_chunk(T, 0)
+                    SHARE_CU[0] = 0
                 db = self.buf("db_dec", 4 * D, zero=True)                      # both biases see the same gate gradients
                 call("t2_colsum", dgd, 4 * D, R, 4 * D, db, side.cuda_stream)
                 for nm in ("decoder.lstm.bias_ih", "decoder.lstm.bias_hh"):    # t2_colsum over ONE row = accumulate
@@ -752,22 +760,60 @@ class Engine:
         # decoder BPTT steps inside attention launches instead measured slower both ways (inside the ds launch: round 1,
         # profiles/r01_sweep_bwd_chunk_co.txt; as a second operand block of the cell-backward launch: 75.3 against 71.9 ms
         # per step, profiles/r02_ab_bwd_schedule.txt) - those launches end when the hosted K = 4096 step ends.
+        gWih = G["decoder.att_rnn.weight_ih"]
+
+        def att_wgrads(hi, lo):      # weight gradients of the attention chain over frames [lo, hi) (accumulating: split-K atomics)
+            n = (hi - lo) * B
+            z0 = _ptr(Z, lo * B * ldz)
+            self._wgrad(z0, ldz, _ptr(ctx["p2"], lo * B * Pd), Pd, gWih, Pd + Ef, 4 * A, Pd, n)
+            self._wgrad(z0, ldz, _ptr(xdec, lo * B * ldx + A), ldx, _ptr(gWih, Pd), Pd + Ef, 4 * A, Ef, n)
+            self._wgrad(z0, ldz, _ptr(xdec, lo * B * ldx), ldx, G["decoder.att_rnn.weight_hh"], A, 4 * A, A, n)
+            self._wgrad(_ptr(Z, (lo + 1) * B * ldz + 4 * A), ldz, _ptr(xdec, (lo + 1) * B * ldx), ldx,
+                        G["decoder.attention.query_layer.weight"], A, Ad, A, n)
+        # Weight gradients along the pipeline: frames are handed to the weight-gradient GEMMs in groups of `wgrad_group` chunks
+        # (a longer K per call keeps the split-K GEMMs efficient); ranges are contiguous and time-descending, so a group is one
+        # [lo, hi) range.  dec_*: gate gradients of the decoder-LSTM BPTT (this stream's own output: no wait);  att_*: of the
+        # attention chain (main stream: wait for the event recorded behind the group's last chunk).
+        WG = max(1, int(self.wgrad_group))
+        dec_grp, att_done, att_grp = None, [], None        # [hi, lo, n]; [(hi, lo, event)]; [hi, lo, n, event]
         for ci_, (hi, lo) in enumerate(chunks):
             with torch.cuda.stream(side):
                 s, inc = dec_bwd_chunk(hi, lo)
                 call("t2_lstm_seq_bwd", s, inc, 1, hi - lo, side.cuda_stream)
                 dxdec_gemm(hi, lo, self.share_cu)
                 ev = side.record_event()
-                if post_wgrads and ci_ >= 4:        # behind the event: the attention chain does not wait for it
-                    SHARE_CU[0] = self.share_cu
+                # behind the event (the attention chain does not wait for any of this)
+                SHARE_CU[0] = self.share_cu
+                if self.chunk_att_wgrads:
+                    dec_grp = [hi, lo, 1] if dec_grp is None else [dec_grp[0], lo, dec_grp[2] + 1]
+                    if dec_grp[2] >= WG:
+                        dec_wgrads_chunk(dec_grp[0], dec_grp[1]); dec_grp = None
+                if post_wgrads and ci_ >= 4:
                     post_wgrads.pop(0)()
-                    SHARE_CU[0] = 0
+                if self.chunk_att_wgrads and len(att_done) >= 2:      # chunks the main stream finished two chunks ago
+                    h2, l2, e2 = att_done.pop(0)
+                    att_grp = [h2, l2, 1, e2] if att_grp is None else [att_grp[0], l2, att_grp[2] + 1, e2]
+                    if att_grp[2] >= WG:
+                        side.wait_event(att_grp[3])
+                        att_wgrads(att_grp[0], att_grp[1]); att_grp = None
+                SHARE_CU[0] = 0
             main.wait_event(ev)
             sb.t_hi, sb.t_lo = hi, lo
             call("t2_attn_seq_bwd", sb, st)
+            if self.chunk_att_wgrads:
+                att_done.append((hi, lo, main.record_event()))
         with torch.cuda.stream(side):
             while post_wgrads:                      # (short sequences: fewer chunks than deferred GEMMs)
                 post_wgrads.pop(0)()
+            SHARE_CU[0] = self.share_cu
+            if dec_grp is not None:
+                dec_wgrads_chunk(dec_grp[0], dec_grp[1])
+            for h2, l2, e2 in att_done:
+                att_grp = [h2, l2, 1, e2] if att_grp is None else [att_grp[0], l2, att_grp[2] + 1, e2]
+            if att_grp is not None:
+                side.wait_event(att_grp[3])
+                att_wgrads(att_grp[0], att_grp[1])
+            SHARE_CU[0] = 0
         dec_wgrads()
         self.mark("bwd.dec.chains")
 
@@ -784,15 +830,12 @@ class Engine:
         side.wait_stream(main)
         with torch.cuda.stream(side):
             sst = side.cuda_stream
-            gWih = G["decoder.att_rnn.weight_ih"]
-            self._wgrad(dga, ldz, ctx["p2"], Pd, gWih, Pd + Ef, 4 * A, Pd, R)
-            self._wgrad(dga, ldz, _ptr(xdec, A), ldx, _ptr(gWih, Pd), Pd + Ef, 4 * A, Ef, R)
-            self._wgrad(dga, ldz, xdec, ldx, G["decoder.att_rnn.weight_hh"], A, 4 * A, A, R)
+            if not self.chunk_att_wgrads:
+                att_wgrads(T, 0)
             db = self.buf("db_att", 4 * A, zero=True)
             call("t2_colsum", dga, ldz, R, 4 * A, db, sst)
             for nm in ("decoder.att_rnn.bias_ih", "decoder.att_rnn.bias_hh"):
                 call("t2_colsum", db, 4 * A, 1, 4 * A, G[nm], sst)
-            self._wgrad(dq, ldz, _ptr(xdec, B * ldx), ldx, G["decoder.attention.query_layer.weight"], A, Ad, A, R)
             call("t2_colsum", dv_part, Ad, B, Ad, G["decoder.attention.v.weight"], sst)
             dU = self.buf("dU", Ad, 2 * KL, zero=True)
             call("t2_colsum", dU_part, Ad * 2 * KL, B, Ad * 2 * KL, dU, sst)

@@ -1,4 +1,4 @@
-"""A/B of one boolean engine attribute on the bench batch (GPU box): python tools/ab_ramp.py [attribute, default ramp_chunks]."""
+"""A/B (GPU box): number of pipeline chunks per weight-gradient GEMM call in the backward frame loop (engine.wgrad_group)."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import VANILLA
@@ -10,10 +10,10 @@ dev = torch.device("cuda:0")
 ps = ParamStore(VANILLA, dev); init_parameters(ps, 0)
 tr = Trainer(ps, lr=1e-3, weight_decay=1e-6)
 batch = {k: v.to(dev) for k, v in ljspeech_batch(32, seed=1234, num_speakers=4).items()}
-ATTR = sys.argv[1] if len(sys.argv) > 1 else "ramp_chunks"
-for rep in range(3):
-    for ramp in (True, False):
-        setattr(tr.engine, ATTR, ramp)
+for rep in range(2):
+    for wg in (0, 1, 2, 3, 4, 6):
+        tr.engine.chunk_att_wgrads = wg > 0
+        tr.engine.wgrad_group = max(wg, 1)
         for _ in range(3):
             tr.train_step(batch)
         torch.cuda.synchronize()
@@ -25,7 +25,5 @@ for rep in range(3):
         dt = (time.perf_counter() - t0) / 10 * 1e3
         tr.engine.profile = False
         seg = tr.engine.segment_times_ms()
-        tr.engine.check_persistent_kernels()
-        print({k: round(v, 2) for k, v in seg.items() if k.startswith("bwd") or k == "optimizer"}, flush=True)
-        print(f"{ATTR}={ramp}: {dt:.2f} ms/step  bwd.postnet {seg['bwd.postnet']:.2f}  bilstm {seg['bwd.bilstm']:.2f}  fwd chain {seg['fwd.dec.attn_chain']:.2f} tail {seg['fwd.dec.lstm_chain_tail']:.2f}  "
-              f"bwd chains {seg['bwd.dec.chains']:.2f}", flush=True)
+        print(f"wgrad_group={wg} (0 = all at the end): {dt:.2f} ms/step  chains {seg['bwd.dec.chains']:.2f}  bilstm {seg['bwd.bilstm']:.2f}  "
+              f"convs {seg['bwd.encoder_convs']:.2f}", flush=True)
