@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the secondary autoregressive decode-rate measurement")
+    ap.add_argument("--no-high", action="store_true", help="skip the extra steps at float32_matmul_precision=high (profiling runs)")
     ap.add_argument("--fixed-shape", action="store_true", help="every utterance L=160, T=860 (roofline accounting variant)")
     ap.add_argument("--matmul-precision", default="highest", choices=["highest", "high", "medium"],
                     help="the reference's training.float32_matmul_precision for the GEMMs; the judged line is 'highest' (fp32-exact)")
@@ -180,7 +181,7 @@ def main():
     # "high", run/train.py:170: three of the six bf16 partial products; mel L1 against the fp32 oracle stays < 1e-4,
     # tests/test_gpu_fullsize.py).  Reported beside the judged fp32-exact line, never as `value`.
     high = None
-    if rank == 0 and world == 1 and args.matmul_precision == "highest":
+    if rank == 0 and world == 1 and args.matmul_precision == "highest" and not args.no_high:
         set_float32_matmul_precision("high")
         for _ in range(2):
             tr.train_step(batch)

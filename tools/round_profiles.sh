@@ -3,7 +3,7 @@
 set -e
 R=$GRAFT_REPO_ROOT; V=${1:-r02}; O=$R/gpurun_out/prof_$V; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -o k -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-decode > $O/train.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -o k -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-decode --no-high > $O/train.log 2>&1
 cp $(find $O/train -name '*kernel_stats.csv' | head -1) $O/${V}_kernel_stats.csv
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dec -o k -- python3 $R/tools/prof_decode.py > $O/dec.log 2>&1
 cp $(find $O/dec -name '*kernel_stats.csv' | head -1) $O/${V}_decode_kernel_stats.csv
