@@ -54,6 +54,18 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_k=1, b_k=1, alpha=1.0, bias=None, bi
     call("t2_gemm", g, _stream())
 
 
+def gemm_fill(A, B, C, M, N, K, lda, ldb, ldc, a_k=1, b_k=1, bias=None):
+    """Plain C = A.B (+ bias) for shapes that leave the chip under-filled (fewer than 256 output tiles of 128 x 128, long K): two
+    K slices accumulate into the zeroed C with atomics - encoder convolution 178 -> 123 us, BiLSTM dgrad 123 -> 94 us
+    (tools/bench_gemm_small.py).  C must be a tensor whose first M rows of ldc floats are exactly the output."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles < 256 and K >= 1024 and torch.is_tensor(C):
+        C.view(-1)[:M * ldc].zero_()
+        gemm(A, B, C, M, N, K, lda, ldb, ldc, a_k=a_k, b_k=b_k, bias=bias, accumulate=2, splitk=2)
+    else:
+        gemm(A, B, C, M, N, K, lda, ldb, ldc, a_k=a_k, b_k=b_k, bias=bias)
+
+
 def _ptr(t: torch.Tensor, elem_off: int = 0) -> int:
     return t.data_ptr() + 4 * elem_off
 
@@ -225,7 +237,7 @@ class Engine:
         wp = self.buf(f"{tag}.wp", Co, 5 * Ci)
         call("t2_pack_conv_weight", w, wp, Co, Ci, 5, 0, _stream())
         raw = self.buf(f"{tag}.raw", B * Lp, Co)
-        gemm(x_pad, wp, raw, B * Lp - 4, Co, 5 * Ci, Ci, 5 * Ci, Co, bias=bias)
+        gemm_fill(x_pad, wp, raw, B * Lp - 4, Co, 5 * Ci, Ci, 5 * Ci, Co, bias=bias)
         mean = self.buf(f"{tag}.mean", Co)
         invstd = self.buf(f"{tag}.invstd", Co)
         sums = self.buf(f"{tag}.sums", 2 * Co + 2, dtype=torch.float64)
@@ -604,7 +616,7 @@ class Engine:
         wf = self.buf(f"{tag}.wf", Ci, 5 * Co)
         call("t2_pack_conv_weight", w, wf, Co, Ci, 5, 1, st)
         dx = self.buf(f"{tag}.dx", B * Lp, Ci)
-        gemm(draw, wf, dx, R, Ci, 5 * Co, Co, 5 * Co, Ci)
+        gemm_fill(draw, wf, dx, R, Ci, 5 * Co, Co, 5 * Co, Ci)
         return dx
 
     def backward_tf(self, ctx, d_post, dproj):
@@ -924,7 +936,7 @@ class Engine:
         else:
             bilstm_wgrads()
         dx = self.buf("enc.dx3", B * Lp, E)
-        gemm(dpre, ps.cat_view("encoder.lstm.weight_ih_l0", 8 * H, E), dx, Rr, E, 8 * H, 8 * H, E, E, a_k=1, b_k=0)
+        gemm_fill(dpre, ps.cat_view("encoder.lstm.weight_ih_l0", 8 * H, E), dx, Rr, E, 8 * H, 8 * H, E, E, a_k=1, b_k=0)
 
         self.mark("bwd.bilstm")
         # ---- encoder convolutions + embedding -----------------------------------------------------------------
