@@ -226,6 +226,15 @@ def main():
                                     hbm_achieved_GBs=gbs, hbm_frac=gbs / HBM_PEAK_GBS,
                                     algorithmic_bytes_per_step=decoder_step_bytes(64, Ld, 512),
                                     algorithmic_flops_per_step=decoder_step_flops(64, Ld, 512)))
+        # SURVEY section 8d also asks for the utterances sorted by length: the same lock-step loop, reported beside.  (Runs in which
+        # utterances stop at different frames are the parity tests' job: tests/test_gpu_fullsize.py, 64 utterances against the oracle.)
+        order = torch.argsort(cl, descending=True)
+        cis, cls_, spks = ci[order].contiguous(), cl[order].contiguous(), spk[order].contiguous()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        eng.infer(cis, cls_, n_dec, speaker_id=spks, training=False, seed=2, check_every=64)
+        torch.cuda.synchronize()
+        decode["sorted_by_length_steps_per_s"] = n_dec / (time.perf_counter() - t2)
 
     if rank == 0:
         Ef = 512
