@@ -143,3 +143,18 @@ def test_mel_filterbank_known_answers_of_the_slaney_scale():
     areas = fb[wide].sum(1) * df
     assert len(wide) > 20 and np.abs(areas - 1.0).max() < 0.02                        # unit area once a filter spans enough bins
     assert float(fb[:, freqs > 8000.0 + df].max()) == 0.0                            # nothing above f_max
+
+
+def test_pipeline_chunk_sizes_cover_the_frames_and_shrink_at_the_end():
+    """engine._chunk_sizes: every frame in exactly one chunk, equal chunks except the ramp CH/2, CH/4, CH/8, CH/8 over the last CH
+    frames (the un-overlapped end of the forward pipeline / start of the backward one); no ramp for short loops or tiny chunks."""
+    from tacotron2_amd.engine import _chunk_sizes
+    for T in (1, 7, 63, 64, 65, 100, 872, 5000):
+        for CH in (4, 8, 16, 64, 80):
+            for ramp in (True, False):
+                z = _chunk_sizes(T, CH, ramp_at_end=ramp)
+                assert sum(z) == T and all(0 < n <= CH for n in z), (T, CH, ramp, z)
+    assert _chunk_sizes(872, 64) == [64] * 12 + [40, 32, 16, 8, 8]
+    assert _chunk_sizes(872, 80)[-4:] == [40, 20, 10, 10]
+    assert _chunk_sizes(872, 64, ramp_at_end=False) == [64] * 13 + [40]
+    assert _chunk_sizes(37, 8) == [8, 8, 8, 8, 5]            # chunks below 16 frames are not ramped
