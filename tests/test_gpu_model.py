@@ -228,12 +228,15 @@ def test_train_step_midsize_matches_oracle():
         ps.load_state_dict({k: v.detach() for k, v in Pc.items()})
 
 
-@pytest.mark.parametrize("B,chunk,chunk_bwd,dec_chain", [(5, 8, 8, "persistent"), (5, 64, 5, "hosted"), (5, 6, 64, "persistent"),
-                                                           (35, 7, 9, "persistent"), (5, 8, 8, "hosted")])
-def test_pipeline_chunking_matches_oracle(B, chunk, chunk_bwd, dec_chain):
+@pytest.mark.parametrize("B,T,chunk,chunk_bwd,dec_chain", [(5, 23, 8, 8, "persistent"), (5, 23, 64, 5, "hosted"), (5, 23, 6, 64, "persistent"),
+                                                             (35, 23, 7, 9, "persistent"), (5, 23, 8, 8, "hosted"),
+                                                             (5, 150, 16, 16, "persistent"), (33, 90, 32, 16, "persistent")])
+def test_pipeline_chunking_matches_oracle(B, T, chunk, chunk_bwd, dec_chain):
     """The frame loop's schedule (chunk sizes; forward: decoder-LSTM chain as persistent launches on the side stream or hosted inside the
     attention-energies launches for B <= 32, two-stream pipeline above; backward: two-stream pipeline) must not change results: every variant against the
-    CPU oracle on the same inputs."""
+    CPU oracle on the same inputs.  The long cases (T = 150 / 90 with 16-frame chunks) have enough chunks for everything the backward
+    schedule does along the pipeline: ramped chunk sizes, weight gradients in groups of four chunks behind main-stream events,
+    deferred postnet / projection weight gradients between chunks."""
     dev = _dev()
     d = R.default_dims(num_chars=39, encoded_dim=64, prenet_dim=32, att_rnn_dim=64, att_dim=32, rnn_hidden_dim=64,
                        postnet_dim=64, num_mels=16, dropout=0.5)
@@ -242,7 +245,7 @@ def test_pipeline_chunking_matches_oracle(B, chunk, chunk_bwd, dec_chain):
     eng.chunk, eng.chunk_bwd, eng.dec_chain = chunk, chunk_bwd, dec_chain
     # (seed 77 at B = 35 puts one encoder pre-activation within 1e-6 of the ReLU kink: fp32 kernels with different summation
     # orders - the two GEMM kernels, the oracle - then legitimately disagree on that element's derivative; tools/debug_b35.py)
-    ci, lens, mel, tl, gate, masks = random_case(d, B, 17, 23, 77 if B != 35 else 79, dev)
+    ci, lens, mel, tl, gate, masks = random_case(d, B, 17, T, 77 if B != 35 else 79, dev)
     Pc = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not R.is_buffer(k)) else v.clone()) for k, v in P.items()}
     o = R.tacotron2_fwd(Pc, d, ci, lens, True, mel, tl, training=True, masks=masks, new_stats={})
     loss = R.tts_loss(o[0], o[1], o[2], mel, gate)[0]
