@@ -29,6 +29,7 @@ extern "C" {
 #define T2_OK 0
 #define T2_ERR_ARG 1     /* bad argument / unsupported shape */
 #define T2_ERR_LAUNCH 2  /* HIP launch or runtime error */
+#define T2_ERR_RESIDENCY 3  /* a persistent launch would not be fully co-resident on this device (caller: use the per-step launches) */
 
 const char* t2_last_error(void);
 int t2_version(void);
@@ -133,6 +134,19 @@ int t2_lstm_seq_fwd(const T2LstmStep* base, const T2LstmStride* inc, int n, int 
  * timeout flag: zeroed by the CALLER before first use and sticky - a wait that timed out (bounded spins) sets it, every launch
  * that sees it ends early (outputs unusable) until the caller has read and cleared it. */
 int t2_lstm_seq_fwd_persist(const T2LstmStep* base, const T2LstmStride* inc, int S, uint32_t* sync, void* stream);
+/* Residency check of the persistent launch above, without launching anything: T2_OK when H/4 workgroups with this K's weight
+ * slice in LDS are all co-resident (compute units of the current device x hipOccupancyMaxActiveBlocksPerMultiprocessor),
+ * T2_ERR_RESIDENCY otherwise - the caller then runs the same steps as t2_lstm_seq_fwd launches.  t2_lstm_seq_fwd_persist makes
+ * the same check itself and returns the same code. */
+int t2_lstm_persist_resident(int H, int K, int B);
+/* Debug / test hook: bound of the inter-workgroup waits of t2_lstm_seq_fwd_persist in polls (default 1 << 21; < 0: every wait
+ * is treated as timed out, which raises the sticky flag sync[256] deterministically).  Returns the previous value. */
+int t2_debug_persist_spin_limit(int polls);
+/* Makes the sticky timeout flag of the persistent launches (sync[256]) fatal without a host synchronisation: if *flag != 0,
+ * x[0..n) is overwritten with NaN (the engine passes the decoder projection of the forward, so every output, the loss and
+ * every gradient of that step become NaN and t2_adam_step - which skips a step whose gradient norm is not finite - leaves
+ * the weights alone).  The host raises at its next synchronisation point. */
+int t2_guard_poison(const uint32_t* flag, float* x, int64_t n, void* stream);
 /* One step of back-propagation through time for an LSTM cell (autograd of the cells above):
  *   dx[b][u] = sum_n dg_next[b][n] * W[n*ldw + u]          (n over N4 = 4H' rows of the producing cell)
  *   epi = 0: dx_out = dx + ext1 + ext2                      (gradient w.r.t. a non-recurrent input slice)
@@ -390,6 +404,8 @@ int t2_logmel_fwd(const float* wav, int64_t n, const float* basis, const float* 
  * Lightning gradient_clip_val=1.0 (run/train.py:240) on one flat fp32 parameter buffer. */
 int t2_philox_mask(float* out, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream);
 int t2_sumsq(const float* g, int64_t n, double* out, void* stream);
+/* A step whose global gradient norm (sumsq) is NaN or infinite is SKIPPED: parameters and moments stay as they are (the
+ * reference would write NaN into every weight, torch clip_grad_norm_ + Adam; there is nothing to match in that state). */
 int t2_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq, float max_norm, float lr,
                  float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 

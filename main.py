@@ -4,10 +4,11 @@
     python main.py --config C --device N train --speech-dir S [--results-dir R] [--resume-ckpt K] [--finetune --finetune-steps n]
     python main.py --config C --device N say --checkpoint K --text "..." [--out out.npy] [--random-seed s] [--speaker-id i]
     python main.py --config C --device N test --speech-dir S --checkpoint K [--hifi-gan-checkpoint G] [--results-dir R]
+    python main.py --config C --device N test-correlation --speech-dir S --checkpoint K [--hifi-gan-checkpoint G] [--results-dir R]
     python main.py --config C --device N train-mel-export --speech-dir S --checkpoint K [--results-dir R]
 
-Other reference sub-commands (test_correlation, preprocess, server) are evaluation / demo tooling
-outside the hot-path scope.  Multi-GPU training: `python -m torch.distributed.run --nproc-per-node N
+Other reference sub-commands (preprocess, server) are data preparation / demo tooling outside the hot-path scope
+(SURVEY.md section 2).  Multi-GPU training: `python -m torch.distributed.run --nproc-per-node N
 main.py --config C train ...` (one process per GPU, RCCL gradient all-reduce)."""
 import click
 
@@ -87,6 +88,27 @@ def test(ctx, speech_dir, checkpoint, hifi_gan_checkpoint, results_dir, batch_si
     do_test(dataset_config=c["dataset"], training_config=c["training"], model_config=c["model"],
             extensions_config=c["extensions"], device=ctx.obj["device"], speech_dir=speech_dir, checkpoint=checkpoint,
             hifi_gan_checkpoint=hifi_gan_checkpoint, results_dir=results_dir, batch_size=batch_size, max_len=max_len, limit=limit)
+
+
+@main.command()
+@click.pass_context
+@click.option("--speech-dir", required=True, type=str, help="A directory containing audio files from the dataset.")
+@click.option("--checkpoint", required=True, type=str, help="A trained Tacotron model checkpoint")
+@click.option("--hifi-gan-checkpoint", required=False, type=str, default=None, help="A trained HiFi-GAN model checkpoint")
+@click.option("--results-dir", required=False, type=str, default=None, help="The directory to save results.")
+@click.option("--samples-per-speaker", required=False, type=int, default=200, help="Utterances drawn per speaker (reference: 200).")
+@click.option("--max-len", required=False, type=int, default=5000, help="Frame cap per utterance (reference: 5000).")
+@click.option("--limit-overrides", required=False, type=int, default=None, help="Only the first n of the 51 control overrides.")
+def test_correlation(ctx, speech_dir, checkpoint, hifi_gan_checkpoint, results_dir, samples_per_speaker, max_len, limit_overrides):
+    """The test manifest under 51 control-vector overrides (run/test_correlation.py of the reference)."""
+    if ctx.obj["config"] is None:
+        raise Exception("Configuration required for testing!")
+    from tacotron2_amd.run.test_correlation import do_test_correlation
+    c = ctx.obj["config"]
+    do_test_correlation(dataset_config=c["dataset"], training_config=c["training"], model_config=c["model"],
+                        extensions_config=c["extensions"], device=ctx.obj["device"], speech_dir=speech_dir, checkpoint=checkpoint,
+                        hifi_gan_checkpoint=hifi_gan_checkpoint, results_dir=results_dir, samples_per_speaker=samples_per_speaker,
+                        max_len=max_len, limit_overrides=limit_overrides)
 
 
 @main.command()

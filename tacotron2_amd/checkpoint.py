@@ -145,4 +145,10 @@ def restore_trainer(ck: dict, trainer) -> bool:
     if sch:
         trainer.milestones = sorted(int(m) for m, c in dict(sch["milestones"]).items() for _ in range(int(c)))
         trainer.base_lr = float(sch["base_lrs"][0])
+    elif opt and opt.get("param_groups"):
+        # no scheduler in the checkpoint (scheduler_milestones = []): Lightning's optimizer.load_state_dict still restores
+        # param_groups[0]["lr"], which replaces the freshly configured lr (and the fine-tune's lr / 10) in the reference
+        pg = opt["param_groups"][0]
+        trainer.base_lr = float(pg.get("initial_lr", pg["lr"]))
+        trainer.milestones = []
     return found

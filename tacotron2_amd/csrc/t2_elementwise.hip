@@ -502,6 +502,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, doub
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n, const double* sumsq, float max_norm,
                             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, float gscale) {
     float clip = 1.f;
+    if (sumsq && !isfinite(*sumsq)) return;    // non-finite gradient norm: skip the step (see include/tacotron2_amd.h)
     if (sumsq && max_norm > 0.f) {
         const float tot = (float)sqrt(*sumsq) * gscale;
         const float c = max_norm / (tot + 1e-6f);
@@ -518,9 +519,22 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n
     }
 }
 
+__global__ void guard_poison_kernel(const uint32_t* flag, float* x, long n) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] = __builtin_nanf("");
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
+
+extern "C" int t2_guard_poison(const uint32_t* flag, float* x, int64_t n, void* stream) {
+    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
+    T2_REQUIRE(flag && x && n >= 0, "t2_guard_poison: bad arguments");
+    if (n == 0) return T2_OK;
+    hipLaunchKernelGGL(guard_poison_kernel, dim3(ew_grid(n) > 1024 ? 1024 : ew_grid(n)), dim3(256), 0, ST, flag, x, (long)n);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
 
 extern "C" int t2_embedding_fwd(const int64_t* idx, const float* table, float* out, int B, int L, int E, int pad, void* stream) {
     (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked

@@ -269,9 +269,9 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_persist_fwd_kernel(PersistK p
                     unsigned got = 0xffffffffu;
                     if (lane < 8) got = __hip_atomic_load(pp.sync + lane * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const unsigned bad = __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = __all(lane >= 8 || got >= want_per_step * (unsigned)s);
+                    ok = __all(lane >= 8 || got >= want_per_step * (unsigned)s) && pp.spin_limit >= 0;
                     if (ok || bad) { ok = ok && !bad; break; }
-                    if (++spins > pp.spin_limit) {
+                    if (++spins > pp.spin_limit || pp.spin_limit < 0) {   // (< 0: debug hook, every wait times out)
                         if (lane == 0) __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
                     }
@@ -598,6 +598,55 @@ extern "C" int t2_lstm_seq_bwd(const T2LstmBwdStep* base, const T2LstmBwdStride*
     return T2_OK;
 }
 
+// (T2_PERSIST_SPIN_LIMIT in the environment presets the debug value for a whole process, e.g. a CLI run under test)
+static int g_persist_spin_limit = getenv("T2_PERSIST_SPIN_LIMIT") ? atoi(getenv("T2_PERSIST_SPIN_LIMIT")) : (1 << 21);
+extern "C" int t2_debug_persist_spin_limit(int polls) {
+    const int old = g_persist_spin_limit;
+    g_persist_spin_limit = polls;
+    return old;
+}
+
+// All H/4 workgroups of the persistent launch must be resident at once (they wait for each other): compute units of the
+// current device x the occupancy the runtime reports for this kernel with its LDS slice.  The answer is cached per (MT, LDS).
+static int persist_resident(int nwg, int MT, size_t lds) {
+    static std::mutex mu;
+    static std::unordered_map<long, int> cap;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { t2_set_error("hipGetDevice failed", __FILE__, __LINE__); return T2_ERR_LAUNCH; }
+    const long key = ((long)dev << 40) | ((long)MT << 32) | (long)lds;
+    auto it = cap.find(key);
+    if (it == cap.end()) {
+        int cus = 0, per_cu = 0;
+        hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e == hipSuccess)
+            e = MT == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_persist_fwd_kernel<1>, 256, lds)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_persist_fwd_kernel<2>, 256, lds);
+        if (e != hipSuccess) { t2_set_error(hipGetErrorString(e), __FILE__, __LINE__); (void)hipGetLastError(); return T2_ERR_LAUNCH; }
+        it = cap.emplace(key, cus * per_cu).first;
+    }
+    if (nwg > it->second) {
+        t2_set_error("t2_lstm_seq_fwd_persist: the launch would not be co-resident on this device (compute units x occupancy "
+                     "< H/4 workgroups); use t2_lstm_seq_fwd", __FILE__, __LINE__);
+        return T2_ERR_RESIDENCY;
+    }
+    return T2_OK;
+}
+
+static size_t persist_lds_bytes(int K) {
+    const int NT = K >> 4, NTpad = (NT + 15) & ~15;
+    return ((size_t)NTpad * 256 + (size_t)4 * 2 * 256 + 4) * sizeof(float);
+}
+
+extern "C" int t2_lstm_persist_resident(int H, int K, int B) {
+    (void)hipGetLastError();
+    T2_REQUIRE(H >= 4 && H % 4 == 0 && K >= 16 && K % 16 == 0 && B >= 1, "t2_lstm_persist_resident: bad arguments");
+    const size_t lds = persist_lds_bytes(K);
+    T2_REQUIRE(t2_allow_lds(lstm_seq_persist_fwd_kernel<1>, lds) && t2_allow_lds(lstm_seq_persist_fwd_kernel<2>, lds),
+               "t2_lstm_persist_resident: weight slice does not fit the LDS");
+    return persist_resident(H / 4, B <= 16 ? 1 : 2, lds);
+}
+
 extern "C" int t2_lstm_seq_fwd_persist(const T2LstmStep* base, const T2LstmStride* inc, int S, uint32_t* sync, void* stream) {
     (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(base && inc && sync && S >= 0, "t2_lstm_seq_fwd_persist: bad arguments");
@@ -609,10 +658,10 @@ extern "C" int t2_lstm_seq_fwd_persist(const T2LstmStep* base, const T2LstmStrid
     T2_REQUIRE(b.seg[0].K == b.H && b.ht_col0 == 0 && inc->xt == inc->ht_out && b.ht_out == b.xt + inc->xt,
                "t2_lstm_seq_fwd_persist: the input of step s+1 must be the tiled h of step s (K = H)");
     T2_REQUIRE(b.H / 4 <= 256 && !b.h_out2, "t2_lstm_seq_fwd_persist: at most 256 workgroups (one per CU), no second h copy");
-    const int NT = b.seg[0].K >> 4, NTpad = (NT + 15) & ~15;
-    const size_t lds = ((size_t)NTpad * 256 + (size_t)4 * 2 * 256 + 4) * sizeof(float);
+    const size_t lds = persist_lds_bytes(b.seg[0].K);
     T2_REQUIRE(t2_allow_lds(lstm_seq_persist_fwd_kernel<1>, lds) && t2_allow_lds(lstm_seq_persist_fwd_kernel<2>, lds),
                "t2_lstm_seq_fwd_persist: weight slice does not fit the LDS");
+    T2_TRY(persist_resident(b.H / 4, (b.B < 32 ? b.B : 32) <= 16 ? 1 : 2, lds));
     hipStream_t st = (hipStream_t)stream;
     // Rows are independent: blocks of up to 32 rows (two 16-row tiles) run as consecutive launches of the same chunk.  Each
     // launch zeroes the arrival counters; the timeout flag (word 256) is sticky - only the host clears it.
@@ -621,7 +670,7 @@ extern "C" int t2_lstm_seq_fwd_persist(const T2LstmStep* base, const T2LstmStrid
         PersistK k;
         t2_lstm_to_k(b, k.s, b0, bn);
         k.i_pre = inc->pre; k.i_drop = inc->drop; k.i_h_out = inc->h_out; k.i_c_out = inc->c_out; k.i_gates = inc->gates_out;
-        k.i_xt = inc->xt; k.i_ht = inc->ht_out; k.i_dt = inc->dt; k.steps = S; k.sync = sync; k.spin_limit = 1 << 21;
+        k.i_xt = inc->xt; k.i_ht = inc->ht_out; k.i_dt = inc->dt; k.steps = S; k.sync = sync; k.spin_limit = g_persist_spin_limit;
         (void)hipMemsetAsync(sync, 0, 16 * 16 * sizeof(uint32_t), st);
         dim3 grid(b.H / 4), block(256);
         if (bn <= 16) hipLaunchKernelGGL((lstm_seq_persist_fwd_kernel<1>), grid, block, lds, st, k);

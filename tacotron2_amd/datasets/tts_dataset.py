@@ -5,6 +5,7 @@ gate (B,T,1) = ones with the last valid frame 0, lengths stacked to (B,).  The l
 from __future__ import annotations
 
 import os
+import threading
 import wave
 from collections import defaultdict
 from typing import Any, Dict, List, Optional
@@ -80,7 +81,10 @@ class TTSDataset(torch.utils.data.Dataset):
         if self.cache:
             cache_path = os.path.join(self.cache_dir, f"{fn.replace('/', '_')}.pt")
             if os.path.exists(cache_path):
-                mel = torch.load(cache_path, weights_only=True)
+                try:
+                    mel = torch.load(cache_path, weights_only=True)
+                except Exception:       # unreadable entry (e.g. left by a killed run): a cache miss, recomputed below
+                    mel = None
         if mel is None:
             wav, _ = load_wav(os.path.join(self.base_dir, fn))
             if self.trim:
@@ -88,7 +92,11 @@ class TTSDataset(torch.utils.data.Dataset):
             wav = np.pad(wav, (0, self.silence))
             mel = self.melspectrogram(torch.from_numpy(np.ascontiguousarray(wav)), id=str(i)).cpu()
             if cache_path is not None:
-                torch.save(mel, cache_path)
+                # several readers share one cache directory (validation set, the prefetch thread, N data-parallel ranks): the
+                # entry appears under its final name only when complete (same pattern as checkpoint.save_atomic)
+                tmp = f"{cache_path}.tmp.{os.getpid()}.{threading.get_ident()}"
+                torch.save(mel, tmp)
+                os.replace(tmp, cache_path)
         gate = torch.ones(len(mel), 1)
         gate[-1] = 0.0
         data = {"chars_idx": self.ids[i], "mel_spectrogram": mel, "gate": gate}
@@ -134,37 +142,53 @@ class LengthBucketBatchSampler(torch.utils.data.Sampler):
     windows of `window` batches, each window is sorted by text length and cut into batches, and the batches are shuffled.
     At b = 32 the padded-to-valid frame ratio of LJSpeech-shaped data drops from 1.53 (random batches) to about 1.1 - the
     padding, not the 112 MB gradient all-reduce, is what limits data-parallel efficiency.  The model
-    sees every utterance once per epoch either way; only the batch composition changes."""
+    sees every utterance once per epoch either way; only the batch composition changes.
 
-    def __init__(self, lengths, batch_size: int, window: int = 16, drop_last: bool = True, seed: int = 0):
+    Data parallelism (rank, world): every rank draws the SAME permutation (same seed), each sorted window is cut into
+    super-batches of world * batch_size utterances and rank r takes the r-th slice of each.  The ranks then see disjoint data
+    and, at every step, batches of similar length - Trainer.global_pad pads all shards to the step's global (L, T), so one rank
+    with a long batch would otherwise set the shape for all of them.  (With world > 1 the dataset must hold the WHOLE manifest,
+    not a per-rank slice.)"""
+
+    def __init__(self, lengths, batch_size: int, window: int = 16, drop_last: bool = True, seed: int = 0, rank: int = 0,
+                 world: int = 1):
         self.lengths, self.batch_size, self.window, self.drop_last = list(lengths), batch_size, max(1, window), drop_last
         self.epoch, self.seed = 0, seed
+        assert 0 <= rank < world
+        self.rank, self.world = rank, world
 
     def __len__(self):
-        n = len(self.lengths)
+        n, sb = len(self.lengths), self.batch_size * self.world
+        if self.world > 1:
+            return n // sb           # whole super-batches only: every rank runs the same number of steps
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
     def __iter__(self):
         g = torch.Generator().manual_seed(self.seed + self.epoch)
         self.epoch += 1
         perm = torch.randperm(len(self.lengths), generator=g).tolist()
-        span = self.batch_size * self.window
+        sb = self.batch_size * self.world
+        span = sb * self.window
+        if self.world > 1:
+            perm = perm[:len(perm) // sb * sb]
         batches = []
         for w0 in range(0, len(perm), span):
             win = sorted(perm[w0:w0 + span], key=lambda i: self.lengths[i])
-            for b0 in range(0, len(win), self.batch_size):
-                b = win[b0:b0 + self.batch_size]
-                if len(b) == self.batch_size or not self.drop_last:
+            for b0 in range(0, len(win), sb):
+                b = win[b0 + self.rank * self.batch_size:b0 + (self.rank + 1) * self.batch_size]
+                if len(b) == self.batch_size or (not self.drop_last and self.world == 1 and b):
                     batches.append(b)
-        for i in torch.randperm(len(batches), generator=g).tolist():
+        for i in torch.randperm(len(batches), generator=g).tolist():      # same order on every rank (same generator state)
             yield batches[i]
 
 
-def TTSDataLoader(dataset, batch_size=1, num_workers=0, shuffle=None, drop_last=True, bucket_window=0, seed=0, **_ignored):
+def TTSDataLoader(dataset, batch_size=1, num_workers=0, shuffle=None, drop_last=True, bucket_window=0, seed=0, rank=0, world=1,
+                  **_ignored):
     """The log-mel runs on the GPU inside __getitem__, so items are produced in-process (num_workers = 0).
-    bucket_window > 0: length-bucketed batches (LengthBucketBatchSampler) instead of the reference's plain shuffle."""
+    bucket_window > 0: length-bucketed batches (LengthBucketBatchSampler) instead of the reference's plain shuffle; with
+    world > 1 the sampler also shards them across the ranks (the dataset then holds the whole manifest)."""
     if bucket_window and batch_size > 1 and hasattr(dataset, "ids"):
-        sampler = LengthBucketBatchSampler([len(i) for i in dataset.ids], batch_size, bucket_window, drop_last, seed)
+        sampler = LengthBucketBatchSampler([len(i) for i in dataset.ids], batch_size, bucket_window, drop_last, seed, rank, world)
         return torch.utils.data.DataLoader(dataset, batch_sampler=sampler, collate_fn=collate, num_workers=0)
     return torch.utils.data.DataLoader(dataset, batch_size=batch_size, collate_fn=collate if batch_size > 1 else None,
                                        num_workers=0, shuffle=shuffle, drop_last=drop_last)

@@ -113,6 +113,7 @@ class Engine:
         self.persist_gemm_side = True    # the hoisted pre_dec GEMM of a chunk runs on the side stream too, in front of the chunk's
                                          # persistent launch (70.0 against 71.3 ms per step on the main stream, profiles/r02_ab_fwd_dec_chain.txt)
         self._persist_sync = None
+        self._persist_ok = {}            # (D, one row tile) -> residency verdict of the persistent launch
         self.defer_wgrads = True      # weight-gradient GEMMs of postnet, projection and encoder leave the main stream (-1.4 ms per step)
         self.wgrad_group = 4          # pipeline chunks per weight-gradient GEMM call (profiles/r02_ab_wgrad_pipeline.txt)
         self.chunk_att_wgrads = True  # attention-chain weight gradients per pipeline chunk, behind the chain, instead of all at its end
@@ -124,6 +125,17 @@ class Engine:
                                       # so only the LATEST forward can be back-propagated (checked in backward_tf)
         self.profile = False          # when True, mark() records HIP events at segment boundaries
         self.marks = []; self.spans = []               # [(name, event)] of the current step
+
+    def persist_resident(self, D: int, B: int) -> bool:
+        """True when the persistent decoder-LSTM launch (H/4 workgroups that wait for each other) is fully co-resident on this
+        device (t2_lstm_persist_resident: compute units x occupancy); otherwise the chain runs as per-step launches."""
+        key = (D, min(B, 32) <= 16)
+        if key not in self._persist_ok:
+            rc = _lib.call_value("t2_lstm_persist_resident", D, D, min(B, 32))
+            if rc not in (0, 3):
+                raise _lib.T2Error(f"t2_lstm_persist_resident failed (rc={rc}): {_lib.lib().t2_last_error().decode()}")
+            self._persist_ok[key] = rc == 0
+        return self._persist_ok[key]
 
     def check_persistent_kernels(self):
         """Host-synchronising check of the persistent launches' timeout flag (bounded spins end the launch early instead of
@@ -482,7 +494,8 @@ class Engine:
         for n in sizes:
             chunks.append((c0, c0 + n)); c0 += n
         co = B <= 32 and self.dec_chain == "hosted"     # the hosted cell needs <= 32 rows (register budget of the host kernel)
-        persist = B <= 64 and self.dec_chain == "persistent" and D // 4 <= 256
+        persist = B <= 64 and self.dec_chain == "persistent" and D // 4 <= 256 and self.persist_resident(D, B)
+        ctx["persist"] = persist
         if persist:
             # The decoder-LSTM chain of a chunk as ONE persistent, weight-stationary launch on the side stream
             # (t2_lstm_seq_fwd_persist): W_hh stays in LDS, the workgroups exchange h through the tiled stash, and the
@@ -541,6 +554,12 @@ class Engine:
             proj.copy_(cmel1.unsqueeze(0).expand(T, B, M + 1))
         gemm(_ptr(xproj, B * ldp), wproj, proj, R, M + 1, ldp, ldp, ldp, M + 1, bias=bproj,
              accumulate=1 if cmel1 is not None else 0)
+        if persist:
+            # A persistent launch that gave up on an inter-workgroup wait (sticky device flag) must not pass unnoticed: with the
+            # flag set the projection - and with it every output, the loss and every gradient of this step - becomes NaN, and
+            # t2_adam_step skips a step with a non-finite gradient norm.  No host synchronisation here; the host raises where it
+            # reads the loss anyway (check_persistent_kernels).
+            call("t2_guard_poison", self._persist_sync.data_ptr() + 4 * 256, proj, R * (M + 1), st)
         self.mark("fwd.dec.proj_gemm")
         mels = torch.empty(B, T, M, dtype=torch.float32, device=self.dev)
         gates = torch.empty(B, T, 1, dtype=torch.float32, device=self.dev)

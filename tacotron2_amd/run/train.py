@@ -84,7 +84,11 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
                 yield {k: v.to(dev) for k, v in b.items()}
     else:
         df = pd.read_csv(dataset_config["train"], delimiter="|", quoting=csv.QUOTE_NONE, engine="c")
-        df = df.iloc[rank::world].reset_index(drop=True)            # utterance sharding across ranks
+        bucket_window = int(training_config.get("bucket_window", 0))
+        if not bucket_window:
+            df = df.iloc[rank::world].reset_index(drop=True)        # utterance sharding across ranks (plain shuffle per rank)
+        # (with length buckets the sampler shards: same permutation on every rank, rank r takes the r-th slice of every sorted
+        #  super-batch, so that all ranks step through batches of similar length - LengthBucketBatchSampler)
         desc = None
         if extensions_config["descriptions"].get("bert_embeddings"):
             desc = [None if (isinstance(x, float)) else x for x in df.description_embedding]
@@ -95,7 +99,7 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
                         **dataset_config["preprocessing"])
         # training.bucket_window (not a reference key): batches of similar text length, see LengthBucketBatchSampler
         loader = TTSDataLoader(ds, batch_size=training_config["batch_size"], shuffle=True, drop_last=True,
-                               bucket_window=int(training_config.get("bucket_window", 0)), seed=rank)
+                               bucket_window=bucket_window, seed=0 if bucket_window else rank, rank=rank, world=world)
         # items and host->device copies of the next batches are prepared by a background thread on its own stream
         prefetch = DevicePrefetcher(loader, _to_dev, dev, depth=int(training_config.get("prefetch_batches", 2)))
         def batches():
@@ -142,26 +146,44 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
         from ..checkpoint import lightning_checkpoint, save_atomic
         save_atomic(lightning_checkpoint(model, tr, epoch=step // steps_per_epoch), path)
 
-    t0, frames = time.time(), 0
+    def healthy(where, loss=None):
+        """Called only where the host synchronises anyway (loss printout, validation, checkpoint): a persistent launch that gave
+        up on a wait has poisoned that step's outputs with NaN and its optimiser step was skipped (engine.forward_tf); training
+        must stop here instead of going on, let alone saving."""
+        tr.engine.check_persistent_kernels()
+        model.tacotron2._engine.check_persistent_kernels()      # (the validation pass runs on the module's own engine)
+        if loss is not None and not all(x == x and abs(x) != float("inf") for x in loss):
+            raise RuntimeError(f"non-finite training loss {loss} at {where}: the optimiser skips such steps, stopping")
+
+    t0 = time.time()
+    frames = torch.zeros((), dtype=torch.int64, device=dev)     # counted on the device: no host synchronisation per step
     it = batches()
     steps_done = 0
+    log_every = int(training_config["args"].get("log_every_n_steps", 50))
     for step in range(start_step, max_steps):
         batch = next(it)
         loss3, _ = tr.train_step(batch)
         steps_done += 1
-        frames += int(batch["mel_spectrogram_len"].sum())
-        if rank == 0 and (step % 50 == 0 or step == max_steps - 1):
-            l = [float(x) for x in loss3.cpu()]
-            dt = time.time() - t0
-            print(f"step {step + 1}/{max_steps} training_gate_loss {l[0]:.5f} training_mel_loss {l[1]:.5f} "
-                  f"training_mel_post_loss {l[2]:.5f} training_loss {sum(l):.5f} lr {tr.lr_at(step):.2e} "
-                  f"{frames * world / max(dt, 1e-9):.0f} mel-frames/s", flush=True)
+        frames += batch["mel_spectrogram_len"].sum()
+        if step % log_every == 0 or step == max_steps - 1:
+            l = [float(x) for x in loss3.cpu()]                 # the step's only host synchronisation, every log_every steps
+            healthy(f"step {step + 1}", l)
+            if rank == 0:
+                dt = time.time() - t0
+                print(f"step {step + 1}/{max_steps} training_gate_loss {l[0]:.5f} training_mel_loss {l[1]:.5f} "
+                      f"training_mel_post_loss {l[2]:.5f} training_loss {sum(l):.5f} lr {tr.lr_at(step):.2e} "
+                      f"{int(frames) * world / max(dt, 1e-9):.0f} mel-frames/s", flush=True)
         if val_loader is not None and (step + 1) % val_every == 0:
             vl = validate()                       # every rank runs it (keeps the ranks in step); rank 0 reports
+            healthy(f"validation after step {step + 1}")
             if rank == 0:
                 print(f"step {step + 1}/{max_steps} validation_loss {vl:.5f}", flush=True)
         if rank == 0 and (step + 1) % ckpt_every == 0 and step + 1 < max_steps:
+            torch.cuda.synchronize()
+            healthy(f"checkpoint after step {step + 1}")
             save(os.path.join(results_dir, "last.ckpt"), step + 1)
+    torch.cuda.synchronize()
+    healthy("the end of training", [float(x) for x in loss3.cpu()] if steps_done else None)
     if rank == 0:
         path = os.path.join(results_dir, "finetuned.ckpt" if finetune else "final.ckpt")
         save(path, max_steps)

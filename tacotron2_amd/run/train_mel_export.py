@@ -56,6 +56,7 @@ def do_train_mel_export(dataset_config: dict, training_config: dict, model_confi
                 _, post, _, _ = model(chars_idx=b["chars_idx"], chars_idx_len=b["chars_idx_len"], teacher_forcing=True,
                                       mel_spectrogram=b["mel_spectrogram"], mel_spectrogram_len=b["mel_spectrogram_len"], **args)
             post = post.cpu()
+            model.tacotron2._engine.check_persistent_kernels()     # (the copy above synchronised) never export a poisoned forward
             for mel_out, n, fn in zip(post, b["mel_spectrogram_len"].cpu().tolist(), b["filename"]):
                 path = os.path.join(results_dir, f"{fn.replace('/', '_')}.np")
                 np.save(path, mel_out[:int(n)].numpy())

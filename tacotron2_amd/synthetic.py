@@ -10,10 +10,19 @@ import torch
 
 
 def ljspeech_batch(batch: int, seed: int = 1234, num_mels: int = 80, num_speakers: int = 0, desc_dim: int = 0,
-                   fixed_shape=None):
+                   fixed_shape=None, shape: str = "ljspeech"):
+    """shape="libritts": lengths of the descriptions-libritts configuration (BASELINE configs[3]; SURVEY.md section 8d: 24 kHz,
+    utterances of at most 10 s).  Fitted to the reference's manifests (data/libritts-train-clean-100.csv joined with
+    data/libritts-durations.csv, 27,948 utterances <= 10 s): text length mean 71.5 / std 42.4 / max 238 (right-skewed: a gamma
+    distribution with those moments), frames = 1 + 24000 * duration // 256 = 5.31 * l + 16.5 + N(0, 63.4) (corr 0.963),
+    16 <= frames <= 938."""
     rng = np.random.default_rng(seed)
     if fixed_shape is not None:
         lens = np.full(batch, fixed_shape[0]); tl = np.full(batch, fixed_shape[1])
+    elif shape == "libritts":
+        k = (71.5 / 42.4) ** 2
+        lens = np.clip(np.round(rng.gamma(k, 71.5 / k, batch)), 2, 238).astype(np.int64)
+        tl = np.clip(np.round(5.31 * lens + 16.5 + rng.normal(0, 63.4, batch)), 16, 938).astype(np.int64)
     else:
         lens = np.clip(np.round(rng.normal(101, 33.6, batch)), 13, 188).astype(np.int64)
         tl = np.clip(np.round(5.68 * lens + rng.normal(0, 54, batch)), 99, 872).astype(np.int64)

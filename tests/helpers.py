@@ -61,3 +61,44 @@ def write_hifigan_checkpoint(hdir, n_mels=80, ch0=16, seed=0):
     path = os.path.join(hdir, "g_00000001")
     torch.save({"generator": sd}, path)
     return path
+
+
+def dekink_masks(P, d, chars_idx, mel, masks, eps=1e-5, training=True):
+    """ReLU has a jump in its derivative at 0: an element whose pre-activation is within fp32 rounding of zero can take
+    either derivative depending on the summation order of the kernel that produced it, and the whole upstream gradient
+    then differs legitimately between two correct fp32 implementations (seen once: tools/debug_b35.py).  This takes such
+    elements out of BOTH sides of a gradient comparison: the dropout scale mask that multiplies the ReLU output is set to
+    zero wherever the oracle's pre-activation is within `eps` of zero (encoder BN-ReLU layers, model/encoder.py:33-44;
+    prenet ReLUs, model/tacotron2.py:85-92).  Layers are handled in order, so a changed mask is seen by the next layer's
+    pre-activations.  Returns (masks with the kink elements dropped, number of elements dropped)."""
+    from oracle import tacotron2_ref as R
+    out = dict(masks)
+    dropped = 0
+    with torch.no_grad():
+        ed = masks.get("enc_drop")
+        if ed is not None:
+            ed = [m.clone() for m in ed]
+            x = P["encoder.embedding.weight"][chars_idx]
+            for li, i in enumerate((0, 4, 8)):
+                x = R.conv1d_cl(x, P[f"encoder.convolutions.{i}.weight"], P[f"encoder.convolutions.{i}.bias"])
+                k = f"encoder.convolutions.{i + 1}"
+                x = R.batch_norm_cl(x, P[k + ".weight"], P[k + ".bias"], P[k + ".running_mean"], P[k + ".running_var"],
+                                    training, None, k)
+                kink = x.abs() < eps
+                dropped += int((kink & (ed[li] != 0)).sum())
+                ed[li][kink] = 0.0
+                x = torch.relu(x) * ed[li]
+            out["enc_drop"] = ed
+        pd = masks.get("prenet_drop")
+        if pd is not None and mel is not None:
+            pd = [m.clone() for m in pd]
+            B, T, M = mel.shape
+            x = torch.cat([torch.zeros(B, 1, M, dtype=mel.dtype), mel], 1)
+            for li, name in enumerate(("prenet.0.weight", "prenet.3.weight")):
+                x = x @ P[name].T
+                kink = (x.abs() < eps) & (x != 0)        # exact zeros (the initial zero frame) have no upstream gradient
+                dropped += int((kink & (pd[li] != 0)).sum())
+                pd[li][kink] = 0.0
+                x = torch.relu(x) * pd[li]
+            out["prenet_drop"] = pd
+    return out, dropped

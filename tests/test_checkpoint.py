@@ -131,6 +131,26 @@ def test_written_checkpoint_loads_into_torch_optimizer_and_round_trips(tmp_path)
         assert torch.equal(tr2.ps.exp_avg[o:o + k], ps.exp_avg[o:o + k]) and torch.equal(tr2.ps.exp_avg_sq[o:o + k], ps.exp_avg_sq[o:o + k])
 
 
+def test_checkpoint_without_scheduler_restores_the_optimizer_lr(tmp_path):
+    """scheduler_milestones = []: no lr_schedulers entry is written (model/tts_model.py:83-90), and on resume Lightning's
+    optimizer.load_state_dict brings back param_groups[0]["lr"] - it replaces the freshly configured lr, including the
+    fine-tune's lr / 10 (run/train.py:110,245).  Same here."""
+    from tacotron2_amd.checkpoint import lightning_checkpoint, restore_trainer, save_atomic
+    from tacotron2_amd.model.tts_model import TTSModel
+    from tacotron2_amd.trainer import Trainer
+    d = _dims()
+    model = TTSModel(lr=2e-3, weight_decay=1e-6, scheduler_milestones=[], device="cpu", **d)
+    tr = Trainer(model.tacotron2.store, lr=2e-3, weight_decay=1e-6, scheduler_milestones=[])
+    tr.ps.init_adam(); tr.global_step = 3
+    path = str(tmp_path / "nosched.ckpt")
+    save_atomic(lightning_checkpoint(model, tr, epoch=0), path)
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    assert ck["lr_schedulers"] == [] and ck["optimizer_states"][0]["param_groups"][0]["lr"] == pytest.approx(2e-3)
+    tr2 = Trainer(model.tacotron2.store, lr=2e-4, weight_decay=1e-6, scheduler_milestones=[5])     # fine-tune style: lr / 10
+    assert restore_trainer(ck, tr2)
+    assert tr2.base_lr == pytest.approx(2e-3) and tr2.milestones == [] and tr2.lr_at(100) == pytest.approx(2e-3)
+
+
 def test_trainable_ranges_exclude_frozen_tensors():
     from tacotron2_amd.model.tts_model import TTSModel
     from tacotron2_amd.trainer import Trainer

@@ -264,6 +264,57 @@ def test_cli_test_command_writes_one_wav_per_manifest_row(tmp_path):
         assert n_ok >= 3, (name, fails)       # the fixture's stop logit falls below zero within a few frames
 
 
+def test_cli_test_correlation_sweeps_the_control_overrides(tmp_path):
+    """`main.py test-correlation` (run/test_correlation.py:30-250): the sampled test manifest once per control-vector override,
+    one directory per override named `str(override)`, numbering from 1 in each.  Weights: the reference-generated `infer_ctrl`
+    fixture (5 controls, small dims, utterances stop after a few frames)."""
+    import wave
+    from helpers import load_golden, params_from, write_hifigan_checkpoint
+    from tacotron2_amd.run.test_correlation import feature_overrides
+    z = load_golden("infer_ctrl")
+    sd = {"tacotron2." + k: v for k, v in params_from(z).items()}
+    hp = dict(lr=1e-3, weight_decay=1e-6, num_chars=39, encoded_dim=32, num_mels=16, prenet_dim=16, att_rnn_dim=32, att_dim=16,
+              rnn_hidden_dim=32, postnet_dim=32, dropout=0.5, controls=True, controls_dim=5)
+    ck = tmp_path / "m.ckpt"
+    torch.save({"state_dict": sd, "hyper_parameters": hp, "global_step": 0, "epoch": 0}, ck)
+    feats = ["f0", "f1", "f2", "f3", "f4"]
+    rows = ["text|wav|speaker_id|" + "|".join(feats)]
+    for spk in (0, 1):
+        rows += [f"{t}|none{spk}{i}.wav|{spk}|0.1|0.2|0.3|0.4|0.5" for i, t in enumerate(
+            ["Hi there.", "A somewhat longer sentence, Dr. Who!", "ok", "Testing: one; two? three."])]
+    csvp = tmp_path / "test.csv"
+    csvp.write_text("\n".join(rows) + "\n")
+    cfg = {"dataset": {"train": "none.csv", "val": "none.csv", "test": str(csvp),
+                       "preprocessing": {"allowed_chars": ALLOWED, "expand_abbreviations": True, "end_token": "^", "num_mels": 16}},
+           "training": {"lr": 1e-3, "batch_size": 4, "weight_decay": 1e-6, "name": "tiny", "args": {"max_steps": 6}},
+           "model": {"scheduler_milestones": [], "args": {"prenet_dim": 16, "att_rnn_dim": 32, "att_dim": 16, "rnn_hidden_dim": 32,
+                                                          "postnet_dim": 32, "dropout": 0.5, "char_embedding_dim": 32}},
+           "extensions": {"speaker_tokens": {"active": False}, "controls": {"active": True, "features": feats}}}
+    cfgp = tmp_path / "cfg.json"
+    cfgp.write_text(json.dumps(cfg))
+    gck = write_hifigan_checkpoint(str(tmp_path / "hifi"), n_mels=16)
+    res = tmp_path / "res"
+    out = _run(["--config", str(cfgp), "--device", "0", "test-correlation", "--speech-dir", "unused", "--checkpoint", str(ck),
+                "--results-dir", str(res), "--samples-per-speaker", "3", "--max-len", "40", "--limit-overrides", "3",
+                "--hifi-gan-checkpoint", gck])
+    want = [str(o) for o in list(feature_overrides(5))[:3]]
+    assert sorted(os.listdir(res)) == sorted(want), os.listdir(res)
+    assert f"0 / 50: {want[0]}" in out                                         # the reference's progress line (:133)
+    lens = {}
+    for w_ in want:
+        d = res / w_
+        fails = set()
+        if os.path.exists(d / "failures.csv"):
+            fails = {int(l.split("|")[0]) for l in open(d / "failures.csv").read().splitlines()}
+        for i in range(1, 7):                                                     # 3 utterances x 2 speakers, numbered from 1
+            with wave.open(str(d / f"{i}.wav"), "rb") as w:
+                assert w.getframerate() == 22050
+                assert (w.getnframes() == 0) == (i in fails) and w.getnframes() % 256 == 0
+                lens.setdefault(w_, []).append(w.getnframes())
+        assert not os.path.exists(d / "7.wav")
+    assert len(lens) == 3
+
+
 def test_device_prefetcher_yields_the_loader_batches_in_order():
     """DevicePrefetcher (background thread + copy stream in front of the training loop): same batches, same order, every epoch;
     a failing item surfaces in the consumer; leaving the loop early stops the thread."""

@@ -13,6 +13,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import tacotron2_ref as R  # noqa: E402
+from tests.helpers import dekink_masks  # noqa: E402
 from tests.test_gpu_model import (MEL_L1_TOL, _dev, _grad_check, build_engine, l1, masks_to_device, mx,  # noqa: E402
                                   random_case)
 
@@ -33,15 +34,19 @@ def _oracle_train(P, d, ci, lens, mel, tl, gate, masks, **kw):
     return [x.detach() for x in o], float(loss), dict(zip(names, grads)), new_stats
 
 
-def _hip_train_and_compare(d, P, case, dev, kw_cpu=None, kw_dev=None, grad_tol=3e-4):
+def _hip_train_and_compare(d, P, case, dev, kw_cpu=None, kw_dev=None, grad_tol=3e-4, check_engine=None):
     ci, lens, mel, tl, gate, masks = case
+    masks, _ = dekink_masks(P, d, ci, mel, masks)      # ReLU-kink elements out of both sides (tests/helpers.py)
     ref, loss, grads, new_stats = _oracle_train(P, d, ci, lens, mel, tl, gate, masks, **(kw_cpu or {}))
     eng, ps = build_engine(d, P, dev)
+    if check_engine is not None:
+        check_engine(eng)
     outs, ctx = eng.forward_tf(ci.to(dev), lens.to(dev), mel.to(dev), tl.to(dev), training=True,
                                masks=masks_to_device(masks, dev), **(kw_dev or {}))
     ps.grad.zero_()
     loss3 = eng.loss_and_grads(outs, ctx, mel.to(dev), gate.to(dev))
     torch.cuda.synchronize()
+    eng.check_persistent_kernels()
     assert l1(outs[0], ref[0]) < MEL_L1_TOL and l1(outs[1], ref[1]) < MEL_L1_TOL, (l1(outs[0], ref[0]), l1(outs[1], ref[1]))
     assert mx(outs[0], ref[0]) < 1e-3 and mx(outs[1], ref[1]) < 2e-3
     assert mx(outs[3], ref[3]) < 2e-5
@@ -109,6 +114,93 @@ def test_descriptions_libritts_dims_train_step_matches_oracle():
     desc = torch.randn(B, 768, generator=g)
     _hip_train_and_compare(d, P, case, dev, kw_cpu=dict(speaker_id=spk, description_embeddings=desc),
                            kw_dev=dict(speaker_id=spk.to(dev), description_embeddings=desc.to(dev)))
+
+
+def _bench_length_case(d, B, L, T, seed, dev):
+    """Ragged batch at the benchmarked sequence lengths: utterance 0 has the full text length, the last one the full frame
+    count (random_case), the others about half - like a bench batch, where padding is 35 % of the frames."""
+    return _ragged_case(d, B, L, T, seed, dev)
+
+
+def _default_schedule(eng):
+    """The bench's schedule, untouched: 64-frame forward chunks with the persistent decoder-LSTM launches, 80-frame backward
+    chunks with ramps, weight gradients in groups of four chunks, deferred weight-gradient GEMMs."""
+    from tacotron2_amd.engine import _chunk_sizes
+    assert (eng.chunk, eng.chunk_bwd, eng.dec_chain, eng.wgrad_group) == (64, 80, "persistent", 4)
+    assert eng.ramp_chunks and eng.defer_wgrads and eng.chunk_att_wgrads
+    assert _chunk_sizes(160, eng.chunk) == [64, 32, 32, 16, 8, 8]           # a full 64-frame persistent launch + the ramp
+    assert _chunk_sizes(160, eng.chunk_bwd) == [80, 40, 20, 10, 10]         # five backward chunks: two weight-gradient groups
+
+
+def test_vanilla_dims_bench_lengths_train_step_matches_oracle():
+    """configs[1] dims AT THE BENCHMARKED LENGTHS: L = 188 characters (the bench batch's text length), T = 160 frames with the
+    default schedule (so: attn_bwd_dw / attn_bwd_ds at Ad = 128, Ef = 512 and L = 188; the persistent decoder-LSTM chain at
+    S = 64 steps and H = 1024; split-K weight gradients accumulated over two pipeline groups at H = 1024; the ramped chunks).
+    Outputs, loss, EVERY parameter gradient and the BN running statistics against the oracle."""
+    dev = _dev()
+    d = R.default_dims(speaker_tokens=True, num_speakers=4)
+    P = R.init_params(d, seed=188)
+    B, L, T = 2, 188, 160
+    case = _bench_length_case(d, B, L, T, 1880, dev)
+    spk = torch.tensor([1, 3], dtype=torch.int32)
+    _hip_train_and_compare(d, P, case, dev, kw_cpu=dict(speaker_id=spk), kw_dev=dict(speaker_id=spk.to(dev)),
+                           check_engine=_default_schedule)
+
+
+def test_descriptions_libritts_dims_bench_lengths_train_step_matches_oracle():
+    """The same at configs[3] dims: E' = 640 (description embeddings) + 562 speaker tokens, L = 188, T = 160, default schedule
+    (config/descriptions-libritts.json:21,42-52 of the reference)."""
+    dev = _dev()
+    d = R.default_dims(speaker_tokens=True, num_speakers=562, description_embeddings=True, description_embeddings_dim=768)
+    P = R.init_params(d, seed=640)
+    B, L, T = 2, 188, 160
+    case = _bench_length_case(d, B, L, T, 6400, dev)
+    g = torch.Generator().manual_seed(64)
+    spk = torch.randint(0, 562, (B,), generator=g, dtype=torch.int32)
+    desc = torch.randn(B, 768, generator=g)
+    _hip_train_and_compare(d, P, case, dev, kw_cpu=dict(speaker_id=spk, description_embeddings=desc),
+                           kw_dev=dict(speaker_id=spk.to(dev), description_embeddings=desc.to(dev)),
+                           check_engine=_default_schedule)
+
+
+def test_descriptions_libritts_full_size_training_step_properties():
+    """BASELINE configs[3] at its real per-GPU size: E' = 640, 562 speaker tokens, batch 64 over 2+ GPUs = 32 utterances per
+    GPU, LibriTTS-shaped lengths (<= 10 s at 24 kHz: T <= 938; tacotron2_amd/synthetic.py).  No oracle at this size:
+    attention rows are distributions supported on the text, masked tails are exactly 0 / -1000, BN running statistics move,
+    every gradient is finite, the loss decreases on a fixed batch, the persistent launches report no timeout."""
+    from tacotron2_amd.init import init_parameters
+    from tacotron2_amd.params import ParamStore
+    from tacotron2_amd.synthetic import ljspeech_batch
+    from tacotron2_amd.trainer import Trainer
+    dev = _dev()
+    dims = dict(num_chars=39, encoded_dim=512, encoder_kernel_size=5, num_mels=80, prenet_dim=256, att_rnn_dim=1024,
+                att_dim=128, rnn_hidden_dim=1024, postnet_dim=512, dropout=0.5, speaker_tokens=True, num_speakers=562,
+                description_embeddings=True, description_embeddings_dim=768)
+    ps = ParamStore(dims, dev); init_parameters(ps, 0)
+    tr = Trainer(ps, lr=1e-3, weight_decay=1e-6)
+    batch = {k: v.to(dev) for k, v in ljspeech_batch(32, seed=1234, num_speakers=562, desc_dim=768, shape="libritts").items()}
+    assert batch["mel_spectrogram"].shape[1] > 872 and batch["mel_spectrogram"].shape[1] <= 938
+    losses = []
+    for step in range(4):
+        loss3, (mels, post, gates, al) = tr.train_step(batch)
+        losses.append(float(loss3.sum()))
+        if step == 0:
+            assert bool(torch.isfinite(ps.grad).all())
+    torch.cuda.synchronize()
+    tr.engine.check_persistent_kernels()
+    assert all(np.isfinite(losses)) and losses[-1] < 0.6 * losses[0], losses
+    cl, ml = batch["chars_idx_len"], batch["mel_spectrogram_len"]
+    assert float((al.sum(-1) - 1).abs().max()) < 1e-4
+    for b in (0, 7, 31):
+        assert float(al[b, :, int(cl[b]):].abs().max()) == 0.0
+        if int(ml[b]) < mels.shape[1]:
+            assert float(mels[b, int(ml[b]):].abs().max()) == 0.0 and float(post[b, int(ml[b]):].abs().max()) == 0.0
+            assert bool((gates[b, int(ml[b]):] == -1000.0).all())
+    assert float((ps.Bf["postnet.postnet.1.running_mean"]).abs().max()) > 0
+    # the speaker table only receives gradient in the rows of this batch's speakers
+    gspk = ps.G["speaker_embedding.weight"]
+    used = torch.zeros(562, dtype=torch.bool, device=dev); used[batch["speaker_id"].long()] = True
+    assert float(gspk[~used].abs().max()) == 0.0 and float(gspk[used].abs().max()) > 0.0
 
 
 def test_vanilla_dims_chunked_pipeline_matches_oracle():

@@ -61,3 +61,27 @@ def test_unsupported_upsampler_shape_fails_loudly():
           "ups.0.bias": torch.zeros(4)}
     with pytest.raises(NotImplementedError):
         Generator(cfg, "cuda:0").load_state_dict(sd)
+
+
+def test_vocoding_a_padded_row_differs_from_vocoding_the_cut_row_only_in_the_tail():
+    """run/test.py:167-181 vocodes the whole padded batch row (masked frames are zeros) and cuts the waveform at
+    mel_length * 256.  The generator's receptive field spans many frames, so this is NOT the same as vocoding `mel[:n]`: the
+    last samples see the activations of the zero frames that follow instead of zero margins.  tacotron2_amd/run/test.py follows
+    the reference; this pins the reason (oracle on both inputs, reference fixture weights) and that the product reproduces the
+    padded-row result."""
+    from oracle import hifigan_ref as H
+    from tacotron2_amd.hifigan import Generator
+    z = load_golden("hifigan")
+    name = "v1"
+    sd = {k[len(name) + 4:]: torch.from_numpy(v) for k, v in z.items() if k.startswith(name + ".sd.")}
+    cfg = {k[len(name) + 5:]: v.tolist() for k, v in z.items() if k.startswith(name + ".cfg.")}
+    mel = torch.from_numpy(z[name + ".mel"])[0]                                    # (80, T)
+    n = mel.shape[1] // 2
+    padded = mel.clone(); padded[:, n:] = 0.0
+    up = int(np.prod(cfg["upsample_rates"]))
+    folded = {k: v.double() for k, v in H.fold_weight_norm(sd).items()}
+    ref_pad = H.generator_fwd(folded, cfg, padded.double())[:n * up]
+    ref_cut = H.generator_fwd(folded, cfg, mel[:, :n].double())
+    assert float((ref_pad - ref_cut).abs().max()) > 1e-2         # the two procedures differ (here, 6 frames, even everywhere)
+    got = Generator(cfg, "cuda:0").load_state_dict(sd)(padded.cuda())[0, 0, :n * up].double().cpu()
+    assert float((got - ref_pad).abs().max()) < 2e-5

@@ -158,3 +158,33 @@ def test_pipeline_chunk_sizes_cover_the_frames_and_shrink_at_the_end():
     assert _chunk_sizes(872, 80)[-4:] == [40, 20, 10, 10]
     assert _chunk_sizes(872, 64, ramp_at_end=False) == [64] * 13 + [40]
     assert _chunk_sizes(37, 8) == [8, 8, 8, 8, 5]            # chunks below 16 frames are not ramped
+
+
+def test_length_bucket_sampler_shards_similar_lengths_across_ranks():
+    """Data-parallel batches: all ranks draw one permutation, rank r takes the r-th slice of every sorted super-batch.  The
+    ranks see disjoint utterances, run the same number of steps, and at every step their batches have similar lengths - the
+    step's global padding (Trainer.global_pad pads every shard to the longest batch of the step) stays near the single-rank
+    bucketed ratio instead of falling back to the ratio of random batches."""
+    from tacotron2_amd.datasets.tts_dataset import LengthBucketBatchSampler
+    rng = np.random.default_rng(0)
+    lengths = np.clip(np.round(rng.normal(101, 33.6, 13100)), 13, 188).astype(int).tolist()
+    world, bs = 8, 32
+    per_rank = [list(LengthBucketBatchSampler(lengths, bs, window=16, seed=0, rank=r, world=world)) for r in range(world)]
+    steps = len(per_rank[0])
+    assert steps == 13100 // (bs * world) and all(len(p) == steps for p in per_rank)
+    seen = [i for p in per_rank for b in p for i in b]
+    assert len(seen) == len(set(seen)) == steps * bs * world                    # disjoint, every utterance at most once
+    L = np.array(lengths)
+    padded = sum(max(L[p[s]].max() for p in per_rank) * bs * world for s in range(steps))
+    valid = sum(L[p[s]].sum() for p in per_rank for s in range(steps))
+    ratio = padded / valid
+    # independent per-rank buckets (seed = rank, the old behaviour): the longest of 8 unrelated batches sets the shape
+    indep = [list(LengthBucketBatchSampler(lengths[r::world], bs, window=16, seed=r)) for r in range(world)]
+    st2 = min(len(p) for p in indep)
+    Ls = [np.array(lengths[r::world]) for r in range(world)]
+    padded2 = sum(max(Ls[r][indep[r][s]].max() for r in range(world)) * bs * world for s in range(st2))
+    valid2 = sum(Ls[r][indep[r][s]].sum() for r in range(world) for s in range(st2))
+    assert ratio < 1.12 and ratio < 0.8 * (padded2 / valid2), (ratio, padded2 / valid2)
+    # one rank: unchanged behaviour (every utterance once, drop_last)
+    one = list(LengthBucketBatchSampler(lengths, bs, window=16, seed=0))
+    assert len(one) == 13100 // bs and len({i for b in one for i in b}) == len(one) * bs
