@@ -45,9 +45,11 @@ def decoder_step_flops(B, L, Ef, P=256, A=1024, D=1024, Ad=128, M=80, F=32, Kl=3
     return B * per
 
 
-def cpu_baseline(dims, batch, t_cap, b_cap):
+def cpu_baseline(dims, batch, t_cap=200, b_cap=32, timed_steps=3, n_inf=100):
     """Oracle (CPU restatement pinned to the reference, oracle/tacotron2_ref.py) timed on this host's cores on a bounded
-    sample of the same workload: the first b_cap utterances, frames capped at t_cap, one fwd+loss+bwd+Adam step."""
+    sample of the same workload, by SURVEY.md section 8d's protocol: same synthetic batch, fp32, all of the process's cores,
+    1 warm-up + 3 timed teacher-forced training steps (fwd + loss + bwd + clip + Adam) at B = 32 with the frames capped at 200,
+    and 100 autoregressive inference steps at B = 32."""
     from oracle import tacotron2_ref as R
     # threads actually used: the process's CPU share (the GPU box gives 16 cores per GPU), never the machine total
     try:
@@ -58,9 +60,7 @@ def cpu_baseline(dims, batch, t_cap, b_cap):
     torch.set_num_threads(cores)
     d = R.default_dims(**dims)
     P = R.init_params(d, seed=0)
-    for k, v in P.items():
-        if v.is_floating_point() and not R.is_buffer(k):
-            v.requires_grad_(True)
+    names = [k for k, v in P.items() if v.is_floating_point() and not R.is_buffer(k)]
     ci = batch["chars_idx"][:b_cap]; cl = batch["chars_idx_len"][:b_cap]
     L = int(cl.max()); ci = ci[:, :L]
     tl = torch.clamp(batch["mel_spectrogram_len"][:b_cap], max=t_cap)
@@ -70,32 +70,42 @@ def cpu_baseline(dims, batch, t_cap, b_cap):
     g = torch.Generator().manual_seed(0)
     sm = lambda shape, p: (torch.rand(shape, generator=g) >= p).float() / (1 - p)
     Pn, M = d["postnet_dim"], d["num_mels"]
-    masks = dict(enc_drop=[sm((b_cap, L, d["encoded_dim"]), 0.5) for _ in range(3)],
-                 prenet_drop=[sm((b_cap, T + 1, d["prenet_dim"]), 0.5) for _ in range(2)],
-                 att_drop=sm((T, b_cap, d["att_rnn_dim"]), 0.1), dec_drop=sm((T, b_cap, d["rnn_hidden_dim"]), 0.1),
-                 post_drop=[sm((b_cap, T, c), 0.5) for c in (Pn, Pn, Pn, Pn, M)])
+    m_ = {k: torch.zeros_like(P[k]) for k in names}
+    v_ = {k: torch.zeros_like(P[k]) for k in names}
+
+    def train_step(step):
+        masks = dict(enc_drop=[sm((b_cap, L, d["encoded_dim"]), 0.5) for _ in range(3)],
+                     prenet_drop=[sm((b_cap, T + 1, d["prenet_dim"]), 0.5) for _ in range(2)],
+                     att_drop=sm((T, b_cap, d["att_rnn_dim"]), 0.1), dec_drop=sm((T, b_cap, d["rnn_hidden_dim"]), 0.1),
+                     post_drop=[sm((b_cap, T, c), 0.5) for c in (Pn, Pn, Pn, Pn, M)])
+        Pc = {k: (v.detach().requires_grad_(True) if k in m_ else v) for k, v in P.items()}
+        new_stats = {}
+        o = R.tacotron2_fwd(Pc, d, ci, cl, True, mel, tl, speaker_id=spk, training=True, masks=masks, new_stats=new_stats)
+        loss = R.tts_loss(o[0], o[1], o[2], mel, gate)[0]
+        grads = torch.autograd.grad(loss, [Pc[k] for k in names])
+        coef, _ = R.clip_coef(list(grads), 1.0)
+        with torch.no_grad():
+            for k, gr in zip(names, grads):
+                P[k], m_[k], v_[k] = R.adam_l2_step(P[k].detach(), gr * coef, m_[k], v_[k], step, 1e-3, 1e-6)
+            P.update(new_stats)
+
+    train_step(1)                                    # warm-up (allocator, thread pool)
     t0 = time.perf_counter()
-    o = R.tacotron2_fwd(P, d, ci, cl, True, mel, tl, speaker_id=spk, training=True, masks=masks)
-    loss = R.tts_loss(o[0], o[1], o[2], mel, gate)[0]
-    names = [k for k, v in P.items() if v.requires_grad]
-    grads = torch.autograd.grad(loss, [P[k] for k in names])
-    coef, _ = R.clip_coef(list(grads), 1.0)
-    with torch.no_grad():
-        for k, gr in zip(names, grads):
-            R.adam_l2_step(P[k], gr * coef, torch.zeros_like(gr), torch.zeros_like(gr), 1, 1e-3, 1e-6)
+    for s_ in range(timed_steps):
+        train_step(2 + s_)
     dt = time.perf_counter() - t0
-    frames = int(tl.sum())
-    # secondary metric on the CPU too: autoregressive inference steps of the same oracle, eval mode, the
-    # same utterances, a bounded number of frames (random weights never emit a stop)
-    n_inf = 40
+    frames = int(tl.sum()) * timed_steps
+    # secondary metric on the CPU too: autoregressive inference steps of the same oracle, eval mode, the same utterances
+    # (random weights never emit a stop, so exactly n_inf steps run)
     with torch.no_grad():
         Pi = {k: v.detach() for k, v in P.items()}
         t1 = time.perf_counter()
         R.tacotron2_fwd(Pi, d, ci, cl, False, speaker_id=spk, max_len_override=n_inf, training=False, masks={})
         dti = time.perf_counter() - t1
     return dict(value=frames / dt, unit="mel-frames/s", cores=cores, kind="port",
-                sample=f"oracle/tacotron2_ref.py, 1 train step (fwd+loss+bwd+clip+Adam), first {b_cap} utterances of the "
-                       f"bench batch, frames capped at {t_cap} (L={L}, T={T}, {frames} valid frames), {dt:.1f} s",
+                sample=f"oracle/tacotron2_ref.py, 1 warm-up + {timed_steps} timed train steps (fwd+loss+bwd+clip+Adam), first "
+                       f"{b_cap} utterances of the bench batch, frames capped at {t_cap} (L={L}, T={T}, {int(tl.sum())} valid "
+                       f"frames per step), {dt:.1f} s timed",
                 decode_steps_per_s=n_inf / dti,
                 decode_sample=f"{n_inf} autoregressive steps, batch {b_cap}, includes encoder and postnet of the call, {dti:.1f} s")
 
@@ -114,6 +124,8 @@ def main():
                     help="the reference's training.float32_matmul_precision for the GEMMs; the judged line is 'highest' (fp32-exact)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0 (needs --backend gloo)")
+    ap.add_argument("--sync-bn", action="store_true", help="BatchNorm statistics over all ranks (training.sync_batchnorm)")
+    ap.add_argument("--one-allreduce", action="store_true", help="a single gradient all-reduce after the backward instead of two buckets")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -143,7 +155,8 @@ def main():
     set_float32_matmul_precision(args.matmul_precision)
     ps = ParamStore(VANILLA, dev)
     init_parameters(ps, seed=0)           # identical replicas on every rank
-    tr = Trainer(ps, lr=1e-3, weight_decay=1e-6, scheduler_milestones=(50000, 75000))
+    tr = Trainer(ps, lr=1e-3, weight_decay=1e-6, scheduler_milestones=(50000, 75000), sync_bn=args.sync_bn,
+                 overlap_allreduce=not args.one_allreduce)
     cpu_batch = ljspeech_batch(args.batch, seed=1234 + rank, num_speakers=4,
                                fixed_shape=(160, 860) if args.fixed_shape else None)
     batch = {k: v.to(dev) for k, v in cpu_batch.items()}
@@ -252,7 +265,10 @@ def main():
                    data="synthetic",
                    config=dict(workload="LJSpeech single-speaker train (vanilla-lj-hifi-stop.json dims), batch 32 per GPU, fp32",
                                global_batch=B * world, L=L, T=T, valid_frames_per_step=float(frames[0]),
-                               padded_frames_per_step=float(frames[1]), parallelism=f"dp{world}"),
+                               padded_frames_per_step=float(frames[1]), parallelism=f"dp{world}",
+                               sync_batchnorm=bool(tr.sync_bn),
+                               allreduce=("none" if world == 1 else "2 buckets, tail overlapped with the encoder backward"
+                                          if tr.overlap_allreduce else "1 call after the backward")),
                    padded_frames_per_s=float(frames[1]) * args.steps / dt,
                    loss=[float(x) for x in loss3.cpu()],
                    roofline=dict(bound="hbm", kernel="teacher-forced decoder frame loop, forward (pre_att GEMM + attention "
@@ -272,7 +288,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             dims = {k: v for k, v in VANILLA.items()}
             print("[bench] GPU timing done; timing the CPU oracle baseline (bounded sample)...", file=sys.stderr, flush=True)
-            out["cpu_baseline"] = cpu_baseline(dims, cpu_batch, t_cap=400, b_cap=32)
+            out["cpu_baseline"] = cpu_baseline(dims, cpu_batch, t_cap=200, b_cap=min(32, args.batch))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()                       # every rank leaves together

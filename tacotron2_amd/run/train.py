@@ -60,8 +60,12 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
     max_steps = max_steps_override or training_config["args"]["max_steps"]
     model = TTSModel(device=dev, **kw)
     start_step = 0
+    # training.sync_batchnorm (not a reference key; Lightning's Trainer(sync_batchnorm=...) name): BatchNorm batch statistics over
+    # all ranks' shards, so that N x b utterances give the single-device result on the N*b batch.  Default: per shard.
     tr = Trainer(model.tacotron2.store, lr=kw["lr"], weight_decay=kw["weight_decay"],
-                 scheduler_milestones=kw["scheduler_milestones"], max_norm=1.0)
+                 scheduler_milestones=kw["scheduler_milestones"], max_norm=1.0,
+                 sync_bn=bool(training_config.get("sync_batchnorm", False)),
+                 overlap_allreduce=bool(training_config.get("overlap_allreduce", True)))
     if resume_ckpt:
         # trainer.fit(ckpt_path=...) (run/train.py:245): weights, global_step, Adam moments and the scheduler state all come
         # back, for plain resumes and for --finetune alike (the fine-tune then runs exactly `finetune_steps` more steps)

@@ -3,8 +3,9 @@ Adam(L2) + MultiStepLR, i.e. what Lightning does around TTSModel.training_step i
 (run/train.py:210-243, model/tts_model.py:78-91,165-253), on the HIP engine.
 
 Data parallelism (new relative to the reference, which is single-device): one process per GPU, utterances sharded
-across ranks, ONE all-reduce of the flat fp32 gradient buffer per step over RCCL/xGMI (torch.distributed backend
-"nccl"), then identical clip + Adam on every rank.  Shards are padded to the global (L, T) maxima so that the mean of
+across ranks, the flat fp32 gradient buffer all-reduced per step over RCCL/xGMI (torch.distributed backend "nccl") - as
+two buckets, the larger one overlapped with the encoder backward (overlap_allreduce), or as ONE call - then identical
+clip + Adam on every rank.  Shards are padded to the global (L, T) maxima so that the mean of
 the per-rank loss means equals the single-device loss on the concatenated batch (the loss is a plain mean over padded
 tensors, model/tts_model.py:197-199).  BatchNorm statistics are per shard (the reference has no multi-device
 behaviour to match).
@@ -22,7 +23,7 @@ from .params import ParamStore
 
 class Trainer:
     def __init__(self, ps: ParamStore, lr: float, weight_decay: float, scheduler_milestones: Sequence[int] = (),
-                 max_norm: float = 1.0, seed: int = 1234, sync_bn: bool = False):
+                 max_norm: float = 1.0, seed: int = 1234, sync_bn: bool = False, overlap_allreduce: bool = True):
         self.ps = ps
         self.engine = Engine(ps)
         self.base_lr, self.weight_decay, self.max_norm = lr, weight_decay, max_norm
@@ -38,6 +39,20 @@ class Trainer:
         self.sync_bn = bool(sync_bn) and self.world > 1
         if self.sync_bn:
             self.engine.sync_bn_group = dist.group.WORLD
+        # overlap_allreduce: the gradient buffer is reduced as two buckets.  The tail [prenet.0.weight, end) - 80 % of the bytes:
+        # both decoder cells, attention, projection, postnet - is complete when the backward frame loop and its weight-gradient
+        # GEMMs are; its all-reduce is started there (behind the engine's side stream) and runs next to the encoder backward
+        # (BiLSTM recurrence + convolutions, ~2.6 ms of latency-bound launches).  The head (encoder, speaker table, description
+        # linear: 22 MB) follows when the backward ends.  Same sums, same result as one all-reduce.
+        self.overlap_allreduce = bool(overlap_allreduce) and self.world > 1
+        self._tail_start = ps.offsets["prenet.0.weight"]
+        self._tail_work = None
+        if self.overlap_allreduce:
+            self.engine.grad_tail_hook = self._start_tail_allreduce
+
+    def _start_tail_allreduce(self):
+        # (called by Engine.backward_tf with its side stream current: the collective is ordered behind that stream's work)
+        self._tail_work = dist.all_reduce(self.ps.grad[self._tail_start:], async_op=True)
 
     def trainable_ranges(self):
         """[start, end) element ranges of the flat buffer that the optimizer updates: everything except the frozen tensors
@@ -98,7 +113,12 @@ class Trainer:
         ps.grad.zero_()
         loss3 = eng.loss_and_grads(outs, ctx, mel, batch["gate"])
         if self.world > 1:
-            dist.all_reduce(ps.grad)              # ONE flat fp32 buffer over RCCL/xGMI
+            if self._tail_work is not None:       # two buckets: the tail has been in flight since the frame loop ended
+                dist.all_reduce(ps.grad[:self._tail_start])
+                self._tail_work.wait()            # (the current stream waits for the collective; no host block on RCCL)
+                self._tail_work = None
+            else:
+                dist.all_reduce(ps.grad)          # ONE flat fp32 buffer over RCCL/xGMI
             eng.mark("allreduce")
         # Frozen tensors (requires_grad=False in the reference: grad None) take no part in the step: their gradients are
         # excluded from the global-norm clip (Lightning's clip_grad_norm_ skips them) and neither the parameters nor their

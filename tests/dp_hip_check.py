@@ -2,8 +2,9 @@
 tests/test_gpu_dp.py through torch.distributed.run, 2 ranks sharing cuda:0 over gloo; RCCL needs one GPU per rank).
 
 Each rank runs the PRODUCT path - Trainer.train_step on its shard of utterances: global (L, T) padding, forward, loss,
-backward with synchronised BatchNorm statistics, ONE all-reduce of the flat gradient buffer, clip + Adam with the 1/world
-scale - with the rows of one shared set of dropout masks.  Rank 0 then repeats the step in one process on the whole batch
+backward with synchronised BatchNorm statistics, the all-reduce of the flat gradient buffer (two buckets, the tail started
+behind the engine's side stream while the encoder backward runs; `--one-allreduce`: a single call), clip + Adam with the
+1/world scale - with the rows of one shared set of dropout masks.  Rank 0 then repeats the step in one process on the whole batch
 (same parameters, same masks) and compares: loss, every parameter gradient (3e-4 of the tensor's scale), the clip norm, the
 BatchNorm running statistics, and that both ranks hold bit-identical parameters after the update."""
 import os
@@ -34,8 +35,9 @@ def main():
     ci, lens, mel, tl, gate, masks = random_case(d, Bt, L, T, 41, dev)
     spk = torch.tensor([0, 3, 1, 1, 2, 0], dtype=torch.int32)
     ps = ParamStore(d, dev); ps.load_state_dict(P)
-    tr = Trainer(ps, lr=1e-3, weight_decay=1e-6, max_norm=1.0, sync_bn=sync_bn)
-    assert tr.world == world and tr.sync_bn == sync_bn
+    overlap = "--one-allreduce" not in sys.argv
+    tr = Trainer(ps, lr=1e-3, weight_decay=1e-6, max_norm=1.0, sync_bn=sync_bn, overlap_allreduce=overlap)
+    assert tr.world == world and tr.sync_bn == sync_bn and tr.overlap_allreduce == overlap
     per = Bt // world
     sl = slice(rank * per, (rank + 1) * per)
     Lr, Tr = int(lens[sl].max()), int(tl[sl].max())                 # the shard arrives padded to ITS OWN maxima

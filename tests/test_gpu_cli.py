@@ -153,6 +153,24 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
     assert all(np.isfinite(d["loss"]))
 
 
+def test_bench_four_ranks_rehearsal_on_one_gpu(tmp_path):
+    """`bench.py --gpus 4` as the driver launches it, rehearsed with four ranks on cuda:0 over gloo (the GPU box admits six
+    processes on its card; the 8-rank run needs the 8-GPU node and is the driver's): global batch = 4 x the per-rank batch,
+    every rank padded to the global shape, the two-bucket all-reduce, one JSON line from rank 0."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", "29614", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
+           "--batch", "3", "--backend", "gloo", "--share-gpu"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                                     # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["config"]["global_batch"] == 12 and d["config"]["parallelism"] == "dp4"
+    assert d["value"] > 0 and d["scaling"] == "weak" and all(np.isfinite(d["loss"]))
+    assert d["config"]["sync_batchnorm"] is False and d["config"]["allreduce"] == "2 buckets, tail overlapped with the encoder backward"
+    assert "cpu_baseline" not in d and d["decode"] is None                     # N = 1 only
+
+
 def test_cli_vanilla_ljspeech_stop_config_batch2_ten_steps(tmp_path):
     """BASELINE configs[0]: config/vanilla-ljspeech-stop.json at batch 2 for 10 train steps.  The reference runs this on
     CPU; this package has no CPU product path by design (the oracle must not become one), so the configuration is

@@ -27,3 +27,10 @@ def test_two_rank_step_with_per_shard_bn_runs_and_keeps_replicas_identical():
     the whole-batch step by construction, replicas must still end bit-identical."""
     r = _run(["--per-shard-bn"], 29622)
     assert r.returncode == 0 and "DP_CHECK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_two_rank_step_with_a_single_allreduce_call():
+    """Trainer(overlap_allreduce=False): ONE all-reduce of the whole flat buffer after the backward (the default reduces it as two
+    buckets and starts the larger one while the encoder backward runs; the tests above cover that path)."""
+    r = _run(["--one-allreduce"], 29623)
+    assert r.returncode == 0 and "DP_CHECK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

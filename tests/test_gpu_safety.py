@@ -54,7 +54,9 @@ def test_engine_falls_back_to_step_launches_without_residency():
     loss_s, _ = tr2.train_step(batch)
     torch.cuda.synchronize()
     assert tr2.engine._persist_sync is None                        # per-step launches on the side stream instead
-    assert torch.allclose(loss_p, loss_s, rtol=1e-6, atol=1e-9) and torch.allclose(ps.flat, ps2.flat, rtol=1e-5, atol=1e-7)
+    assert torch.allclose(loss_p, loss_s, rtol=1e-6, atol=1e-9)
+    # same gradients (compared before Adam, whose first update is ~lr * sign(g) and amplifies rounding noise of tiny elements)
+    assert float((ps.grad - ps2.grad).abs().max()) < 1e-5 * float(ps.grad.abs().max())
 
 
 def test_timed_out_persistent_launch_poisons_the_step_and_raises():
