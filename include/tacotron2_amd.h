@@ -268,13 +268,6 @@ typedef struct {
                                         zero-filled by the caller; read by the per-frame products of dgates[t+1] */
     uint64_t* clk;                   /* diagnostic, normally NULL: 32 device words, s_memtime stamps of workgroup (0,0) at phase
                                         boundaries of the dw kernel [16..19] and the ds kernel [24..30] */
-    /* Optional co-scheduled recurrence (mirror of T2AttnSeq.co_step): step i of an independent LSTM back-propagation (the
-     * decoder LSTM's BPTT of frames the attention chain reaches LATER) runs inside the products launch of the i-th frame of this
-     * call - the launch that already holds the two K = 4A products of dgates[t+1], kernels of the same kind (packed transposed
-     * weight stream, x16-tiled gradients), so the hosted step ends with its hosts instead of stretching a latency-bound kernel.
-     * Needs the packed path (wtpacked, dg_next, no dg2) and the same B.  Steps beyond the frame range run as plain launches at
-     * the end of the call. */
-    const T2LstmBwdStep* co_step; const T2LstmBwdStride* co_inc; int co_steps;
 } T2AttnSeqBwd;
 int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream);
 

@@ -958,14 +958,7 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
     T2_REQUIRE(!a->dgates_t || A % 16 == 0, "t2_attn_seq_bwd: dgates_t needs A % 16 == 0");
     const int thi = (a->t_hi == 0 && a->t_lo == 0) ? T : a->t_hi, tlo = (a->t_hi == 0 && a->t_lo == 0) ? 0 : a->t_lo;
     T2_REQUIRE(tlo >= 0 && thi <= T && tlo <= thi, "t2_attn_seq_bwd: bad frame range");
-    T2LstmBwdStep s2[3];
-    T2LstmBwdStep co;
-    int co_left = 0;
-    if (a->co_step && a->co_steps > 0) {
-        T2_REQUIRE(a->co_inc != nullptr, "t2_attn_seq_bwd: co_inc required with co_step");
-        co = *a->co_step; co_left = a->co_steps;
-        T2_REQUIRE(co.wtpacked && co.dg_next && !co.dg2 && co.B == B, "t2_attn_seq_bwd: the hosted step needs the packed path and the same B");
-    }
+    T2LstmBwdStep s2[2];
     for (int t = thi - 1; t >= tlo; --t) {
         const bool last = (t == T - 1);
         const float* zrow = Z + (long)(t + 1) * B * ldz;
@@ -986,13 +979,7 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         r.ext1 = a->dh_ext + (long)t * B * a->ld_dh; r.ldx1 = a->ld_dh;
         r.dx_out = a->dh_rec; r.lddx = A;
         if (a->dgates_t) r.dgt_next = a->dgates_t + (long)(t + 1) * zts;
-        if (co_left > 0) {     // the hosted BPTT step rides in this launch (third descriptor)
-            s2[2] = co;
-            T2_TRY(t2_lstm_step_bwd_launch(s2, 3, st));
-            t2_lstm_bwd_advance(co, *a->co_inc); --co_left;
-        } else {
-            T2_TRY(t2_lstm_step_bwd_launch(s2, 2, st));
-        }
+        T2_TRY(t2_lstm_step_bwd_launch(s2, 2, st));
         // (2),(3) attention backward
         AttnBwdK k;
         memset(&k, 0, sizeof(k));
@@ -1027,10 +1014,6 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         c.dg_out = Z + (long)t * B * ldz; c.ldgo = ldz;
         if (a->dgates_t) c.dgt_out = a->dgates_t + (long)t * zts;
         T2_TRY(t2_lstm_step_bwd_launch(&c, 1, st));
-    }
-    for (; co_left > 0; --co_left) {   // hosted steps that found no frame to ride in
-        T2_TRY(t2_lstm_step_bwd_launch(&co, 1, st));
-        t2_lstm_bwd_advance(co, *a->co_inc);
     }
     T2_CHECK_LAUNCH();
     return T2_OK;

@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256, 1) void lstm_step_bwd_fast_kernel(BwdK2 pp) {
 }
 
 int launch_bwd(const T2LstmBwdStep* steps, int n, hipStream_t st) {
-    T2_REQUIRE(n >= 1 && n <= 3, "lstm bwd step: n must be 1, 2 or 3");
+    T2_REQUIRE(n == 1 || n == 2, "lstm bwd step: n must be 1 or 2");
     BwdK2 kk;
     for (int i = 0; i < n; ++i) { T2_TRY(t2_lstm_check_bwd(steps[i])); t2_lstm_to_bk(steps[i], kk.s[i]); }
     bool fast = true;
@@ -481,7 +481,7 @@ int launch_bwd(const T2LstmBwdStep* steps, int n, hipStream_t st) {
     for (int i = 0; i < n; ++i)
         T2_REQUIRE((!steps[i].dgt_next && !steps[i].dgt_out) || (fast && steps[i].H % 16 == 0 && t2_aligned16(steps[i].dgt_next)),
                    "lstm bwd step: x16-tiled operands need the packed path and H % 16 == 0");
-    for (int i = n; i < 3; ++i) kk.s[i] = kk.s[0];
+    for (int i = n; i < 2; ++i) kk.s[i] = kk.s[0];
     int maxcols = steps[0].ncols;
     for (int i = 1; i < n; ++i) maxcols = steps[i].ncols > maxcols ? steps[i].ncols : maxcols;
     dim3 grid(t2_cdiv(maxcols, 16), t2_cdiv(steps[0].B, 16), n), block(256);
@@ -570,7 +570,7 @@ extern "C" int t2_lstm_step_fwd(const T2LstmStep* steps, int n, void* stream) {
 
 extern "C" int t2_lstm_step_bwd(const T2LstmBwdStep* steps, int n, void* stream) {
     (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
-    T2_REQUIRE(steps != nullptr && (n == 1 || n == 2), "t2_lstm_step_bwd: need 1 or 2 steps");
+    T2_REQUIRE(steps != nullptr, "t2_lstm_step_bwd: null");
     return launch_bwd(steps, n, (hipStream_t)stream);
 }
 

@@ -221,7 +221,7 @@ struct BwdK {
     const int32_t* len; int t;
     const float* dgt; long dgt_cs; float* dgt_out;   // x16-tiled dg_next / dg_out (chunk stride Bp*16 floats)
 };
-struct BwdK2 { BwdK s[3]; };   // up to three steps per launch (blockIdx.z)
+struct BwdK2 { BwdK s[2]; };
 
 inline void t2_lstm_to_bk(const T2LstmBwdStep& s, BwdK& k) {
     k.B = s.B; k.H = s.H; k.N4 = s.N4;

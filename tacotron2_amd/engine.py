@@ -97,30 +97,6 @@ def _chunk_sizes(T: int, CH: int, ramp_at_end: bool = True):
     return sizes + tail
 
 
-def _hosted_bwd_schedule(T: int, CH: int, margin: int, ramp: bool = True):
-    """Backward pipeline with the decoder-LSTM BPTT steps HOSTED in the attention chain's products launches (Engine.bwd_host).
-    Frames are counted in processing order (index 0 = frame T-1).  The BPTT runs `lead` = CH + margin frames ahead of the
-    attention chain: a chunk of CH BPTT frames, and the GEMM that turns its gate gradients into d[att_h, ctx], must be complete
-    before the attention chain reaches the chunk.  Returns (standalone, hosted, h0):
-      standalone  [(hi, lo)] BPTT chunks run as plain launches on the side stream before / next to the first attention frames
-                  (the first lead + h0 frames, ramped so that the attention chain can start after CH/8 frames),
-      hosted      [(hi, lo)] BPTT chunks whose steps ride one per attention frame, starting with attention frame index h0
-                  (h0: the attention frames the main stream gets through while the side stream finishes the standalone part)."""
-    lead = min(T, CH + margin)
-    h0 = min(T, lead // 5 + 2) if lead < T else 0
-    S = min(T, lead + h0)
-    sa, hi, left = [], T, S
-    sizes = [CH // 8, CH // 8, CH // 4, CH // 2] if (ramp and CH >= 16) else []
-    while left > 0:
-        n = min(sizes.pop(0) if sizes else CH, left)
-        sa.append((hi, hi - n)); hi -= n; left -= n
-    hosted = []
-    while hi > 0:
-        n = min(CH, hi)
-        hosted.append((hi, hi - n)); hi -= n
-    return sa, hosted, h0
-
-
 class Engine:
     """Forward/backward of the whole model on one device.  `ps` is the ParamStore."""
 
@@ -132,9 +108,6 @@ class Engine:
         self._side = None
         self.chunk = 64               # frames per pipeline chunk of the forward frame loop
         self.chunk_bwd = 80           # frames per chunk of the backward pipeline (80*32 rows = 240 tiles of the dxdec GEMM)
-        self.bwd_host = False         # decoder-LSTM BPTT steps hosted in the attention chain's products launches (_hosted_bwd_schedule)
-        self.bwd_host_chunk = 48      # frames per BPTT chunk (= per dxdec GEMM) of the hosted schedule
-        self.bwd_host_margin = 8      # attention frames between a hosted chunk's last BPTT step and the chain reaching that chunk
         self.dec_chain = "persistent" # forward decoder-LSTM chain: "persistent" (one weight-stationary launch per chunk on the side
                                       # stream) or "hosted" (its steps ride in the attention-energies launches)
         self.persist_gemm_side = True    # the hoisted pre_dec GEMM of a chunk runs on the side stream too, in front of the chunk's
@@ -816,9 +789,11 @@ class Engine:
         for n in reversed(_chunk_sizes(T, CH, ramp_at_end=self.ramp_chunks)):
             chunks.append((hi, hi - n)); hi -= n
         # Two-stream pipeline: decoder chain of chunk k+1 on the side stream next to the attention chain of chunk k.  Hosting the
-        # decoder BPTT steps inside attention launches instead measured slower both ways (inside the ds launch: round 1,
+        # decoder BPTT steps inside attention launches instead measured slower every way (inside the ds launch: round 1,
         # profiles/r01_sweep_bwd_chunk_co.txt; as a second operand block of the cell-backward launch: 75.3 against 71.9 ms
-        # per step, profiles/r02_ab_bwd_schedule.txt) - those launches end when the hosted K = 4096 step ends.
+        # per step, profiles/r02_ab_bwd_schedule.txt; as a third descriptor of the products launch - a kernel of the same kind -
+        # 71.0 against 66.6 ms, profiles/r03_ab_bwd_host.txt): as its own launch the step overlaps the latency-bound dw / ds /
+        # cell-backward launches of the chain, hosted it doubles the load of the CUs that carry it.
         gWih = G["decoder.att_rnn.weight_ih"]
 
         def att_wgrads(hi, lo):      # weight gradients of the attention chain over frames [lo, hi) (accumulating: split-K atomics)
@@ -835,9 +810,6 @@ class Engine:
         # attention chain (main stream: wait for the event recorded behind the group's last chunk).
         WG = max(1, int(self.wgrad_group))
         dec_grp, att_done, att_grp = None, [], None        # [hi, lo, n]; [(hi, lo, event)]; [hi, lo, n, event]
-        if self.bwd_host:
-            self._backward_chains_hosted(locals())
-            chunks = []
         for ci_, (hi, lo) in enumerate(chunks):
             with torch.cuda.stream(side):
                 s, inc = dec_bwd_chunk(hi, lo)
@@ -864,9 +836,6 @@ class Engine:
             call("t2_attn_seq_bwd", sb, st)
             if self.chunk_att_wgrads:
                 att_done.append((hi, lo, main.record_event()))
-        if self.bwd_host:
-            dec_grp = att_grp = None; att_done = []                   # (the hosted schedule has flushed its own groups)
-            side.wait_event(main.record_event())                      # the last hosted BPTT steps ran on the main stream
         with torch.cuda.stream(side):
             while post_wgrads:                      # (short sequences: fewer chunks than deferred GEMMs)
                 post_wgrads.pop(0)()
@@ -1006,104 +975,6 @@ class Engine:
         call("t2_embedding_bwd", ctx["chars_idx"], dx, G["encoder.embedding.weight"], B, L, E, Lp, 0, st)
         torch.cuda.current_stream().wait_stream(self.side_stream())
         self.mark("bwd.encoder_convs")
-
-    def _backward_chains_hosted(self, v: dict):
-        """The two recurrences of the backward with the decoder-LSTM BPTT steps riding in the attention chain's products launches
-        (t2_attn_seq_bwd co_step; schedule: _hosted_bwd_schedule).  `v`: the local operands of backward_tf."""
-        T, B, D, st = v["T"], v["B"], v["D"], v["st"]
-        main, side, sb = v["main"], v["side"], v["sb"]
-        dec_bwd_chunk, dxdec_gemm = v["dec_bwd_chunk"], v["dxdec_gemm"]
-        dec_wgrads_chunk, att_wgrads, post_wgrads = v["dec_wgrads_chunk"], v["att_wgrads"], v["post_wgrads"]
-        WG = max(1, int(self.wgrad_group))
-        sa, hosted, h0 = _hosted_bwd_schedule(T, int(self.bwd_host_chunk), int(self.bwd_host_margin), self.ramp_chunks)
-        bchunks = sa + hosted
-        gemm_ev = {}
-        st8 = dict(dec_grp=None, att_grp=None, att_done=[], nside=0)
-
-        def side_after_gemm(hi, lo):
-            """Side-stream work that nothing on the critical path waits for, queued behind a chunk's dxdec GEMM event."""
-            SHARE_CU[0] = self.share_cu
-            if self.chunk_att_wgrads:
-                g = st8["dec_grp"]
-                g = [hi, lo, 1] if g is None else [g[0], lo, g[2] + 1]
-                if g[2] >= WG:
-                    dec_wgrads_chunk(g[0], g[1]); g = None
-                st8["dec_grp"] = g
-            st8["nside"] += 1
-            if post_wgrads and st8["nside"] > 4:
-                post_wgrads.pop(0)()
-            if self.chunk_att_wgrads and len(st8["att_done"]) >= 2:
-                h2, l2, e2 = st8["att_done"].pop(0)
-                a = st8["att_grp"]
-                a = [h2, l2, 1, e2] if a is None else [a[0], l2, a[2] + 1, e2]
-                if a[2] >= WG:
-                    side.wait_event(a[3])
-                    att_wgrads(a[0], a[1]); a = None
-                st8["att_grp"] = a
-            SHARE_CU[0] = 0
-
-        # ---- side stream, up front: the standalone BPTT chunks, each followed by its dxdec GEMM ----
-        with torch.cuda.stream(side):
-            for k, (hi, lo) in enumerate(sa):
-                s_, inc_ = dec_bwd_chunk(hi, lo)
-                call("t2_lstm_seq_bwd", s_, inc_, 1, hi - lo, side.cuda_stream)
-                dxdec_gemm(hi, lo, self.share_cu)
-                gemm_ev[k] = side.record_event()
-                side_after_gemm(hi, lo)
-            ev_sa = side.record_event()
-        # ---- main stream: attention frames in segments cut where an event is needed ----
-        start_of = {T - hi: k for k, (hi, lo) in enumerate(bchunks)}             # attention frame index -> chunk it enters
-        done_at, a = {}, h0
-        for j, (hi, lo) in enumerate(hosted):                                    # attention frame index after which hosted chunk j is complete
-            a += hi - lo
-            done_at[a] = len(sa) + j
-        cuts = sorted(set([0, T, h0] + list(start_of) + [c for c in done_at if c <= T]))
-        b_next = sa[-1][1] if sa else T                                          # next BPTT frame to host is b_next - 1
-        keep = []
-        for a0, a1 in zip(cuts[:-1], cuts[1:]):
-            if a0 in start_of:
-                main.wait_event(gemm_ev[start_of[a0]])
-            nh = 0
-            if hosted and a0 >= h0 and b_next > 0:
-                if a0 == h0:
-                    main.wait_event(ev_sa)
-                nh = min(a1 - a0, b_next)
-            sb.t_hi, sb.t_lo = T - a0, T - a1
-            if nh > 0:
-                import ctypes as _C
-                s_, inc_ = dec_bwd_chunk(b_next, b_next - nh)
-                keep.append((s_, inc_))
-                sb.co_step, sb.co_inc, sb.co_steps = _C.pointer(s_), _C.pointer(inc_), nh
-                b_next -= nh
-            else:
-                sb.co_step, sb.co_inc, sb.co_steps = None, None, 0
-            call("t2_attn_seq_bwd", sb, st)
-            if a1 in start_of or a1 == T:                                        # an attention chunk ended: its weight gradients may go
-                k_end = start_of.get(a1, len(bchunks)) - 1
-                if self.chunk_att_wgrads and k_end >= 0:
-                    st8["att_done"].append((bchunks[k_end][0], bchunks[k_end][1], main.record_event()))
-            if a1 in done_at:                                                    # a hosted BPTT chunk is complete: its GEMM, on the side stream
-                k = done_at[a1]
-                ev = main.record_event()
-                with torch.cuda.stream(side):
-                    side.wait_event(ev)
-                    dxdec_gemm(bchunks[k][0], bchunks[k][1], self.share_cu)
-                    gemm_ev[k] = side.record_event()
-                    side_after_gemm(bchunks[k][0], bchunks[k][1])
-        sb.co_step, sb.co_inc, sb.co_steps = None, None, 0
-        # ---- flush what the groups still hold ----
-        with torch.cuda.stream(side):
-            SHARE_CU[0] = self.share_cu
-            if st8["dec_grp"] is not None:
-                side.wait_event(main.record_event())
-                dec_wgrads_chunk(st8["dec_grp"][0], st8["dec_grp"][1])
-            a = st8["att_grp"]
-            for h2, l2, e2 in st8["att_done"]:
-                a = [h2, l2, 1, e2] if a is None else [a[0], l2, a[2] + 1, e2]
-            if a is not None:
-                side.wait_event(a[3])
-                att_wgrads(a[0], a[1])
-            SHARE_CU[0] = 0
 
     # =============================================================================================
     # loss + one optimisation step

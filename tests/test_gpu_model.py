@@ -230,24 +230,19 @@ def test_train_step_midsize_matches_oracle():
 
 @pytest.mark.parametrize("B,T,chunk,chunk_bwd,dec_chain", [(5, 23, 8, 8, "persistent"), (5, 23, 64, 5, "hosted"), (5, 23, 6, 64, "persistent"),
                                                              (35, 23, 7, 9, "persistent"), (5, 23, 8, 8, "hosted"),
-                                                             (5, 150, 16, 16, "persistent"), (33, 90, 32, 16, "persistent"),
-                                                             (5, 23, 8, -8, "persistent"), (5, 150, 16, -16, "persistent"),
-                                                             (33, 90, 32, -16, "persistent"), (5, 4, 8, -48, "persistent")])
+                                                             (5, 150, 16, 16, "persistent"), (33, 90, 32, 16, "persistent")])
 def test_pipeline_chunking_matches_oracle(B, T, chunk, chunk_bwd, dec_chain):
     """The frame loop's schedule (chunk sizes; forward: decoder-LSTM chain as persistent launches on the side stream or hosted inside the
     attention-energies launches for B <= 32, two-stream pipeline above; backward: two-stream pipeline) must not change results: every variant against the
     CPU oracle on the same inputs.  The long cases (T = 150 / 90 with 16-frame chunks) have enough chunks for everything the backward
     schedule does along the pipeline: ramped chunk sizes, weight gradients in groups of four chunks behind main-stream events,
-    deferred postnet / projection weight gradients between chunks.  chunk_bwd < 0: Engine.bwd_host (the BPTT steps of the decoder
-    LSTM ride in the attention chain's products launches, `lead` frames ahead; _hosted_bwd_schedule)."""
+    deferred postnet / projection weight gradients between chunks."""
     dev = _dev()
     d = R.default_dims(num_chars=39, encoded_dim=64, prenet_dim=32, att_rnn_dim=64, att_dim=32, rnn_hidden_dim=64,
                        postnet_dim=64, num_mels=16, dropout=0.5)
     P = R.init_params(d, seed=11)
     eng, ps = build_engine(d, P, dev)
-    eng.chunk, eng.chunk_bwd, eng.dec_chain = chunk, abs(chunk_bwd), dec_chain
-    if chunk_bwd < 0:        # the backward with the decoder-LSTM BPTT steps hosted in the attention chain's products launches
-        eng.bwd_host, eng.bwd_host_chunk, eng.bwd_host_margin = True, -chunk_bwd, max(1, -chunk_bwd // 4)
+    eng.chunk, eng.chunk_bwd, eng.dec_chain = chunk, chunk_bwd, dec_chain
     # (seed 77 at B = 35 puts one encoder pre-activation within 1e-6 of the ReLU kink: fp32 kernels with different summation
     # orders - the two GEMM kernels, the oracle - then legitimately disagree on that element's derivative; tools/debug_b35.py.
     # dekink_masks drops such elements from both sides through the dropout mask behind the ReLU.)
