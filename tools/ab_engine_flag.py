@@ -1,0 +1,31 @@
+"""A/B of one Engine attribute on the bench batch (GPU box): `python tools/ab_engine_flag.py attr v0 v1 [v2 ...]` alternates the
+values in one process (two repetitions, 3 warm-up + 8 timed steps each) and prints ms per step and the HIP-event segments."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import VANILLA
+from tacotron2_amd.init import init_parameters
+from tacotron2_amd.params import ParamStore
+from tacotron2_amd.synthetic import ljspeech_batch
+from tacotron2_amd.trainer import Trainer
+attr, vals = sys.argv[1], [eval(v) for v in sys.argv[2:]]
+dev = torch.device("cuda:0")
+ps = ParamStore(VANILLA, dev); init_parameters(ps, 0)
+tr = Trainer(ps, lr=1e-3, weight_decay=1e-6)
+batch = {k: v.to(dev) for k, v in ljspeech_batch(32, seed=1234, num_speakers=4).items()}
+for rep in range(2):
+    for v in vals:
+        assert hasattr(tr.engine, attr), attr
+        setattr(tr.engine, attr, v)
+        for _ in range(3):
+            tr.train_step(batch)
+        torch.cuda.synchronize()
+        tr.engine.profile = True
+        t0 = time.perf_counter()
+        for _ in range(8):
+            loss3, _ = tr.train_step(batch)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 8 * 1e3
+        tr.engine.profile = False
+        seg = tr.engine.segment_times_ms()
+        keys = ("fwd.encoder", "fwd.dec.attn_chain", "fwd.postnet", "bwd.postnet", "bwd.dec.chains", "bwd.bilstm", "bwd.encoder_convs")
+        print(f"{attr}={v!r}: {dt:.2f} ms/step  " + "  ".join(f"{k} {seg.get(k, 0):.2f}" for k in keys) + f"  loss {float(loss3.sum()):.4f}", flush=True)
