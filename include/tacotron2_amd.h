@@ -268,9 +268,6 @@ typedef struct {
                                         zero-filled by the caller; read by the per-frame products of dgates[t+1] */
     uint64_t* clk;                   /* diagnostic, normally NULL: 32 device words, s_memtime stamps of workgroup (0,0) at phase
                                         boundaries of the dw kernel [16..19] and the ds kernel [24..30] */
-    int acc_in_cell;                 /* 1: the accumulators nothing in the chain waits for (dpmT, dv_part, dU_part) are updated by
-                                        extra workgroups of the frame's cell-backward launch instead of by the ds launch, which
-                                        then only produces ds -> dq and the location-path partials (same results) */
 } T2AttnSeqBwd;
 int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream);
 

@@ -54,40 +54,33 @@ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 template <int NTH>
 struct StageRegs { float uv[1024 / NTH]; float iv[1024 / NTH]; };
 
-// DO_INP / DO_U: which of the two images a kernel needs (the lean ds kernel only the filter rows, the accumulation workgroups
-// only the haloed inputs)
-template <int NTH, bool DO_INP = true, bool DO_U = true>
+template <int NTH>
 __device__ __forceinline__ void stage_issue(StageRegs<NTH>& r, const float* w_prev, long ldw, const float* cum_prev, long ldcum,
                                             const float* U, const float* dummy, int b, int j, int L, int Lp, int tid) {
     constexpr int PER = 1024 / NTH;
     const float* wsrc = w_prev ? w_prev + (long)b * ldw : dummy;
     const float* csrc = cum_prev ? cum_prev + (long)b * ldcum : dummy;
-    if (DO_U) {
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {   // Us[al][c][32]: taps 0..30 of channel c, tap 31 = 0 (rows padded for aligned 16-byte reads)
-            const int idx = tid + NTH * i, al = idx >> 6, c = (idx >> 5) & 1, k = idx & 31;
-            r.uv[i] = U[(long)(j * 16 + al) * 2 * KL + c * KL + imin(k, KL - 1)];
-        }
+    for (int i = 0; i < PER; ++i) {   // Us[al][c][32]: taps 0..30 of channel c, tap 31 = 0 (rows padded for aligned 16-byte reads)
+        const int idx = tid + NTH * i, al = idx >> 6, c = (idx >> 5) & 1, k = idx & 31;
+        r.uv[i] = U[(long)(j * 16 + al) * 2 * KL + c * KL + imin(k, KL - 1)];
     }
-    if (DO_INP) {
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int idx = tid + NTH * i;
-            const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
-            const int lc = imin(imax(l, 0), L - 1);
-            r.iv[i] = (c ? csrc : wsrc)[lc];
-        }
+    for (int i = 0; i < PER; ++i) {
+        const int idx = tid + NTH * i;
+        const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
+        const int lc = imin(imax(l, 0), L - 1);
+        r.iv[i] = (c ? csrc : wsrc)[lc];
     }
 }
 
-template <int NTH, bool DO_INP = true, bool DO_U = true>
+template <int NTH>
 __device__ __forceinline__ void stage_commit(const StageRegs<NTH>& r, float* inp, float* Us, const float* w_prev, long ldw,
                                              const float* cum_prev, long ldcum, const float* dummy, int b, int L, int Lp, int tid) {
     constexpr int PER = 1024 / NTH;
     const float* wsrc = w_prev ? w_prev + (long)b * ldw : dummy;
     const float* csrc = cum_prev ? cum_prev + (long)b * ldcum : dummy;
     const bool wz = w_prev == nullptr, cz = cum_prev == nullptr;
-    if (DO_INP) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int idx = tid + NTH * i;
@@ -95,8 +88,7 @@ __device__ __forceinline__ void stage_commit(const StageRegs<NTH>& r, float* inp
         const bool ok = l >= 0 && l < L && !(c ? cz : wz);
         if (idx < 2 * Lp) inp[idx] = ok ? r.iv[i] : 0.f;
     }
-    }
-    for (int base = 1024; DO_INP && base < 2 * Lp; base += 1024) {   // long texts (2*Lp > 1024): further rounds, load then store
+    for (int base = 1024; base < 2 * Lp; base += 1024) {   // long texts (2*Lp > 1024): further rounds, load then store
         float iv[PER];
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
@@ -113,22 +105,20 @@ __device__ __forceinline__ void stage_commit(const StageRegs<NTH>& r, float* inp
             if (idx < 2 * Lp) inp[idx] = ok ? iv[i] : 0.f;
         }
     }
-    if (DO_U) {
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int idx = tid + NTH * i;
-            Us[idx] = (idx & 31) < KL ? r.uv[i] : 0.f;
-        }
+    for (int i = 0; i < PER; ++i) {
+        const int idx = tid + NTH * i;
+        Us[idx] = (idx & 31) < KL ? r.uv[i] : 0.f;
     }
 }
 
-template <int NTH, bool DO_INP = true, bool DO_U = true>
+template <int NTH>
 __device__ __forceinline__ void stage_inp_U(float* inp, float* Us, const float* w_prev, long ldw, const float* cum_prev,
                                             long ldcum, const float* U, const float* dummy, int b, int j, int L, int Lp,
                                             int tid) {
     StageRegs<NTH> r;
-    stage_issue<NTH, DO_INP, DO_U>(r, w_prev, ldw, cum_prev, ldcum, U, dummy, b, j, L, Lp, tid);
-    stage_commit<NTH, DO_INP, DO_U>(r, inp, Us, w_prev, ldw, cum_prev, ldcum, dummy, b, L, Lp, tid);
+    stage_issue<NTH>(r, w_prev, ldw, cum_prev, ldcum, U, dummy, b, j, L, Lp, tid);
+    stage_commit<NTH>(r, inp, Us, w_prev, ldw, cum_prev, ldcum, dummy, b, L, Lp, tid);
 }
 
 constexpr int ENT = 512;   // threads of the energy / ds kernels: two waves per SIMD double the VALU issue rate
@@ -745,10 +735,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dw_kernel(AttnBwdK p) {
     T2_STAMP(p, stamp, 19);
 }
 
-// LEAN = false: everything about a (sample, 16-dim slice) in this kernel (phases A-D).  LEAN = true: only what the NEXT launches
-// of the chain wait for - ds, dq (phase B) and the d_in partials (phase D); the accumulators that nothing in the chain reads
-// (dpmT, dv, dU: phases A', B', C) are left to attn_bwd_acc_body, whose workgroups ride in the cell-backward launch.
-template <bool LEAN>
 __device__ __forceinline__ void attn_bwd_ds_body(const AttnBwdK& p, const int b, const int j, float* sm) {
     const int tid = threadIdx.x;
     const bool stamp = b == 0 && j == 0 && tid == 0;
@@ -756,8 +742,8 @@ __device__ __forceinline__ void attn_bwd_ds_body(const AttnBwdK& p, const int b,
     const int al = tid >> 5, sub = tid & 31, a = j * 16 + al;
     const int L = p.L, NG = (L + 3) >> 2, Lp = 4 * NG + 36, L4 = 4 * NG;
     constexpr int DH = 16;         // halo of the ds rows (16, not 15: keeps every 4-position read 16-byte aligned)
-    float* inp = sm;               // [2][Lp]  haloed (w_{t-1}, cum_{t-1}), index l + 15   (absent when LEAN)
-    float* dsp = inp + (LEAN ? 0 : 2 * Lp);     // [16][Lp] haloed ds, index l + 16
+    float* inp = sm;               // [2][Lp]  haloed (w_{t-1}, cum_{t-1}), index l + 15
+    float* dsp = inp + 2 * Lp;     // [16][Lp] haloed ds, index l + 16
     float* Us = dsp + 16 * Lp;     // [16][2][32]
     float* tvs = Us + 16 * 64;     // [16][L4] de*th      } after phase C these three (32*L4 floats) hold the
     float* des = tvs + 16 * L4;    // [L4]                } per-dim d_in partials dinq[16][2][L4]
@@ -775,23 +761,20 @@ __device__ __forceinline__ void attn_bwd_ds_body(const AttnBwdK& p, const int b,
         for (int i = 0; i < 4; ++i) {
             const int l = imin(4 * lg + i, L - 1);
             thv[it][i] = t4[i];
-            if (!LEAN) dpv[it][i] = p.dpmT[rowoff + l];
+            dpv[it][i] = p.dpmT[rowoff + l];
         }
     }
     // phase C ownership: (dim al, channel c_c, tap group c_kg of 8 taps, position quarter c_lq)
     const int c_c = sub >> 4, c_kg = (sub >> 2) & 3, c_lq = sub & 3, c_k0 = 8 * c_kg;
     float* dU_dst = p.dU_part + (((long)b * p.Ad + a) * 2 + c_c) * KL + c_k0;
     float dU_old[8];
-    float dv_old = 0.f;
-    if (!LEAN) {
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) dU_old[kk] = dU_dst[imin(kk, KL - 1 - c_k0)];
-        dv_old = p.dv_part[(long)b * p.Ad + a];
-    }
+    for (int kk = 0; kk < 8; ++kk) dU_old[kk] = dU_dst[imin(kk, KL - 1 - c_k0)];
+    const float dv_old = p.dv_part[(long)b * p.Ad + a];
     float dev[2];   // de for up to 1024 positions
 #pragma unroll
     for (int i = 0; i < 2; ++i) dev[i] = p.de[(long)b * L + imin(tid + ENT * i, L - 1)];
-    stage_inp_U<ENT, !LEAN, true>(inp, Us, p.w_prev, p.ldwp, p.cum_prev, p.ldcp, p.U, p.th, b, j, L, Lp, tid);
+    stage_inp_U<ENT>(inp, Us, p.w_prev, p.ldwp, p.cum_prev, p.ldcp, p.U, p.th, b, j, L, Lp, tid);
     for (int idx = tid; idx < 16 * Lp; idx += ENT) dsp[idx] = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -814,7 +797,7 @@ __device__ __forceinline__ void attn_bwd_ds_body(const AttnBwdK& p, const int b,
                 for (int i = 0; i < 4; ++i) {
                     const int l = imin(4 * lg + i, L - 1);
                     thv[it][i] = t4[i];
-                    if (!LEAN) dpv[it][i] = p.dpmT[rowoff + l];
+                    dpv[it][i] = p.dpmT[rowoff + l];
                 }
             }
             f32x4 d4 = {0.f, 0.f, 0.f, 0.f}, t4 = {0.f, 0.f, 0.f, 0.f};
@@ -826,11 +809,11 @@ __device__ __forceinline__ void attn_bwd_ds_body(const AttnBwdK& p, const int b,
                     const float th = thv[it][i];
                     d4[i] = de4[i] * va * (1.f - th * th);
                     t4[i] = de4[i] * th;
-                    if (!LEAN) p.dpmT[rowoff + l] = dpv[it][i] + d4[i];
+                    p.dpmT[rowoff + l] = dpv[it][i] + d4[i];
                 }
             }
             *reinterpret_cast<f32x4*>(dsp + al * Lp + DH + 4 * lg) = d4;
-            if (!LEAN) *reinterpret_cast<f32x4*>(tvs + al * L4 + 4 * lg) = t4;
+            *reinterpret_cast<f32x4*>(tvs + al * L4 + 4 * lg) = t4;
         }
     }
     __syncthreads();
@@ -840,22 +823,19 @@ __device__ __forceinline__ void attn_bwd_ds_body(const AttnBwdK& p, const int b,
         float sq = 0.f, sv = 0.f;
         for (int lg = sub; lg < NG; lg += 32) {
             const f32x4 d4 = *reinterpret_cast<const f32x4*>(dsp + al * Lp + DH + 4 * lg);
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(tvs + al * L4 + 4 * lg);
             sq += (d4[0] + d4[1]) + (d4[2] + d4[3]);
-            if (!LEAN) {
-                const f32x4 t4 = *reinterpret_cast<const f32x4*>(tvs + al * L4 + 4 * lg);
-                sv += (t4[0] + t4[1]) + (t4[2] + t4[3]);
-            }
+            sv += (t4[0] + t4[1]) + (t4[2] + t4[3]);
         }
-        sq = t2_half_sum_hi(sq);                            // totals of the dim's 32 lanes land in its upper 16 lanes
-        if (!LEAN) sv = t2_half_sum_hi(sv);
+        sq = t2_half_sum_hi(sq); sv = t2_half_sum_hi(sv);   // totals of the dim's 32 lanes land in its upper 16 lanes
         if (sub == 31) {
             p.dq[(long)b * p.lddq + a] = sq;
-            if (!LEAN) p.dv_part[(long)b * p.Ad + a] = dv_old + sv;
+            p.dv_part[(long)b * p.Ad + a] = dv_old + sv;
         }
     }
 
     T2_STAMP(p, stamp, 27);
-    if (!LEAN) {   // phase C: dU[a][c][k0..k0+7] += sum_l ds[l] * in[c][l + k - 15]; 8 taps x 4 positions per register tile,
+    {   // phase C: dU[a][c][k0..k0+7] += sum_l ds[l] * in[c][l + k - 15]; 8 taps x 4 positions per register tile,
         // a quarter of the position groups per thread, quarters combined by two shuffles
         float out[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const float* dsr = dsp + al * Lp + DH;
@@ -949,158 +929,10 @@ __device__ __forceinline__ void attn_bwd_ds_body(const AttnBwdK& p, const int b,
     T2_STAMP(p, stamp, 30);
 }
 
-
-// The accumulators of a (sample, 16-dim slice) that nothing in the backward chain waits for (phases A', B', C of the full ds body):
-// dpmT += ds, dv += sum_l de*th, dU += ds (*) in.  512 threads; the workgroups ride in the attention-cell backward launch (the
-// fourth launch of a frame: 128 latency-bound workgroups on 256 CUs), so the ds launch on the critical path sheds them.
-__device__ __forceinline__ void attn_bwd_acc_body(const AttnBwdK& p, const int b, const int j, float* sm) {
-    const int tid = threadIdx.x;
-    const int al = tid >> 5, sub = tid & 31, a = j * 16 + al;
-    const int L = p.L, NG = (L + 3) >> 2, Lp = 4 * NG + 36, L4 = 4 * NG;
-    constexpr int DH = 16;
-    float* inp = sm;               // [2][Lp]  haloed (w_{t-1}, cum_{t-1}), index l + 15
-    float* dsp = inp + 2 * Lp;     // [16][Lp] haloed ds, index l + 16
-    float* des = dsp + 16 * Lp;    // [L4]
-    const long rowoff = ((long)b * p.Ad + a) * L;
-    float thv[EMAXI][4], dpv[EMAXI][4];
-    const float va = p.v[a];
-    const float* th_row = p.th + ((long)b * p.Ad + a) * L4;
-#pragma unroll
-    for (int it = 0; it < EMAXI; ++it) {
-        const int lg = imin(sub + 32 * it, NG - 1);
-        const f32x4 t4 = *reinterpret_cast<const f32x4*>(th_row + 4 * lg);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int l = imin(4 * lg + i, L - 1);
-            thv[it][i] = t4[i];
-            dpv[it][i] = p.dpmT[rowoff + l];
-        }
-    }
-    const int c_c = sub >> 4, c_kg = (sub >> 2) & 3, c_lq = sub & 3, c_k0 = 8 * c_kg;
-    float* dU_dst = p.dU_part + (((long)b * p.Ad + a) * 2 + c_c) * KL + c_k0;
-    float dU_old[8];
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) dU_old[kk] = dU_dst[imin(kk, KL - 1 - c_k0)];
-    const float dv_old = p.dv_part[(long)b * p.Ad + a];
-    float dev[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) dev[i] = p.de[(long)b * L + imin(tid + ENT * i, L - 1)];
-    stage_inp_U<ENT, true, false>(inp, nullptr, p.w_prev, p.ldwp, p.cum_prev, p.ldcp, p.U, p.th, b, j, L, Lp, tid);
-    for (int idx = tid; idx < 16 * Lp; idx += ENT) dsp[idx] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int l = tid + ENT * i;
-        if (l < L4) des[l] = l < L ? dev[i] : 0.f;
-    }
-    for (int l = tid + 1024; l < L4; l += ENT) des[l] = l < L ? p.de[(long)b * L + l] : 0.f;
-    __syncthreads();
-    float sv = 0.f;
-    for (int base = 0; base < NG; base += 32 * EMAXI) {
-#pragma unroll
-        for (int it = 0; it < EMAXI; ++it) {
-            const int lg = base + sub + 32 * it;
-            if (lg >= NG) continue;
-            if (base > 0) {
-                const f32x4 t4 = *reinterpret_cast<const f32x4*>(th_row + 4 * lg);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int l = imin(4 * lg + i, L - 1);
-                    thv[it][i] = t4[i];
-                    dpv[it][i] = p.dpmT[rowoff + l];
-                }
-            }
-            f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 de4 = *reinterpret_cast<const f32x4*>(des + 4 * lg);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int l = 4 * lg + i;
-                if (l < L) {
-                    const float th = thv[it][i];
-                    d4[i] = de4[i] * va * (1.f - th * th);
-                    sv += de4[i] * th;
-                    p.dpmT[rowoff + l] = dpv[it][i] + d4[i];
-                }
-            }
-            *reinterpret_cast<f32x4*>(dsp + al * Lp + DH + 4 * lg) = d4;
-        }
-    }
-    sv = t2_half_sum_hi(sv);
-    if (sub == 31) p.dv_part[(long)b * p.Ad + a] = dv_old + sv;
-    __syncthreads();
-    {   // dU[a][c][k0..k0+7] += sum_l ds[l] * in[c][l + k - 15] (phase C of the full ds body)
-        float out[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const float* dsr = dsp + al * Lp + DH;
-        const float* inr = inp + c_c * Lp + c_k0;
-        for (int lg = c_lq; lg < NG; lg += 4) {
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dsr + 4 * lg);
-            float wv[12];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(inr + 4 * lg + 4 * i);
-                wv[4 * i] = t[0]; wv[4 * i + 1] = t[1]; wv[4 * i + 2] = t[2]; wv[4 * i + 3] = t[3];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk) out[kk] = fmaf(d4[i], wv[i + kk], out[kk]);
-        }
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) out[kk] = t2_quad_sum(out[kk]);
-        if (c_lq == 0) {
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
-                if (c_k0 + kk < KL) dU_dst[kk] = dU_old[kk] + out[kk];
-        }
-    }
-}
-
 __global__ __launch_bounds__(ENT, 2) void attn_bwd_ds_kernel(AttnBwdK p) {
     T2_CHAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    attn_bwd_ds_body<false>(p, blockIdx.x, blockIdx.y, sm);
-}
-
-__global__ __launch_bounds__(ENT, 2) void attn_bwd_ds_lean_kernel(AttnBwdK p) {
-    T2_CHAIN_PRIO();
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    attn_bwd_ds_body<true>(p, blockIdx.x, blockIdx.y, sm);
-}
-
-// Heterogeneous launch (the frame's fourth): workgroups [0, nC) are the 16 x 16 tiles of the attention-LSTM cell backward
-// (t2_lstm_bwd_fast_body, 256 threads: the upper four waves end at once), workgroups [nC, nC + B * Ad/16) the accumulation
-// workgroups of the frame's attention backward.  The cell tiles come first in block order: they are what the next frame waits for.
-__global__ __launch_bounds__(ENT, 2) void attn_cell_bwd_acc_kernel(BwdK c, int ctx_, int cty_, AttnBwdK p) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int bid = blockIdx.x, nC = ctx_ * cty_;
-    if (bid < nC) {
-        T2_CHAIN_PRIO();
-        if (threadIdx.x >= 256) return;
-        t2_lstm_bwd_fast_body<4, 4>(c, bid % ctx_, bid / ctx_, sm);
-        return;
-    }
-    const int id = bid - nC;
-    attn_bwd_acc_body(p, id % p.B, id / p.B, sm);
-}
-
-// The same for the frame's FIRST launch (the two K = 4A products of dgates[t+1]): workgroups [0, nP) are the product tiles
-// (bid -> tile (x, y) of descriptor z), the rest the accumulation workgroups of the frame processed BEFORE this one (t + 1).
-__global__ __launch_bounds__(ENT, 2) void attn_products_acc_kernel(BwdK2 pp, int gx, int gy, AttnBwdK p) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int bid = blockIdx.x, nP = gx * gy * 2;
-    if (bid < nP) {
-        T2_CHAIN_PRIO();
-        if (threadIdx.x >= 256) return;
-        const int z = bid / (gx * gy), r = bid - z * gx * gy;
-        t2_lstm_bwd_fast_body<4, 4>(pp.s[z], r % gx, r / gx, sm);
-        return;
-    }
-    const int id = bid - nP;
-    attn_bwd_acc_body(p, id % p.B, id / p.B, sm);
-}
-
-__global__ __launch_bounds__(ENT, 2) void attn_acc_kernel(AttnBwdK p) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    attn_bwd_acc_body(p, blockIdx.x, blockIdx.y, sm);
+    attn_bwd_ds_body(p, blockIdx.x, blockIdx.y, sm);
 }
 
 }  // namespace
@@ -1115,15 +947,8 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
     const long ldx = A + Ef;
     const int NG = (L + 3) >> 2, Lp = 4 * NG + 36, L4 = 4 * NG;
     const size_t sm_dw = (size_t)((Ef > 640 ? Ef : 640) + ((L + 3) & ~3) + 8) * sizeof(float);
-    const bool lean = a->acc_in_cell != 0;
-    const size_t sm_ds = (size_t)((lean ? 16 : 18) * Lp + 16 * 64 + 32 * L4) * sizeof(float);
-    const size_t sm_acc_ = (size_t)(18 * Lp + L4) * sizeof(float), sm_acc = sm_acc_ > 4096 ? sm_acc_ : 4096;
-    T2_REQUIRE(t2_allow_lds(attn_bwd_ds_kernel, sm_ds) && t2_allow_lds(attn_bwd_ds_lean_kernel, sm_ds) &&
-               t2_allow_lds(attn_cell_bwd_acc_kernel, sm_acc) && t2_allow_lds(attn_products_acc_kernel, sm_acc) &&
-               t2_allow_lds(attn_acc_kernel, sm_acc), "t2_attn_seq_bwd: LDS budget exceeded");
-    const bool acc_next = a->acc_in_cell == 2;     // accumulation workgroups of frame t ride in the products launch of frame t - 1
-    AttnBwdK kprev;
-    bool have_prev = false;
+    const size_t sm_ds = (size_t)(18 * Lp + 16 * 64 + 32 * L4) * sizeof(float);
+    T2_REQUIRE(t2_allow_lds(attn_bwd_ds_kernel, sm_ds), "t2_attn_seq_bwd: LDS budget exceeded");
     T2_REQUIRE(a->wtp_ctx && a->wtp_h, "t2_attn_seq_bwd: packed weight streams (t2_lstm_pack_bwd) are required");
     // Z[s][b] = [ dgates_s (4A) | dq_{s-1} (Ad) ], s = 0..T; slot T's dgates part is zero-filled by the caller, so the
     // backward step of frame t always reads ONE contiguous row Z[t+1] (no special case for the last frame).
@@ -1154,17 +979,7 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         r.ext1 = a->dh_ext + (long)t * B * a->ld_dh; r.ldx1 = a->ld_dh;
         r.dx_out = a->dh_rec; r.lddx = A;
         if (a->dgates_t) r.dgt_next = a->dgates_t + (long)(t + 1) * zts;
-        if (acc_next && have_prev) {
-            T2_TRY(t2_lstm_check_bwd(s2[0])); T2_TRY(t2_lstm_check_bwd(s2[1]));
-            BwdK2 kk;
-            t2_lstm_to_bk(s2[0], kk.s[0]); t2_lstm_to_bk(s2[1], kk.s[1]);
-            const int mc = s2[0].ncols > s2[1].ncols ? s2[0].ncols : s2[1].ncols;
-            const int gx = t2_cdiv(mc, 16), gy = t2_cdiv(B, 16);
-            hipLaunchKernelGGL(attn_products_acc_kernel, dim3(gx * gy * 2 + B * NA), dim3(ENT), sm_acc, st, kk, gx, gy, kprev);
-            have_prev = false;
-        } else {
-            T2_TRY(t2_lstm_step_bwd_launch(s2, 2, st));
-        }
+        T2_TRY(t2_lstm_step_bwd_launch(s2, 2, st));
         // (2),(3) attention backward
         AttnBwdK k;
         memset(&k, 0, sizeof(k));
@@ -1184,8 +999,7 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         k.dv_part = a->dv_part; k.dU_part = a->dU_part; k.din_part_out = a->din_part;
         k.clk = (unsigned long long*)a->clk;
         hipLaunchKernelGGL(attn_bwd_dw_kernel, dim3(B, t2_cdiv(L, 32)), dim3(256), sm_dw, st, k);
-        if (lean) hipLaunchKernelGGL(attn_bwd_ds_lean_kernel, dim3(B, NA), dim3(ENT), sm_ds, st, k);
-        else hipLaunchKernelGGL(attn_bwd_ds_kernel, dim3(B, NA), dim3(ENT), sm_ds, st, k);
+        hipLaunchKernelGGL(attn_bwd_ds_kernel, dim3(B, NA), dim3(ENT), sm_ds, st, k);
         // (4) attention-LSTM cell backward: dh = (dh_ext + dgates_{t+1}.W_hh) + dq_t.Wq  (short K = Ad product + pointwise)
         T2LstmBwdStep c;
         memset(&c, 0, sizeof(c));
@@ -1199,20 +1013,8 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         c.dc = a->dc; c.lddc = A;
         c.dg_out = Z + (long)t * B * ldz; c.ldgo = ldz;
         if (a->dgates_t) c.dgt_out = a->dgates_t + (long)t * zts;
-        if (acc_next) {
-            kprev = k; have_prev = true;
-            T2_TRY(t2_lstm_step_bwd_launch(&c, 1, st));
-        } else if (lean) {     // cell-backward tiles + the frame's accumulation workgroups in one launch
-            T2_TRY(t2_lstm_check_bwd(c));
-            BwdK ck;
-            t2_lstm_to_bk(c, ck);
-            const int ctx_ = t2_cdiv(c.ncols, 16), cty_ = t2_cdiv(B, 16);
-            hipLaunchKernelGGL(attn_cell_bwd_acc_kernel, dim3(ctx_ * cty_ + B * NA), dim3(ENT), sm_acc, st, ck, ctx_, cty_, k);
-        } else {
-            T2_TRY(t2_lstm_step_bwd_launch(&c, 1, st));
-        }
+        T2_TRY(t2_lstm_step_bwd_launch(&c, 1, st));
     }
-    if (have_prev) hipLaunchKernelGGL(attn_acc_kernel, dim3(B, NA), dim3(ENT), sm_acc, st, kprev);   // the call's last frame
     T2_CHECK_LAUNCH();
     return T2_OK;
 }

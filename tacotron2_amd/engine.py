@@ -120,7 +120,6 @@ class Engine:
         self.ramp_chunks = True       # short chunks at the un-overlapped end of the forward / start of the backward pipeline
         self.share_cu = 1             # side-stream GEMMs next to the chains at ONE workgroup per CU: two 73 KB-LDS workgroups
                                       # per CU lock the attention kernels out (84.3 -> 83.2 ms)
-        self.attn_acc_in_cell = True  # attention backward: dpmT / dv / dU accumulation rides in the cell-backward launch (T2AttnSeqBwd.acc_in_cell)
         self.sync_bn_group = None     # torch.distributed group: BatchNorm statistics over all ranks' shards (Trainer(sync_bn=True))
         self.grad_tail_hook = None    # called on the side stream once the gradients from prenet.0.weight onwards are enqueued
         self.generation = 0           # bumped by every forward: activations live in the shared named workspaces,
@@ -737,8 +736,7 @@ class Engine:
                   cum=ctx["cum"], th=ctx["th"], att_drop=masks.get("att_drop"),
                   dh_ext=dxdec, ld_dh=ldx, dctx_ext1=_ptr(dxdec, A), ld_dc1=ldx, dctx_ext2=_ptr(dxproj, D), ld_dc2=ldp,
                   dgates=Z, dctx_tot=dctx_tot, dq=None, dpmT=dpmT, dv_part=dv_part, dU_part=dU_part,
-                  dc=dc_att, G=Gc, de=de, din_part=din_part, dgates_t=Zt, clk=getattr(self, "clk_bwd", None),
-                  acc_in_cell=int(self.attn_acc_in_cell))
+                  dc=dc_att, G=Gc, de=de, din_part=din_part, dgates_t=Zt, clk=getattr(self, "clk_bwd", None))
         self.mark("bwd.dec.proj")
         main, side = torch.cuda.current_stream(), self.side_stream()
         side.wait_stream(main)

@@ -637,28 +637,3 @@ def test_inference_above_64_utterances_is_one_loop_like_the_reference():
     assert mels.shape == ref[0].shape and (lengths.cpu() == trace["lengths"]).all()
     assert l1(mels, ref[0]) < MEL_L1_TOL and l1(post, ref[1]) < MEL_L1_TOL and mx(al, ref[3]) < 5e-5
     assert ((gates.cpu() == -1000.0) == (ref[2] == -1000.0)).all()
-
-
-@pytest.mark.parametrize("mode", [0, 1, 2])
-def test_attention_backward_accumulator_placement_matches_oracle(mode):
-    """T2AttnSeqBwd.acc_in_cell: where the accumulators that nothing in the backward chain waits for (dpmT, dv, dU) are updated -
-    0 in the ds launch, 1 by extra workgroups of the cell-backward launch, 2 by extra workgroups of the NEXT frame's products
-    launch (the last frame of a chunk in a launch of its own).  Every gradient against the oracle in each mode, several chunks."""
-    dev = _dev()
-    d = R.default_dims(num_chars=39, encoded_dim=64, prenet_dim=32, att_rnn_dim=64, att_dim=32, rnn_hidden_dim=64,
-                       postnet_dim=64, num_mels=16, dropout=0.5)
-    P = R.init_params(d, seed=13)
-    eng, ps = build_engine(d, P, dev)
-    eng.chunk, eng.chunk_bwd, eng.attn_acc_in_cell = 8, 8, mode
-    ci, lens, mel, tl, gate, masks = random_case(d, 5, 19, 37, 91, dev)
-    masks, _ = dekink_masks(P, d, ci, mel, masks)
-    Pc = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not R.is_buffer(k)) else v.clone()) for k, v in P.items()}
-    o = R.tacotron2_fwd(Pc, d, ci, lens, True, mel, tl, training=True, masks=masks, new_stats={})
-    loss = R.tts_loss(o[0], o[1], o[2], mel, gate)[0]
-    names = [k for k, v in Pc.items() if v.requires_grad]
-    grads = torch.autograd.grad(loss, [Pc[k] for k in names])
-    outs, ctx = eng.forward_tf(ci.to(dev), lens.to(dev), mel.to(dev), tl.to(dev), training=True, masks=masks_to_device(masks, dev))
-    ps.grad.zero_()
-    eng.loss_and_grads(outs, ctx, mel.to(dev), gate.to(dev))
-    torch.cuda.synchronize()
-    _grad_check(ps, {k: g for k, g in zip(names, grads)})
