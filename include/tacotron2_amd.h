@@ -65,6 +65,11 @@ typedef struct {
     int native_fp32;                 /* 0 (default): fp32 result on the bf16 matrix pipe by error-free 3-way operand splitting
                                         (6 exact bf16 products per element pair, two fp32 accumulators; csrc/t2_gemm.hip);
                                         1: v_mfma_f32_32x32x2_f32 (f32-input MFMA, 1/16 of the bf16 rate) */
+    int a_tap_len; int64_t a_tap_stride;   /* optional (a_kmajor = 1): the K axis of A is a_tap_len-long blocks that are a_tap_stride
+                                        elements apart: element (m, k) at A[m*lda + (k / a_tap_len)*a_tap_stride + k % a_tap_len].  A DILATED
+                                        Conv1d(k, d) on channel-last rows is then ONE GEMM (tap block j = the Ci channels of row
+                                        m + j*d: a_tap_len = Ci, a_tap_stride = d*Ci, lda = Ci) instead of k accumulating ones
+                                        (model/hifi_gan.py:60-87).  a_tap_len must be a multiple of 32; 0 = plain rows */
     int precision;                   /* the reference's training.float32_matmul_precision (run/train.py:170), split kernel only:
                                         0 = "highest" (default): six bf16 products per element pair, fp32-exact operands;
                                         1 = "high": three products (a1b1 + a1b2 + a2b1, "bf16x3" in torch's terms, ~16

@@ -35,7 +35,13 @@ struct GemmK {
     long sA, sB, sC;
     int a_vec, b_vec;
     int ntm, ntn;
+    int a_tap_len; long a_tap_stride;     // T2Gemm.a_tap_len / a_tap_stride (0: plain rows)
 };
+
+// physical element offset of logical k0 (a multiple of the tile depth, which divides a_tap_len) on A's K axis
+__device__ __forceinline__ long a_koff(const GemmK& p, int k0) {
+    return p.a_tap_len ? (long)(k0 / p.a_tap_len) * p.a_tap_stride + (k0 % p.a_tap_len) : (long)k0;
+}
 
 // Load 4 consecutive elements starting at p[0] with `nvalid` (<=4) of them in range.
 __device__ __forceinline__ f32x4 load4(const float* p, int nvalid, bool vec) {
@@ -56,7 +62,8 @@ __device__ __forceinline__ f32x4 load4(const float* p, int nvalid, bool vec) {
 // MMAJ: k rows kk in [k0,k0+32), r in [r0, r0+128): idx = tid + 256*j, kk = idx>>5, rq = idx&31
 template <bool KMAJ>
 __device__ __forceinline__ void stage_load(f32x4 (&reg)[4], const float* __restrict__ base, long ld, int r0, int k0,
-                                           int R, int Kend, bool vec, int tid) {
+                                           int R, int Kend, bool vec, int tid, long kphys = -1) {
+    const long kp0 = kphys >= 0 ? kphys : (long)k0;     // where logical k0 sits on the operand's K axis (tap-strided A)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int idx = tid + 256 * j;
@@ -64,7 +71,7 @@ __device__ __forceinline__ void stage_load(f32x4 (&reg)[4], const float* __restr
             const int r = r0 + (idx >> 3), k = k0 + ((idx & 7) << 2);
             int nv = (r < R) ? (Kend - k) : 0;
             nv = nv < 0 ? 0 : nv;
-            reg[j] = load4(base + (long)r * ld + k, nv, vec);
+            reg[j] = load4(base + (long)r * ld + kp0 + ((idx & 7) << 2), nv, vec);
         } else {
             const int k = k0 + (idx >> 5), r = r0 + ((idx & 31) << 2);
             int nv = (k < Kend) ? (R - r) : 0;
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(GemmK p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 ra[4], rb[4];
-    stage_load<AK>(ra, A, p.lda, m0, kt0 * BK, p.M, Kend, p.a_vec, tid);
+    stage_load<AK>(ra, A, p.lda, m0, kt0 * BK, p.M, Kend, p.a_vec, tid, AK ? a_koff(p, kt0 * BK) : -1);
     stage_load<BKM>(rb, B, p.ldb, n0, kt0 * BK, p.N, Kend, p.b_vec, tid);
     stage_store<AK>(ra, smem, tid);
     stage_store<BKM>(rb, smem + TILE_FLOATS, tid);
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(GemmK p) {
     for (int kt = kt0; kt < kt1; ++kt) {
         const bool more = (kt + 1) < kt1;
         if (more) {
-            stage_load<AK>(ra, A, p.lda, m0, (kt + 1) * BK, p.M, Kend, p.a_vec, tid);
+            stage_load<AK>(ra, A, p.lda, m0, (kt + 1) * BK, p.M, Kend, p.a_vec, tid, AK ? a_koff(p, (kt + 1) * BK) : -1);
             stage_load<BKM>(rb, B, p.ldb, n0, (kt + 1) * BK, p.N, Kend, p.b_vec, tid);
         }
         const float* As = smem + cur * 2 * TILE_FLOATS;
@@ -274,16 +281,18 @@ __device__ __forceinline__ Split3 split3(const f32x4 v) {
 // FULL (wave-uniform: the tile is interior and 16-byte loads are legal): plain vector loads, no guards.
 template <bool KMAJ, bool FULL>
 __device__ __forceinline__ void split_stage_load(f32x4 (&reg)[2], const float* __restrict__ base, long ld, int r0, int k0, int R,
-                                                 int Kend, bool vec, int tid) {
+                                                 int Kend, bool vec, int tid, long kphys = -1) {
+    const long kp0 = kphys >= 0 ? kphys : (long)k0;     // where logical k0 sits on the operand's K axis (tap-strided A)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int idx = tid + 256 * j;
         if (KMAJ) {
             const int r = r0 + (idx >> 2), k = k0 + ((idx & 3) << 2);
-            if (FULL) { reg[j] = *reinterpret_cast<const f32x4*>(base + (long)r * ld + k); continue; }
+            const long kp = kp0 + ((idx & 3) << 2);
+            if (FULL) { reg[j] = *reinterpret_cast<const f32x4*>(base + (long)r * ld + kp); continue; }
             int nv = (r < R) ? (Kend - k) : 0;
             nv = nv < 0 ? 0 : nv;
-            reg[j] = load4(base + (long)r * ld + k, nv, vec);
+            reg[j] = load4(base + (long)r * ld + kp, nv, vec);
         } else {
             const int k = k0 + (idx >> 5), r = r0 + ((idx & 31) << 2);
             if (FULL) { reg[j] = *reinterpret_cast<const f32x4*>(base + (long)k * ld + r); continue; }
@@ -379,11 +388,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(GemmK p) {
     // MFMAs, the other set receives tile kt+2 (requested at the top of the iteration: a whole tile of MFMAs to land).
     f32x4 ra[2], rb[2], na[2], nb[2];
     auto load_tile = [&](f32x4 (&xa)[2], f32x4 (&xb)[2], int kt) {
+        const long ka = AK ? a_koff(p, kt * SBK) : -1;
         if (interior && (kt + 1) * SBK <= Kend) {
-            split_stage_load<AK, true>(xa, A, p.lda, m0, kt * SBK, p.M, Kend, true, tid);
+            split_stage_load<AK, true>(xa, A, p.lda, m0, kt * SBK, p.M, Kend, true, tid, ka);
             split_stage_load<BKM, true>(xb, B, p.ldb, n0, kt * SBK, p.N, Kend, true, tid);
         } else {
-            split_stage_load<AK, false>(xa, A, p.lda, m0, kt * SBK, p.M, Kend, p.a_vec, tid);
+            split_stage_load<AK, false>(xa, A, p.lda, m0, kt * SBK, p.M, Kend, p.a_vec, tid, ka);
             split_stage_load<BKM, false>(xb, B, p.ldb, n0, kt * SBK, p.N, Kend, p.b_vec, tid);
         }
     };
@@ -489,6 +499,10 @@ extern "C" int t2_gemm(const T2Gemm* g, void* stream) {
     p.a_vec = (g->lda % 4 == 0) && t2_aligned16(g->A) && (g->sA % 4 == 0);
     p.b_vec = (g->ldb % 4 == 0) && t2_aligned16(g->B) && (g->sB % 4 == 0);
     p.ntm = t2_cdiv(g->M, BM); p.ntn = t2_cdiv(g->N, BN);
+    T2_REQUIRE(g->a_tap_len == 0 || (g->a_kmajor && g->a_tap_len % 32 == 0 && g->a_tap_len > 0 && g->K % g->a_tap_len == 0),
+               "t2_gemm: a_tap_len needs a k-major A, a multiple of 32 and K a whole number of taps");
+    p.a_tap_len = g->a_tap_len; p.a_tap_stride = (long)g->a_tap_stride;
+    if (g->a_tap_len) p.a_vec = p.a_vec && (g->a_tap_stride % 4 == 0);
     dim3 grid(p.ntm * p.ntn, 1, batch * splitk), block(256);
     hipStream_t s = (hipStream_t)stream;
     // share_cu: 24 KB of (unused) dynamic LDS on top of the 73.7 KB static tile buffers -> a second workgroup no longer fits

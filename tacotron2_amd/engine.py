@@ -46,11 +46,12 @@ def set_float32_matmul_precision(name: str) -> None:
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_k=1, b_k=1, alpha=1.0, bias=None, bias2=None, mulmask=None, ldmask=0,
-         relu=0, accumulate=0, splitk=1, batch=1, sA=0, sB=0, sC=0):
+         relu=0, accumulate=0, splitk=1, batch=1, sA=0, sB=0, sC=0, a_tap_len=0, a_tap_stride=0):
     """C-ABI t2_gemm on raw pointers (ints) or tensors."""
     g = make("T2Gemm", A=A, B=B, C=C, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, a_kmajor=a_k, b_kmajor=b_k,
              alpha=alpha, bias=bias, bias2=bias2, mulmask=mulmask, ldmask=ldmask, relu=relu, accumulate=accumulate,
-             splitk=splitk, batch=batch, sA=sA, sB=sB, sC=sC, share_cu=SHARE_CU[0], native_fp32=GEMM_NATIVE_FP32[0], precision=GEMM_PRECISION[0])
+             splitk=splitk, batch=batch, sA=sA, sB=sB, sC=sC, share_cu=SHARE_CU[0], native_fp32=GEMM_NATIVE_FP32[0], precision=GEMM_PRECISION[0],
+             a_tap_len=a_tap_len, a_tap_stride=a_tap_stride)
     call("t2_gemm", g, _stream())
 
 

@@ -4,7 +4,9 @@ keys (weight-normed `weight_g` / `weight_v` as in the published UNIVERSAL_V1 che
 
 Everything is channel-last (T, C) with zero margins of PAD rows on both sides, one utterance at a time:
   * Conv1d(k, dilation d, 'same'): d = 1 is ONE GEMM over overlapping rows (lda = C < K = k*C, as the Tacotron convolutions);
-    d > 1 is k GEMMs over rows shifted by j*d that accumulate into the output (B = the packed weight's tap-j column block);
+    d > 1 is ONE GEMM too - the K axis of an A row is k blocks of C channels that lie d rows apart (T2Gemm.a_tap_len / a_tap_stride) -
+    for channel counts that are multiples of 32 (every layer of the published configurations), else k GEMMs over rows shifted by
+    j*d that accumulate into the output (B = the packed weight's tap-j column block);
   * ConvTranspose1d(k = 2u, stride u, padding u/2) - every upsampling layer of HiFi-GAN - is ONE GEMM: output position
     o = q*u + r - u/2 receives x[q] . W[:, :, r] + x[q-1] . W[:, :, r+u], so the A rows are the overlapping pairs
     [x[q-1] | x[q]] (K = 2*Cin) and the N = u*Cout output columns of row q are u consecutive output positions;
@@ -60,6 +62,10 @@ class _Conv:
         yo = _ptr(y, PAD * Co)
         if self.d == 1:
             gemm(_ptr(x, (PAD - self.p) * Ci), self.wp, yo, L, Co, k * Ci, Ci, k * Ci, Co, bias=self.b, accumulate=1 if accumulate else 0)
+            return
+        if Ci % 32 == 0:     # dilated: still ONE GEMM - the A row's K axis is k blocks of Ci channels, d rows apart (T2Gemm.a_tap_len)
+            gemm(_ptr(x, (PAD - self.p) * Ci), self.wp, yo, L, Co, k * Ci, Ci, k * Ci, Co, bias=self.b,
+                 accumulate=1 if accumulate else 0, a_tap_len=Ci, a_tap_stride=self.d * Ci)
             return
         for j in range(k):
             gemm(_ptr(x, (PAD + j * self.d - self.p) * Ci), _ptr(self.wp, j * Ci), yo, L, Co, Ci, Ci, k * Ci, Co,

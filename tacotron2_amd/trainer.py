@@ -95,10 +95,13 @@ class Trainer:
             out["gate"] = torch.nn.functional.pad(batch["gate"], (0, 0, 0, Tg - T))
         return out
 
-    def train_step(self, batch: dict, masks: Optional[dict] = None):
-        """One optimisation step on this rank's shard.  Returns the device tensor loss3 = (gate, mel, post) means."""
+    def train_step(self, batch: dict, masks: Optional[dict] = None, padded: bool = False):
+        """One optimisation step on this rank's shard.  Returns the device tensor loss3 = (gate, mel, post) means.
+        padded=True: the caller has already brought the shard to the global (L, T) (global_pad) - the per-step shape
+        negotiation, a tiny all-reduce followed by a host read, is skipped."""
         eng, ps = self.engine, self.ps
-        batch = self.global_pad(batch)
+        if not padded:
+            batch = self.global_pad(batch)
         ci, mel = batch["chars_idx"], batch["mel_spectrogram"]
         B, L = ci.shape
         T = mel.shape[1]

@@ -130,6 +130,30 @@ def test_gemm_overlapping_rows_is_conv1d(dev, gemm_kernel):
     assert _rel(got, ref) < 2e-6
 
 
+@pytest.mark.parametrize("Ci,k,d", [(32, 3, 3), (64, 7, 5), (32, 11, 2)])
+def test_gemm_tap_strided_rows_is_dilated_conv1d(dev, gemm_kernel, Ci, k, d):
+    """T2Gemm.a_tap_len / a_tap_stride: the K axis of an A row is k blocks of Ci channels that lie d rows apart -> a dilated
+    'same' Conv1d (model/hifi_gan.py:60-87) as ONE GEMM, with and without accumulation into the output."""
+    from tacotron2_amd.engine import gemm
+    L, Co = 137, 40
+    g = torch.Generator().manual_seed(d)
+    x = torch.randn(L, Ci, generator=g); w = torch.randn(Co, Ci, k, generator=g) / (Ci * k) ** 0.5; bias = torch.randn(Co, generator=g)
+    p = (k * d - d) // 2
+    xp = torch.zeros(L + 2 * p, Ci, dtype=torch.float64); xp[p:p + L] = x.double()
+    ref = bias.double()[None, :].expand(L, -1).clone()
+    for j in range(k):
+        ref += xp[j * d:j * d + L] @ w[:, :, j].double().t()
+    xd = xp.float().to(dev).contiguous()
+    wp = w.permute(0, 2, 1).reshape(Co, k * Ci).contiguous().to(dev)
+    y = torch.zeros(L, Co, device=dev)
+    gemm(xd, wp, y, L, Co, k * Ci, Ci, k * Ci, Co, bias=bias.to(dev), a_tap_len=Ci, a_tap_stride=d * Ci)
+    assert _rel(y, ref) < 2e-6
+    base = torch.randn(L, Co, generator=g)
+    y2 = base.to(dev).clone()
+    gemm(xd, wp, y2, L, Co, k * Ci, Ci, k * Ci, Co, bias=bias.to(dev), accumulate=1, a_tap_len=Ci, a_tap_stride=d * Ci)
+    assert _rel(y2, ref + base.double()) < 2e-6
+
+
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
 def test_split_gemm_is_as_accurate_as_f32_mfma(dev, layout):
     """The bf16x3-split kernel against the f32-input MFMA kernel on a long reduction (K = 4096) with operands spanning many
