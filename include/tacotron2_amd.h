@@ -178,6 +178,9 @@ typedef struct {
      * read instead of dg_next (which must still be non-NULL); dgt_out = tiled copy of dg_out ([4H/16][Bp][16]). */
     const float* dgt_next;
     float* dgt_out;
+    int off_chain;                          /* 1: this step is NOT on the critical chain of its stream schedule (the decoder-LSTM BPTT,
+                                               a chunk ahead on the side stream): its waves keep the default issue priority instead
+                                               of the chain kernels' raised one */
 } T2LstmBwdStep;
 int t2_lstm_step_bwd(const T2LstmBwdStep* steps, int n, void* stream);
 typedef struct { int64_t dg, dg2, ext1, ext2, drop, gates, c_prev, c_cur; int dt; int64_t dgt; } T2LstmBwdStride;

@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(BwdK2 pp) {
 // Fast path of the backward step: ONE contiguous gradient row block dg[b][0:K) (K = N4 + N2) against the packed,
 // zero-padded transposed weight stream; same branch-free double-buffered structure as the forward fast path.
 __global__ __launch_bounds__(256, 1) void lstm_step_bwd_fast_kernel(BwdK2 pp) {
-    T2_CHAIN_PRIO();
+    if (!pp.s[blockIdx.z].off_chain) T2_CHAIN_PRIO();
     __shared__ float red[4 * 256];
     t2_lstm_bwd_fast_body<4, 4>(pp.s[blockIdx.z], blockIdx.x, blockIdx.y, red);
 }

@@ -220,6 +220,7 @@ struct BwdK {
     float* dg_out2; long ldgo2;
     const int32_t* len; int t;
     const float* dgt; long dgt_cs; float* dgt_out;   // x16-tiled dg_next / dg_out (chunk stride Bp*16 floats)
+    int off_chain;                      // T2LstmBwdStep.off_chain
 };
 struct BwdK2 { BwdK s[2]; };
 
@@ -233,6 +234,7 @@ inline void t2_lstm_to_bk(const T2LstmBwdStep& s, BwdK& k) {
     k.gates = s.gates; k.ldgs = s.ldgs; k.c_prev = s.c_prev; k.ldcp = s.ldcp; k.c_cur = s.c_cur; k.ldcc = s.ldcc;
     k.dc = s.dc; k.lddc = s.lddc; k.dg_out = s.dg_out; k.ldgo = s.ldgo; k.len = s.len; k.t = s.t;
     k.dgt = s.dgt_next; k.dgt_out = s.dgt_out; k.dgt_cs = (long)((s.B + 15) / 16 * 16) * 16;
+    k.off_chain = s.off_chain;
 }
 
 inline int t2_lstm_check_bwd(const T2LstmBwdStep& s) {

@@ -108,7 +108,7 @@ class Engine:
         self._ws: Dict[str, torch.Tensor] = {}
         self._side = None
         self.chunk = 64               # frames per pipeline chunk of the forward frame loop
-        self.chunk_bwd = 80           # frames per chunk of the backward pipeline (80*32 rows = 240 tiles of the dxdec GEMM)
+        self.chunk_bwd = 64           # frames per chunk of the backward pipeline (r03: 64 beats 80 by 0.2 ms with the BPTT launches at default wave priority)
         self.dec_chain = "persistent" # forward decoder-LSTM chain: "persistent" (one weight-stationary launch per chunk on the side
                                       # stream) or "hosted" (its steps ride in the attention-energies launches)
         self.persist_gemm_side = True    # the hoisted pre_dec GEMM of a chunk runs on the side stream too, in front of the chunk's
@@ -121,6 +121,7 @@ class Engine:
         self.ramp_chunks = True       # short chunks at the un-overlapped end of the forward / start of the backward pipeline
         self.share_cu = 1             # side-stream GEMMs next to the chains at ONE workgroup per CU: two 73 KB-LDS workgroups
                                       # per CU lock the attention kernels out (84.3 -> 83.2 ms)
+        self.bptt_off_chain = True    # the decoder-LSTM BPTT launches (side stream, a chunk ahead) keep the default wave priority
         self.sync_bn_group = None     # torch.distributed group: BatchNorm statistics over all ranks' shards (Trainer(sync_bn=True))
         self.grad_tail_hook = None    # called on the side stream once the gradients from prenet.0.weight onwards are enqueued
         self.generation = 0           # bumped by every forward: activations live in the shared named workspaces,
@@ -751,7 +752,8 @@ class Engine:
                      gates=_ptr(ctx["gates_dec"], (hi - 1) * B * 4 * D), ldgs=4 * D,
                      c_prev=_ptr(ctx["dec_c"], (hi - 1) * B * D), ldcp=D, c_cur=_ptr(ctx["dec_c"], hi * B * D), ldcc=D,
                      dc=dc_dec, lddc=D, dg_out=_ptr(dgd, (hi - 1) * B * 4 * D), ldgo=4 * D,
-                     dgt_next=_ptr(dgd_t, hi * Bp * 4 * D), dgt_out=_ptr(dgd_t, (hi - 1) * Bp * 4 * D))
+                     dgt_next=_ptr(dgd_t, hi * Bp * 4 * D), dgt_out=_ptr(dgd_t, (hi - 1) * Bp * 4 * D),
+                     off_chain=1 if self.bptt_off_chain else 0)
             inc = make("T2LstmBwdStride", dg=-B * 4 * D, ext1=-B * ldp, drop=-B * D, gates=-B * 4 * D, c_prev=-B * D,
                        c_cur=-B * D, dt=0, dgt=-Bp * 4 * D)
             return s, inc
