@@ -123,13 +123,13 @@ def _bench_length_case(d, B, L, T, seed, dev):
 
 
 def _default_schedule(eng):
-    """The bench's schedule, untouched: 64-frame forward chunks with the persistent decoder-LSTM launches, 80-frame backward
+    """The bench's schedule, untouched: 64-frame forward chunks with the persistent decoder-LSTM launches, 64-frame backward
     chunks with ramps, weight gradients in groups of four chunks, deferred weight-gradient GEMMs."""
     from tacotron2_amd.engine import _chunk_sizes
-    assert (eng.chunk, eng.chunk_bwd, eng.dec_chain, eng.wgrad_group) == (64, 80, "persistent", 4)
-    assert eng.ramp_chunks and eng.defer_wgrads and eng.chunk_att_wgrads
+    assert (eng.chunk, eng.chunk_bwd, eng.dec_chain, eng.wgrad_group) == (64, 64, "persistent", 4)
+    assert eng.ramp_chunks and eng.defer_wgrads and eng.chunk_att_wgrads and eng.bptt_off_chain
     assert _chunk_sizes(160, eng.chunk) == [64, 32, 32, 16, 8, 8]           # a full 64-frame persistent launch + the ramp
-    assert _chunk_sizes(160, eng.chunk_bwd) == [80, 40, 20, 10, 10]         # five backward chunks: two weight-gradient groups
+    assert _chunk_sizes(160, eng.chunk_bwd) == [64, 32, 32, 16, 8, 8]       # six backward chunks: two weight-gradient groups
 
 
 def test_vanilla_dims_bench_lengths_train_step_matches_oracle():
