@@ -226,7 +226,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // forward gets 6 ms slower.)
 template <int MT>
 __global__ __launch_bounds__(256, 1) void lstm_seq_persist_fwd_kernel(PersistK pp) {
-    T2_CHAIN_PRIO();
+    T2_CHAIN_PRIO();      // (default priority for this launch: +0.25 ms per step, profiles/r03_ab_bptt_priority_chunks.txt)
     extern __shared__ __attribute__((aligned(16))) float plds[];
     const LstmK& p = pp.s;
     const int tid = threadIdx.x, lane = tid & 63;
