@@ -139,34 +139,140 @@ __device__ __forceinline__ void load_taps(const float* Us, int al, float (&uk)[2
     }
 }
 
+// ---- exact fp32 products on the bf16 matrix pipe (the scheme of csrc/t2_gemm.hip): a = h + m + l with three bf16 terms, six of
+//      the nine cross products issued, the small ones into their own accumulator ----
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+struct Split8 { bf16x8 h, m, l; };
+__device__ __forceinline__ unsigned at_pk_bf16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2v));
+}
+__device__ __forceinline__ Split8 t2_split8(const float (&v)[8]) {
+    u32x4v h, m, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = at_pk_bf16(v[2 * i], v[2 * i + 1]);
+        const float r0 = v[2 * i] - __builtin_bit_cast(float, h[i] << 16), r1 = v[2 * i + 1] - __builtin_bit_cast(float, h[i] & 0xffff0000u);
+        m[i] = at_pk_bf16(r0, r1);
+        const float q0 = r0 - __builtin_bit_cast(float, m[i] << 16), q1 = r1 - __builtin_bit_cast(float, m[i] & 0xffff0000u);
+        l[i] = at_pk_bf16(q0, q1);
+    }
+    Split8 s;
+    s.h = __builtin_bit_cast(bf16x8, h); s.m = __builtin_bit_cast(bf16x8, m); s.l = __builtin_bit_cast(bf16x8, l);
+    return s;
+}
+// hi/lo += A (x) B for one K = 32 block of v_mfma_f32_16x16x32_bf16 (lane l: A[row l&15][8(l>>4) + j], B[8(l>>4) + j][col l&15];
+// C: col = l&15, row = 4(l>>4) + reg)
+__device__ __forceinline__ void t2_mfma6(const Split8& a, const Split8& b, f32x4& hi, f32x4& lo) {
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.l, lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.m, lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.h, lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.m, lo, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, hi, 0, 0, 0);
+}
+
+// The location convolution of a (sample, 16-dim slice) is a small GEMM: loc[l][a] = sum_{(c,k)} IN[l][(c,k)] * U[a][(c,k)] with the
+// Toeplitz operand IN[l][(c,k)] = in[c][l + k - 15] read straight from the haloed input rows in LDS - M = positions (tiles of 16),
+// N = the slice's 16 dims, K = 2 x 32 taps - on v_mfma_f32_16x16x32_bf16 with exactly split operands (1.3 us of packed FMAs before).
+// A lane ends up with 4 consecutive positions of ONE dim (C layout), the shape the tanh stash and the processed-memory rows are
+// accessed in, and the sum over the slice's dims is a 16-lane DPP row reduction - no LDS round trip for the partial energies.
+// Eight waves: two position tiles and two query dims per wave for L <= 256 (a 1024-thread build ended each kernel 0.3 us earlier and
+// every launch 1.5 us later: sixteen waves per workgroup take that much longer to start and drain).  At most 128 VGPRs: two of
+// these waves and one wave of a side-stream GEMM workgroup (up to 256 VGPRs) must fit one SIMD's register file, or the chain
+// waits for GEMM tiles to finish (a 148-register build cost 2.3 ms per training step).
+//
+// Both MFMA operands are split into their three bf16 planes ONCE, by the thread that stages the value, on its way into LDS:
+//   inputs   PX[plane][i] = the dword (x[i], x[i+1]) for EVERY i (each value is written as the low half of item i and the high
+//            half of item i-1), so a lane's 8 consecutive taps at any offset o are the four dwords PX[o], PX[o+2], PX[o+4], PX[o+6];
+//   filters  UX[plane][dim][c][tap] as bf16 with a row stride of 40 dwords: a lane's 8 taps are one 16-byte read, conflict-free
+//            over the 16 dims of a lane group.
+struct Bf3 { unsigned short h, m, l; };
+__device__ __forceinline__ Bf3 t2_split1(float v) {
+    Bf3 s;
+    const unsigned hh = at_pk_bf16(v, 0.f) & 0xffffu;
+    const float r = v - __builtin_bit_cast(float, hh << 16);
+    const unsigned mm = at_pk_bf16(r, 0.f) & 0xffffu;
+    const float t = r - __builtin_bit_cast(float, mm << 16);
+    s.h = (unsigned short)hh; s.m = (unsigned short)mm; s.l = (unsigned short)(at_pk_bf16(t, 0.f) & 0xffffu);
+    return s;
+}
+
+template <int NTH>
+__device__ __forceinline__ void stage_commit_split(const StageRegs<NTH>& r, unsigned* PX, unsigned* UX, const float* w_prev, long ldw,
+                                                   const float* cum_prev, long ldcum, const float* dummy, int b, int L, int Lp, int tid) {
+    constexpr int PER = 1024 / NTH;
+    const float* wsrc = w_prev ? w_prev + (long)b * ldw : dummy;
+    const float* csrc = cum_prev ? cum_prev + (long)b * ldcum : dummy;
+    const bool wz = w_prev == nullptr, cz = cum_prev == nullptr;
+    unsigned short* px = reinterpret_cast<unsigned short*>(PX);
+    unsigned short* ux = reinterpret_cast<unsigned short*>(UX);
+    auto put = [&](int idx, float v) {
+        const Bf3 s = t2_split1(v);
+        px[2 * idx] = s.h; px[2 * (2 * Lp + idx)] = s.m; px[2 * (4 * Lp + idx)] = s.l;
+        if (idx > 0) { px[2 * idx - 1] = s.h; px[2 * (2 * Lp + idx) - 1] = s.m; px[2 * (4 * Lp + idx) - 1] = s.l; }
+    };
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int idx = tid + NTH * i;
+        const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
+        const bool ok = l >= 0 && l < L && !(c ? cz : wz);
+        if (idx < 2 * Lp) put(idx, ok ? r.iv[i] : 0.f);
+    }
+    for (int base = 1024; base < 2 * Lp; base += 1024) {   // long texts (2*Lp > 1024): further rounds, load then store
+        float iv[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = base + tid + NTH * i;
+            const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
+            const int lc = imin(imax(l, 0), L - 1);
+            iv[i] = (c ? csrc : wsrc)[lc];
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = base + tid + NTH * i;
+            const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
+            const bool ok = l >= 0 && l < L && !(c ? cz : wz);
+            if (idx < 2 * Lp) put(idx, ok ? iv[i] : 0.f);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int idx = tid + NTH * i, al = idx >> 6, c = (idx >> 5) & 1, k = idx & 31;
+        const Bf3 s = t2_split1(k < KL ? r.uv[i] : 0.f);
+        const int o = al * 80 + c * 32 + k;
+        ux[o] = s.h; ux[1280 + o] = s.m; ux[2560 + o] = s.l;
+    }
+}
+
 __device__ __forceinline__ void attn_energy_body(const AttnK& p, const int b, const int j, float* sm) {
     const int tid = threadIdx.x, lane = tid & 63;
     const bool stamp = b == 0 && j == 0 && tid == 0;
     T2_STAMP(p, stamp, 0);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
-    const int al = tid >> 5, sub = tid & 31, a = j * 16 + al;
-    const int L = p.L, NG = (L + 3) >> 2, Lp = 4 * NG + 36;
-    float* inp = sm;             // [2][Lp]   zero-haloed (w_prev, cum_prev), index l + 15
-    float* Us = inp + 2 * Lp;    // [16][2][32] folded location filter rows of this slice
-    float* qs = Us + 16 * 64;    // [16]
-    float* ec = qs + 16;         // [16][4*NG] per-dim energy contributions
+    const int n = lane & 15, q = lane >> 4;                   // MFMA column = dim of the slice (also this lane's A row), row group
+    const int a = j * 16 + n;
+    const int L = p.L, NG = (L + 3) >> 2, L4 = 4 * NG, NT = (L + 15) >> 4, Lp = 4 * NG + 48;
+    float* qs = sm;                                           // [16]
+    unsigned* PX = reinterpret_cast<unsigned*>(qs + 16);      // [3][2*Lp]  haloed (w_prev, cum_prev) at index l + 15, neighbour pairs
+    unsigned* UX = PX + 6 * Lp;                               // [3][16*40] folded location filter rows of this slice (tap 31 = 0)
     const long rowoff = ((long)b * p.Ad + a) * L;
 
     // ---- issue first: the haloed location inputs and filter rows (the only loads the convolution waits for) ----
     StageRegs<ENT> sr;
     stage_issue<ENT>(sr, p.w_prev, p.ldw, p.cum_prev, p.ldcum, p.U, p.pmT, b, j, L, Lp, tid);
-    // ---- issue: first round of processed-memory values + v ----
-    float pmv[EMAXI][4];
+    // ---- issue: processed-memory values of this wave's first two position tiles (mt = w, w + 8) + v ----
+    float pmv[2][4];
     const float va = p.v[a];
 #pragma unroll
-    for (int it = 0; it < EMAXI; ++it) {
-        const int lg = imin(2 * sub + it, NG - 1);   // a thread owns two ADJACENT 4-position groups (8 positions)
+    for (int it = 0; it < 2; ++it) {
+        const int lg = imin(4 * (w + 8 * it) + q, NG - 1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) pmv[it][i] = p.pmT[rowoff + imin(4 * lg + i, L - 1)];
     }
-    // ---- issue: query-projection operands of the first 1024 columns (2 dims per wave, 16-byte loads).  They are consumed
-    //      AFTER the location convolution, which does not depend on the query: the 64 KB of Wq rows arrive while the
-    //      convolution runs, and only the small staging loads sit in front of it ----
+    // ---- issue: query-projection operands of the first 1024 columns (2 dims per wave, 16-byte loads); consumed after the
+    //      convolution, when the 64 KB of Wq rows have arrived ----
     const float* h = p.att_h + (long)b * p.ldh;
     const float* wq0 = p.Wq + (long)(j * 16 + w * 2) * p.A;
     f32x4 hv[4], wv[2][4];
@@ -177,132 +283,120 @@ __device__ __forceinline__ void attn_energy_body(const AttnK& p, const int b, co
 #pragma unroll
         for (int aa = 0; aa < 2; ++aa) wv[aa][i] = *reinterpret_cast<const f32x4*>(wq0 + (long)aa * p.A + k);
     }
-    stage_commit<ENT>(sr, inp, Us, p.w_prev, p.ldw, p.cum_prev, p.ldcum, p.pmT, b, L, Lp, tid);
-    __syncthreads();   // staging visible
+    stage_commit_split<ENT>(sr, PX, UX, p.w_prev, p.ldw, p.cum_prev, p.ldcum, p.pmT, b, L, Lp, tid);
+    __syncthreads();   // planes visible
     T2_STAMP(p, stamp, 1);
-
-    float qa = 0.f;
-    for (int base = 0; base < NG; base += 32 * EMAXI) {
-        if (base > 0) {   // later rounds (L > 256)
+    // ---- fragments: filter rows of this lane's dim (B: taps 8q .. 8q+7 of channel c) and a tile's Toeplitz rows
+    //      (A: IN[l = 16 mt + n][(c, 8q + jj)] = in[c][l + 8q + jj - 15] = padded index c*Lp + l + 8q + jj) ----
+    Split8 bs[2];
 #pragma unroll
-            for (int it = 0; it < EMAXI; ++it) {
-                const int lg = imin(base + 2 * sub + it, NG - 1);
+    for (int c = 0; c < 2; ++c) {
+        const int o = n * 40 + c * 16 + 4 * q;
+        bs[c].h = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(UX + o));
+        bs[c].m = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(UX + 640 + o));
+        bs[c].l = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(UX + 1280 + o));
+    }
+    auto conv_tile = [&](int mt) -> f32x4 {
+        Split8 as[2];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) pmv[it][i] = p.pmT[rowoff + imin(4 * lg + i, L - 1)];
-            }
+        for (int c = 0; c < 2; ++c) {
+            const unsigned* ap = PX + c * Lp + 16 * mt + n + 8 * q;
+            as[c].h = __builtin_bit_cast(bf16x8, (u32x4v){ap[0], ap[2], ap[4], ap[6]});
+            as[c].m = __builtin_bit_cast(bf16x8, (u32x4v){ap[2 * Lp], ap[2 * Lp + 2], ap[2 * Lp + 4], ap[2 * Lp + 6]});
+            as[c].l = __builtin_bit_cast(bf16x8, (u32x4v){ap[4 * Lp], ap[4 * Lp + 2], ap[4 * Lp + 4], ap[4 * Lp + 6]});
         }
-        // 8 adjacent positions x 31 taps x 2 channels on packed FMAs.  Position pairs (0,1) (2,3) (4,5) (6,7) are the halves
-        // of four v_pk_fma_f32 accumulators; the window pairs (win[k], win[k+1]) are the register pairs of the aligned LDS
-        // read for even k and pairs built with one v_pk_mov_b32 each for odd k, the tap is broadcast through op_sel.  The
-        // two groups share one 40-float window: 10 x 16-byte LDS reads per channel instead of 18.
-        float acc[EMAXI][4];
-        {
-            const int lg0 = imin(base + 2 * sub, NG - 1);
-            f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f}, a45 = {0.f, 0.f}, a67 = {0.f, 0.f};
-#pragma nounroll
-            for (int c = 0; c < 2; ++c) {
-                float ukc[32];   // this channel's taps (read per channel: both channels' taps at once spill registers)
-                {
-                    const f32x4* up = reinterpret_cast<const f32x4*>(Us + al * 64 + c * 32);
+        f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, l0 = h0, l1 = h0, l2 = h0;     // four independent accumulators
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const f32x4 t = up[i];
-                        ukc[4 * i] = t[0]; ukc[4 * i + 1] = t[1]; ukc[4 * i + 2] = t[2]; ukc[4 * i + 3] = t[3];
-                    }
-                }
-                // aligned window pairs from one 40-float LDS read; the odd-aligned pairs are built in registers
-                // (one v_pk_mov_b32 each), so even and odd taps both run on v_pk_fma_f32 without repacking
-                f32x2 we[20], wo[19];
-                const f32x4* wp = reinterpret_cast<const f32x4*>(inp + c * Lp + 4 * lg0);
-#pragma unroll
-                for (int i = 0; i < 10; ++i) {
-                    const f32x4 t = wp[i];
-                    we[2 * i] = (f32x2){t[0], t[1]}; we[2 * i + 1] = (f32x2){t[2], t[3]};
-                }
-#pragma unroll
-                for (int m = 0; m < 19; ++m) wo[m] = (f32x2){we[m][1], we[m + 1][0]};
-#pragma unroll
-                for (int k = 0; k < KL; ++k) {
-                    const f32x2 u = {ukc[k], ukc[k]};
-                    if ((k & 1) == 0) {
-                        a01 = __builtin_elementwise_fma(u, we[k / 2], a01);
-                        a23 = __builtin_elementwise_fma(u, we[k / 2 + 1], a23);
-                        a45 = __builtin_elementwise_fma(u, we[k / 2 + 2], a45);
-                        a67 = __builtin_elementwise_fma(u, we[k / 2 + 3], a67);
-                    } else {
-                        a01 = __builtin_elementwise_fma(u, wo[k / 2], a01);
-                        a23 = __builtin_elementwise_fma(u, wo[k / 2 + 1], a23);
-                        a45 = __builtin_elementwise_fma(u, wo[k / 2 + 2], a45);
-                        a67 = __builtin_elementwise_fma(u, wo[k / 2 + 3], a67);
-                    }
-                }
-            }
-            acc[0][0] = a01[0]; acc[0][1] = a01[1]; acc[0][2] = a23[0]; acc[0][3] = a23[1];
-            acc[1][0] = a45[0]; acc[1][1] = a45[1]; acc[1][2] = a67[0]; acc[1][3] = a67[1];
+        for (int c = 0; c < 2; ++c) {
+            l0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as[c].l, bs[c].h, l0, 0, 0, 0);
+            l1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as[c].h, bs[c].l, l1, 0, 0, 0);
+            l2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as[c].m, bs[c].m, l2, 0, 0, 0);
+            l0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as[c].m, bs[c].h, l0, 0, 0, 0);
+            l1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as[c].h, bs[c].m, l1, 0, 0, 0);
+            h0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as[c].h, bs[c].h, h0, 0, 0, 0);
         }
-        T2_STAMP(p, stamp && base == 0, 4);
-        if (base == 0) {   // query projection: dot products of the hoisted operands (+ the columns past 1024), wave sums
-            float qacc[2] = {0.f, 0.f};
+        return h0 + ((l0 + l1) + l2);
+    };
+    // ---- the convolution of this wave's position tiles on the matrix pipe (independent of the query) ----
+    f32x4 loc[2];
+    loc[0] = w < NT ? conv_tile(w) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    loc[1] = w + 8 < NT ? conv_tile(w + 8) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    T2_STAMP(p, stamp, 4);
+    // ---- query projection: dot products of the hoisted operands (+ the columns past 1024), wave sums -> qs ----
+    {
+        float qacc[2] = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float okf = (lane * 4 + 256 * i) < p.A ? 1.f : 0.f;
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa)
+                qacc[aa] += okf * (hv[i][0] * wv[aa][i][0] + hv[i][1] * wv[aa][i][1] + hv[i][2] * wv[aa][i][2] +
+                                   hv[i][3] * wv[aa][i][3]);
+        }
+        for (int k0 = lane * 4 + 1024; k0 < p.A; k0 += 1024) {
+            f32x4 hv2[4], wv2[2][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float okf = (lane * 4 + 256 * i) < p.A ? 1.f : 0.f;
+                const int k = imin(k0 + 256 * i, p.A - 4);
+                hv2[i] = *reinterpret_cast<const f32x4*>(h + k);
+#pragma unroll
+                for (int aa = 0; aa < 2; ++aa) wv2[aa][i] = *reinterpret_cast<const f32x4*>(wq0 + (long)aa * p.A + k);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float okf = (k0 + 256 * i) < p.A ? 1.f : 0.f;
 #pragma unroll
                 for (int aa = 0; aa < 2; ++aa)
-                    qacc[aa] += okf * (hv[i][0] * wv[aa][i][0] + hv[i][1] * wv[aa][i][1] + hv[i][2] * wv[aa][i][2] +
-                                       hv[i][3] * wv[aa][i][3]);
+                    qacc[aa] += okf * (hv2[i][0] * wv2[aa][i][0] + hv2[i][1] * wv2[aa][i][1] + hv2[i][2] * wv2[aa][i][2] +
+                                       hv2[i][3] * wv2[aa][i][3]);
             }
-            for (int k0 = lane * 4 + 1024; k0 < p.A; k0 += 1024) {
-                f32x4 hv2[4], wv2[2][4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int k = imin(k0 + 256 * i, p.A - 4);
-                    hv2[i] = *reinterpret_cast<const f32x4*>(h + k);
-#pragma unroll
-                    for (int aa = 0; aa < 2; ++aa) wv2[aa][i] = *reinterpret_cast<const f32x4*>(wq0 + (long)aa * p.A + k);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float okf = (k0 + 256 * i) < p.A ? 1.f : 0.f;
-#pragma unroll
-                    for (int aa = 0; aa < 2; ++aa)
-                        qacc[aa] += okf * (hv2[i][0] * wv2[aa][i][0] + hv2[i][1] * wv2[aa][i][1] + hv2[i][2] * wv2[aa][i][2] +
-                                           hv2[i][3] * wv2[aa][i][3]);
-                }
-            }
-            // wave w computed dims 2w and 2w+1 - exactly the dims of its own lanes (al = tid >> 5): no exchange, no barrier
-            const float sq0 = t2_wave_sum(qacc[0]), sq1 = t2_wave_sum(qacc[1]);
-            qa = lane < 32 ? sq0 : sq1;
-            T2_STAMP(p, stamp, 5);
         }
+        const float sq0 = t2_wave_sum(qacc[0]), sq1 = t2_wave_sum(qacc[1]);
+        if (lane == 0) { qs[2 * w] = sq0; qs[2 * w + 1] = sq1; }
+        T2_STAMP(p, stamp, 5);
+    }
+    __syncthreads();   // qs visible
+    const float qa = qs[n];
+    // this lane: dim n, positions 16 mt + 4q + i
+    auto epilogue = [&](int mt, const f32x4 acc, const float (&pm4)[4]) {
+        const int lg = 4 * mt + q;
+        f32x4 th4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int it = 0; it < EMAXI; ++it) {
-            const int lg = base + 2 * sub + it;
-            if (lg >= NG) continue;
-            f32x4 th4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int l = 4 * lg + i;
-                if (l < L) {
-                    th4[i] = t2_tanh(qa + acc[it][i] + pmv[it][i]);
-                    ec[al * 4 * NG + l] = va * th4[i];
-                }
-            }
-            // tanh stash rows are padded to 4*NG floats: one aligned 16-byte store per item
-            if (p.th_out) *reinterpret_cast<f32x4*>(p.th_out + ((long)b * p.Ad + a) * (4 * NG) + 4 * lg) = th4;
+        for (int i = 0; i < 4; ++i) {
+            const int l = 4 * lg + i;
+            if (l < L) th4[i] = t2_tanh(qa + acc[i] + pm4[i]);
         }
+        // tanh stash rows are padded to 4*NG floats: one aligned 16-byte store per lane
+        if (p.th_out && lg < NG) *reinterpret_cast<f32x4*>(p.th_out + ((long)b * p.Ad + a) * L4 + 4 * lg) = th4;
+        // Sum over the slice's 16 dims = the 16 lanes of this row group, for 4 positions at once: two exchange steps leave lane
+        // (n & 3) = i with position i's sum over its quad, two rotations add the four quads (4 DPP adds instead of 16).
+        const float e0 = va * th4[0], e1 = va * th4[1], e2 = va * th4[2], e3 = va * th4[3];
+        const bool b0 = n & 1, b1 = n & 2;
+        float x = b0 ? e1 : e0, y = b0 ? e0 : e1;          // keep the value of my parity, hand the other to my neighbour
+        float z = b0 ? e3 : e2, u = b0 ? e2 : e3;
+        x += t2_dpp<0xB1, 0xf>(0.f, y);                    // quad_perm [1,0,3,2]: lane gets its parity's value from the neighbour
+        z += t2_dpp<0xB1, 0xf>(0.f, u);
+        float s = b1 ? z : x, t = b1 ? x : z;              // lanes 0,1 keep positions 0,1; lanes 2,3 keep positions 2,3
+        s += t2_dpp<0x4E, 0xf>(0.f, t);                    // quad_perm [2,3,0,1]
+        s += t2_dpp<0x124, 0xf>(0.f, s);                   // row_ror:4
+        s += t2_dpp<0x128, 0xf>(0.f, s);                   // row_ror:8 -> lane n holds position (n & 3)'s sum over all 16 dims
+        const int lw = 4 * lg + n;
+        if (n < 4 && lw < L) p.e_part[((long)b * (p.Ad >> 4) + j) * L + lw] = s;
+    };
+    if (w < NT) epilogue(w, loc[0], pmv[0]);
+    if (w + 8 < NT) epilogue(w + 8, loc[1], pmv[1]);
+    for (int mt = w + 16; mt < NT; mt += 8) {     // long texts (L > 256): further tiles, load then compute
+        float pm4[4];
+        const int lgc = imin(4 * mt + q, NG - 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pm4[i] = p.pmT[rowoff + imin(4 * lgc + i, L - 1)];
+        epilogue(mt, conv_tile(mt), pm4);
     }
     T2_STAMP(p, stamp, 2);
-    __syncthreads();
-    for (int l = tid; l < L; l += ENT) {
-        float s = 0.f;
-#pragma unroll
-        for (int al2 = 0; al2 < 16; ++al2) s += ec[al2 * 4 * NG + l];
-        p.e_part[((long)b * (p.Ad >> 4) + j) * L + l] = s;
-    }
     T2_STAMP(p, stamp, 3);
 }
 
-__global__ __launch_bounds__(ENT, 2) void attn_energy_kernel(AttnK p) {
+__global__ __launch_bounds__(ENT, 4) void attn_energy_kernel(AttnK p) {
     T2_CHAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) float sm[];
     attn_energy_body(p, blockIdx.x, blockIdx.y, sm);
@@ -466,8 +560,8 @@ bool co_eligible(const T2LstmStep& c) { return c.wpacked && c.nseg == 1 && c.B <
 int launch_attn(const T2AttnStep& s, hipStream_t st, const T2LstmStep* co = nullptr) {
     AttnK k;
     to_ak(s, k);
-    const int NG = (s.L + 3) >> 2, Lp = 4 * NG + 36;
-    const size_t sm_e = (size_t)(2 * Lp + 16 * 64 + 16 + 16 * 4 * NG) * sizeof(float);
+    const int NG = (s.L + 3) >> 2, Lp = 4 * NG + 48;
+    const size_t sm_e = (size_t)(16 + 6 * Lp + 3 * 640) * sizeof(float);
     const int wsn = ((s.L + 3) & ~3) > 192 ? ((s.L + 3) & ~3) : 192;
     const size_t sm_c = (size_t)(wsn + 8 + 256) * sizeof(float);
     T2_REQUIRE(t2_allow_lds(attn_energy_kernel, sm_e), "attention: LDS budget exceeded (energies kernel)");

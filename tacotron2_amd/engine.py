@@ -111,6 +111,7 @@ class Engine:
         self.chunk_bwd = 64           # frames per chunk of the backward pipeline (r03: 64 beats 80 by 0.2 ms with the BPTT launches at default wave priority)
         self.dec_chain = "persistent" # forward decoder-LSTM chain: "persistent" (one weight-stationary launch per chunk on the side
                                       # stream) or "hosted" (its steps ride in the attention-energies launches)
+        self.share_cu_fwd = None      # (A/B knob) share_cu of the forward's chunk GEMMs; None = self.share_cu
         self.persist_gemm_side = True    # the hoisted pre_dec GEMM of a chunk runs on the side stream too, in front of the chunk's
                                          # persistent launch (70.0 against 71.3 ms per step on the main stream, profiles/r02_ab_fwd_dec_chain.txt)
         self._persist_sync = None
@@ -516,7 +517,7 @@ class Engine:
                 with torch.cuda.stream(side):
                     side.wait_event(ev)
                     if self.persist_gemm_side:
-                        SHARE_CU[0] = self.share_cu
+                        SHARE_CU[0] = self.share_cu if self.share_cu_fwd is None else self.share_cu_fwd
                         pre_dec_gemm(c0, c1)
                         SHARE_CU[0] = 0
                     stp, inc = dec_chunk(c0, c1)
