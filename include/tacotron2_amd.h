@@ -276,6 +276,10 @@ typedef struct {
                                         zero-filled by the caller; read by the per-frame products of dgates[t+1] */
     uint64_t* clk;                   /* diagnostic, normally NULL: 32 device words, s_memtime stamps of workgroup (0,0) at phase
                                         boundaries of the dw kernel [16..19] and the ds kernel [24..30] */
+    float* ws_bd;                    /* optional workspace of (Ad/16) * 15360 floats: with it (and L <= 208) the per-slice kernel runs its
+                                        two correlations (dU, d_in) on the bf16 matrix pipe with exactly split operands; the workspace
+                                        receives the filter operand of d_in in fragment layout, rewritten by every call (same results
+                                        to fp32 rounding; NULL = the packed-FMA kernel) */
 } T2AttnSeqBwd;
 int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream);
 

@@ -54,23 +54,28 @@ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 template <int NTH>
 struct StageRegs { float uv[1024 / NTH]; float iv[1024 / NTH]; };
 
-template <int NTH>
+// DO_INP / DO_U: which of the two images a kernel needs (the matrix-pipe ds kernel takes its filter operand from global memory)
+template <int NTH, bool DO_INP = true, bool DO_U = true>
 __device__ __forceinline__ void stage_issue(StageRegs<NTH>& r, const float* w_prev, long ldw, const float* cum_prev, long ldcum,
-                                            const float* U, const float* dummy, int b, int j, int L, int Lp, int tid) {
+                                            const float* U, const float* dummy, int b, int j, int L, int Lp, int tid, int kpad = KPAD) {
     constexpr int PER = 1024 / NTH;
     const float* wsrc = w_prev ? w_prev + (long)b * ldw : dummy;
     const float* csrc = cum_prev ? cum_prev + (long)b * ldcum : dummy;
+    if (DO_U) {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {   // Us[al][c][32]: taps 0..30 of channel c, tap 31 = 0 (rows padded for aligned 16-byte reads)
-        const int idx = tid + NTH * i, al = idx >> 6, c = (idx >> 5) & 1, k = idx & 31;
-        r.uv[i] = U[(long)(j * 16 + al) * 2 * KL + c * KL + imin(k, KL - 1)];
+        for (int i = 0; i < PER; ++i) {   // Us[al][c][32]: taps 0..30 of channel c, tap 31 = 0 (rows padded for aligned 16-byte reads)
+            const int idx = tid + NTH * i, al = idx >> 6, c = (idx >> 5) & 1, k = idx & 31;
+            r.uv[i] = U[(long)(j * 16 + al) * 2 * KL + c * KL + imin(k, KL - 1)];
+        }
     }
+    if (DO_INP) {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int idx = tid + NTH * i;
-        const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
-        const int lc = imin(imax(l, 0), L - 1);
-        r.iv[i] = (c ? csrc : wsrc)[lc];
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + NTH * i;
+            const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - kpad;
+            const int lc = imin(imax(l, 0), L - 1);
+            r.iv[i] = (c ? csrc : wsrc)[lc];
+        }
     }
 }
 
@@ -162,6 +167,18 @@ __device__ __forceinline__ Split8 t2_split8(const float (&v)[8]) {
     s.h = __builtin_bit_cast(bf16x8, h); s.m = __builtin_bit_cast(bf16x8, m); s.l = __builtin_bit_cast(bf16x8, l);
     return s;
 }
+struct Split3 { uint2 h, m, l; };
+__device__ __forceinline__ Split3 split3_attn(const f32x4 v) {      // four values -> packed (v0,v1), (v2,v3) of every plane
+    Split3 s;
+    s.h.x = at_pk_bf16(v[0], v[1]); s.h.y = at_pk_bf16(v[2], v[3]);
+    const float r0 = v[0] - __builtin_bit_cast(float, s.h.x << 16), r1 = v[1] - __builtin_bit_cast(float, s.h.x & 0xffff0000u);
+    const float r2 = v[2] - __builtin_bit_cast(float, s.h.y << 16), r3 = v[3] - __builtin_bit_cast(float, s.h.y & 0xffff0000u);
+    s.m.x = at_pk_bf16(r0, r1); s.m.y = at_pk_bf16(r2, r3);
+    const float q0 = r0 - __builtin_bit_cast(float, s.m.x << 16), q1 = r1 - __builtin_bit_cast(float, s.m.x & 0xffff0000u);
+    const float q2 = r2 - __builtin_bit_cast(float, s.m.y << 16), q3 = r3 - __builtin_bit_cast(float, s.m.y & 0xffff0000u);
+    s.l.x = at_pk_bf16(q0, q1); s.l.y = at_pk_bf16(q2, q3);
+    return s;
+}
 // hi/lo += A (x) B for one K = 32 block of v_mfma_f32_16x16x32_bf16 (lane l: A[row l&15][8(l>>4) + j], B[8(l>>4) + j][col l&15];
 // C: col = l&15, row = 4(l>>4) + reg)
 __device__ __forceinline__ void t2_mfma6(const Split8& a, const Split8& b, f32x4& hi, f32x4& lo) {
@@ -199,9 +216,10 @@ __device__ __forceinline__ Bf3 t2_split1(float v) {
     return s;
 }
 
-template <int NTH>
+template <int NTH, bool DO_U = true>
 __device__ __forceinline__ void stage_commit_split(const StageRegs<NTH>& r, unsigned* PX, unsigned* UX, const float* w_prev, long ldw,
-                                                   const float* cum_prev, long ldcum, const float* dummy, int b, int L, int Lp, int tid) {
+                                                   const float* cum_prev, long ldcum, const float* dummy, int b, int L, int Lp, int tid,
+                                                   int kpad = KPAD) {
     constexpr int PER = 1024 / NTH;
     const float* wsrc = w_prev ? w_prev + (long)b * ldw : dummy;
     const float* csrc = cum_prev ? cum_prev + (long)b * ldcum : dummy;
@@ -216,7 +234,7 @@ __device__ __forceinline__ void stage_commit_split(const StageRegs<NTH>& r, unsi
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int idx = tid + NTH * i;
-        const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
+        const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - kpad;
         const bool ok = l >= 0 && l < L && !(c ? cz : wz);
         if (idx < 2 * Lp) put(idx, ok ? r.iv[i] : 0.f);
     }
@@ -225,24 +243,26 @@ __device__ __forceinline__ void stage_commit_split(const StageRegs<NTH>& r, unsi
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int idx = base + tid + NTH * i;
-            const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
+            const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - kpad;
             const int lc = imin(imax(l, 0), L - 1);
             iv[i] = (c ? csrc : wsrc)[lc];
         }
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int idx = base + tid + NTH * i;
-            const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
+            const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - kpad;
             const bool ok = l >= 0 && l < L && !(c ? cz : wz);
             if (idx < 2 * Lp) put(idx, ok ? iv[i] : 0.f);
         }
     }
+    if (DO_U) {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int idx = tid + NTH * i, al = idx >> 6, c = (idx >> 5) & 1, k = idx & 31;
-        const Bf3 s = t2_split1(k < KL ? r.uv[i] : 0.f);
-        const int o = al * 80 + c * 32 + k;
-        ux[o] = s.h; ux[1280 + o] = s.m; ux[2560 + o] = s.l;
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + NTH * i, al = idx >> 6, c = (idx >> 5) & 1, k = idx & 31;
+            const Bf3 s = t2_split1(k < KL ? r.uv[i] : 0.f);
+            const int o = al * 80 + c * 32 + k;
+            ux[o] = s.h; ux[1280 + o] = s.m; ux[2560 + o] = s.l;
+        }
     }
 }
 
@@ -704,6 +724,7 @@ struct AttnBwdK {
     const float* w_prev; long ldwp; const float* cum_prev; long ldcp;
     float* dpmT; float* dq; long lddq; float* dv_part; float* dU_part; float* din_part_out;
     unsigned long long* clk;   // diagnostic stamps (T2AttnSeqBwd.clk) or null
+    const unsigned* bd;        // matrix-pipe ds kernel: fragment-ready bf16 planes of the d_in filter operand (attn_bwd_prep_kernel)
 };
 
 namespace {
@@ -1029,6 +1050,240 @@ __global__ __launch_bounds__(ENT, 2) void attn_bwd_ds_kernel(AttnBwdK p) {
     attn_bwd_ds_body(p, blockIdx.x, blockIdx.y, sm);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The ds kernel with both correlations on the bf16 matrix pipe (L <= 256; exactly split operands, six products - the scheme of the
+// energies kernel).  Phases A / B as attn_bwd_ds_body (ds, dpmT, dq, dv), then
+//   dU   (phase C)  dU[a][(c,k)] += sum_l ds[a][l] * IN[l][(c,k)],  IN[l][(c,k)] = in[c][l + k - 15]: M = the slice's 16 dims,
+//                   N = 4 tiles of 16 (c,k) columns, K = positions; 24 (tile, k-step) pairs over 8 waves, the two K halves of a tile
+//                   meet in LDS;
+//   d_in (phase D)  with l' = 8 m + s:  d_in[c][8m + s] = sum_{a,k'} ds[a][8m + 15 - k'] * U[a][c][k' + s]  - the shift s of the
+//                   output position moves into the FILTER operand, so that N = (c, s) fills all 16 MFMA columns (as a plain
+//                   Toeplitz GEMM the two channels would use 2 of 16): M = positions / 8, K = 16 dims x 40 shifted taps.  The
+//                   filter operand depends only on U: attn_bwd_prep_kernel lays it out once per call as fragment-ready bf16 planes
+//                   (p.bd), loaded straight from L2 at kernel entry; the sum over the slice's dims happens in K (no 16-way LDS
+//                   reduction), the 8 waves' K shares are summed through LDS.
+// ds lives in LDS only as its three bf16 planes, plain bf16 rows DX[plane][dim][x] with ds[l] at x = 25 + l (halo 25: the d_in
+// fragments - 8 consecutive elements from x = 8 (m + rb + 1) - and the dU fragments - from x = 32 ks + 8 q - are then aligned
+// 16-byte items, one ds_read_b128 per plane, rows an odd number of items apart), written by the threads that compute it; the haloed
+// inputs as neighbour pairs with their own halo of 40 (stage_commit_split), so that in[c][l + k - 15] sits at index x + k.
+// 1.4 + 1.8 us of packed-FMA loops before.
+constexpr int DSH = 25;      // halo of the ds planes
+
+__global__ void attn_bwd_prep_kernel(const float* U, unsigned* bd, int Ad) {
+    // bd[((j*20 + ks)*3 + plane)*64 + lane] (16 bytes each): lane (n = (c, s), q) holds B[(a, r = 8 rb + jj)][(c, s)] = U[a][c][32 - r + s]
+    // for block 4 ks + q = 5 a + rb (zero outside the 31 taps)
+    const int j = blockIdx.x, ks = blockIdx.y, lane = threadIdx.x, n = lane & 15, q = lane >> 4;
+    const int blk = 4 * ks + q, al = blk / 5, rb = blk - 5 * al, c = n >> 3, sft = n & 7;
+    float v[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const int k = 32 - (8 * rb + jj) + sft;
+        v[jj] = (k >= 0 && k < KL) ? U[((long)(j * 16 + al) * 2 + c) * KL + k] : 0.f;
+    }
+    const Split8 sp = t2_split8(v);
+    u32x4v* o = reinterpret_cast<u32x4v*>(bd) + ((long)(j * 20 + ks) * 3) * 64 + lane;
+    o[0] = __builtin_bit_cast(u32x4v, sp.h); o[64] = __builtin_bit_cast(u32x4v, sp.m); o[128] = __builtin_bit_cast(u32x4v, sp.l);
+}
+
+struct DsDims { int NG, L4, M8, MT, KS, S16, LpI; };
+__host__ __device__ inline DsDims ds_dims(int L) {
+    DsDims d;
+    d.NG = (L + 3) >> 2; d.L4 = 4 * d.NG; d.M8 = (L + 7) >> 3; d.MT = (d.M8 + 15) >> 4; d.KS = (L + 31) >> 5;
+    int g = d.M8 + 5;                                   // d_in fragments reach item m + rb + 1 <= M8 + 4
+    if (4 * d.KS + 4 > g) g = 4 * d.KS + 4;             // dU fragments: items 4 ks + q, ks <= KS
+    if ((DSH + d.L4 + 7) / 8 + 1 > g) g = (DSH + d.L4 + 7) / 8 + 1;
+    d.S16 = g | 1;                                      // odd row stride (in 16-byte items): the 16 dims of a lane group hit 16 slots
+    d.LpI = 32 * d.KS + 64;
+    return d;
+}
+
+__global__ __launch_bounds__(ENT, 4) void attn_bwd_ds_mfma_kernel(AttnBwdK p) {
+    T2_CHAIN_PRIO();
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x, j = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool stamp = b == 0 && j == 0 && tid == 0;
+    T2_STAMP(p, stamp, 24);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int al = tid >> 5, sub = tid & 31, a = j * 16 + al;
+    const int n = lane & 15, q = lane >> 4;
+    const int L = p.L;
+    const DsDims dd = ds_dims(L);
+    const int NG = dd.NG, L4 = dd.L4, M8 = dd.M8, MT = dd.MT, KS = dd.KS, S16 = dd.S16, LpI = dd.LpI;
+    u32x4v* DX = reinterpret_cast<u32x4v*>(sm);              // [3][16][S16] items of 8 bf16
+    unsigned* PX = reinterpret_cast<unsigned*>(DX + 48 * S16);   // [3][2*LpI] neighbour pairs, in[c][l'] at index l' + 40
+    float* des = reinterpret_cast<float*>(PX + 6 * LpI);     // [L4]
+    float* redC = des + L4;                                  // [4][256]   phase C: second K half of each (c,k) tile
+    float* red = reinterpret_cast<float*>(DX);               // [8][MT][256] phase D: the waves' K shares (aliases DX after the MFMAs)
+    const long rowoff = ((long)b * p.Ad + a) * L;
+    // ---- issue: tanh stash + old dpmT, de, location inputs, old accumulator values ----
+    float thv[EMAXI][4], dpv[EMAXI][4];
+    const float va = p.v[a];
+    const float* th_row = p.th + ((long)b * p.Ad + a) * L4;
+#pragma unroll
+    for (int it = 0; it < EMAXI; ++it) {
+        const int lg = imin(sub + 32 * it, NG - 1);
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(th_row + 4 * lg);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            thv[it][i] = t4[i];
+            dpv[it][i] = p.dpmT[rowoff + imin(4 * lg + i, L - 1)];
+        }
+    }
+    // phase C result ownership of waves 0..3: tile nt = w, lane holds dims 4q + r, column n -> (c, k)
+    const int c_nt = w & 3, c_c = c_nt >> 1, c_k = 16 * (c_nt & 1) + n;
+    float dU_old[4] = {0.f, 0.f, 0.f, 0.f};
+    if (w < 4 && c_k < KL) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dU_old[r] = p.dU_part[(((long)b * p.Ad + j * 16 + 4 * q + r) * 2 + c_c) * KL + c_k];
+    }
+    const float dv_old = p.dv_part[(long)b * p.Ad + a];
+    float dev[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dev[i] = p.de[(long)b * L + imin(tid + ENT * i, L - 1)];
+    StageRegs<ENT> sr;
+    stage_issue<ENT, true, false>(sr, p.w_prev, p.ldwp, p.cum_prev, p.ldcp, p.U, p.th, b, j, L, LpI, tid, 40);
+    for (int i = tid; i < 48 * S16; i += ENT) DX[i] = (u32x4v){0u, 0u, 0u, 0u};     // halo and tail of the ds planes
+    stage_commit_split<ENT, false>(sr, PX, nullptr, p.w_prev, p.ldwp, p.cum_prev, p.ldcp, p.th, b, L, LpI, tid, 40);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int l = tid + ENT * i;
+        if (l < L4) des[l] = l < L ? dev[i] : 0.f;
+    }
+    __syncthreads();
+    T2_STAMP(p, stamp, 25);
+
+    // ---- phase A: ds -> its bf16 planes, dpmT accumulation; phase B sums in registers ----
+    float sq = 0.f, sv = 0.f;
+    {
+        unsigned short* dx16 = reinterpret_cast<unsigned short*>(DX);
+#pragma unroll
+        for (int it = 0; it < EMAXI; ++it) {
+            const int lg = sub + 32 * it;
+            if (lg >= NG) continue;
+            f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 de4 = *reinterpret_cast<const f32x4*>(des + 4 * lg);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int l = 4 * lg + i;
+                if (l < L) {
+                    const float th = thv[it][i];
+                    d4[i] = de4[i] * va * (1.f - th * th);
+                    sv += de4[i] * th;
+                    p.dpmT[rowoff + l] = dpv[it][i] + d4[i];
+                }
+            }
+            sq += (d4[0] + d4[1]) + (d4[2] + d4[3]);
+            const Split3 s3 = split3_attn(d4);     // packed (d0,d1), (d2,d3) of every plane
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const uint2 pk = pl == 0 ? s3.h : (pl == 1 ? s3.m : s3.l);
+                unsigned short* row = dx16 + (pl * 16 + al) * S16 * 8 + DSH + 4 * lg;     // x = 25 + 4 lg: odd
+                row[0] = (unsigned short)(pk.x & 0xffffu);
+                *reinterpret_cast<unsigned*>(row + 1) = (pk.x >> 16) | (pk.y << 16);
+                row[3] = (unsigned short)(pk.y >> 16);
+            }
+        }
+    }
+    sq = t2_half_sum_hi(sq); sv = t2_half_sum_hi(sv);   // totals of the dim's 32 lanes land in its upper 16 lanes
+    if (sub == 31) {
+        p.dq[(long)b * p.lddq + a] = sq;
+        p.dv_part[(long)b * p.Ad + a] = dv_old + sv;
+    }
+    // this wave's d_in filter fragments (k-steps w, w + 8, w + 16 < 20): from L2, independent of the chain
+    u32x4v bdv[3][3];
+    const u32x4v* bdp = reinterpret_cast<const u32x4v*>(p.bd) + (long)j * 20 * 3 * 64 + lane;
+#pragma unroll
+    for (int ki = 0; ki < 3; ++ki) {
+        const int ks = imin(w + 8 * ki, 19);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bdv[ki][pl] = bdp[(ks * 3 + pl) * 64];
+    }
+    __syncthreads();
+    T2_STAMP(p, stamp, 26);
+
+    // ---- phase C: dU tile c_nt, k-steps (w >> 2), +2, +4, ...: A[a = n][x = 32 ks + 8 q + jj] (ds[l = x - 25]),
+    //      B[x][(c,k)] = in[c][l + k - 15] = input index x + k ----
+    f32x4 cC;
+    {
+        f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, l0 = h0, l1 = h0, l2 = h0;
+        for (int ks = w >> 2; ks < KS + 1; ks += 2) {            // x runs to 25 + L - 1 < 32 (KS + 1)
+            const int it = n * S16 + 4 * ks + q;
+            Split8 fa, fb;
+            fa.h = __builtin_bit_cast(bf16x8, DX[it]); fa.m = __builtin_bit_cast(bf16x8, DX[16 * S16 + it]); fa.l = __builtin_bit_cast(bf16x8, DX[32 * S16 + it]);
+            const unsigned* bp = PX + c_c * LpI + 32 * ks + 8 * q + c_k;
+            fb.h = __builtin_bit_cast(bf16x8, (u32x4v){bp[0], bp[2], bp[4], bp[6]});
+            fb.m = __builtin_bit_cast(bf16x8, (u32x4v){bp[2 * LpI], bp[2 * LpI + 2], bp[2 * LpI + 4], bp[2 * LpI + 6]});
+            fb.l = __builtin_bit_cast(bf16x8, (u32x4v){bp[4 * LpI], bp[4 * LpI + 2], bp[4 * LpI + 4], bp[4 * LpI + 6]});
+            l0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.l, fb.h, l0, 0, 0, 0);
+            l1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.l, l1, 0, 0, 0);
+            l2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.m, fb.m, l2, 0, 0, 0);
+            l0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.m, fb.h, l0, 0, 0, 0);
+            l1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.m, l1, 0, 0, 0);
+            h0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.h, h0, 0, 0, 0);
+        }
+        cC = h0 + ((l0 + l1) + l2);
+    }
+    if (w >= 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) redC[c_nt * 256 + (4 * q + r) * 16 + n] = cC[r];
+    }
+    T2_STAMP(p, stamp, 28);
+    // ---- phase D: d_in, this wave's K share (k-steps w, w + 8, w + 16) for the MT row tiles:
+    //      A[m][(a, r = 8 rb + jj)] = ds[a][8 m + r - 17] = element x = 8 (m + rb + 1) + jj of dim a ----
+    f32x4 cD[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, l0 = h0, l1 = h0, l2 = h0;
+        if (mt < MT) {
+            const int m = imin(16 * mt + n, M8 - 1);
+#pragma unroll
+            for (int ki = 0; ki < 3; ++ki) {
+                const int ks = w + 8 * ki;
+                if (ks < 20) {
+                    const int blk = 4 * ks + q, ad = blk / 5, rb = blk - 5 * ad;
+                    const int it = ad * S16 + m + rb + 1;
+                    Split8 fa, fb;
+                    fa.h = __builtin_bit_cast(bf16x8, DX[it]); fa.m = __builtin_bit_cast(bf16x8, DX[16 * S16 + it]); fa.l = __builtin_bit_cast(bf16x8, DX[32 * S16 + it]);
+                    fb.h = __builtin_bit_cast(bf16x8, bdv[ki][0]); fb.m = __builtin_bit_cast(bf16x8, bdv[ki][1]); fb.l = __builtin_bit_cast(bf16x8, bdv[ki][2]);
+                    l0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.l, fb.h, l0, 0, 0, 0);
+                    l1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.l, l1, 0, 0, 0);
+                    l2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.m, fb.m, l2, 0, 0, 0);
+                    l0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.m, fb.h, l0, 0, 0, 0);
+                    l1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.m, l1, 0, 0, 0);
+                    h0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.h, h0, 0, 0, 0);
+                }
+            }
+        }
+        cD[mt] = h0 + ((l0 + l1) + l2);
+    }
+    __syncthreads();      // every wave has read its last ds fragment: the planes' memory becomes the reduction buffer
+    T2_STAMP(p, stamp, 27);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        if (mt < MT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((w * MT + mt) * 16 + 4 * q + r) * 16 + n] = cD[mt][r];
+        }
+    }
+    if (w < 4 && c_k < KL) {      // dU: first K half (registers) + second (redC, visible since the barrier above)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            p.dU_part[(((long)b * p.Ad + j * 16 + 4 * q + r) * 2 + c_c) * KL + c_k] = dU_old[r] + cC[r] + redC[c_nt * 256 + (4 * q + r) * 16 + n];
+    }
+    __syncthreads();
+    T2_STAMP(p, stamp, 29);
+    for (int o = tid; o < MT * 256; o += ENT) {
+        const int mt = o >> 8, ml = (o >> 4) & 15, nn = o & 15;
+        float s2 = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) s2 += red[((ww * MT + mt) * 16 + ml) * 16 + nn];
+        const int m = 16 * mt + ml, l = 8 * m + (nn & 7);
+        if (m < M8 && l < L) p.din_part_out[(((long)b * (p.Ad >> 4) + j) * 2 + (nn >> 3)) * L + l] = s2;
+    }
+    T2_STAMP(p, stamp, 30);
+}
+
 }  // namespace
 
 extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
@@ -1043,6 +1298,13 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
     const size_t sm_dw = (size_t)((Ef > 640 ? Ef : 640) + ((L + 3) & ~3) + 8) * sizeof(float);
     const size_t sm_ds = (size_t)(18 * Lp + 16 * 64 + 32 * L4) * sizeof(float);
     T2_REQUIRE(t2_allow_lds(attn_bwd_ds_kernel, sm_ds), "t2_attn_seq_bwd: LDS budget exceeded");
+    // matrix-pipe build of the ds kernel: when the caller gives the workspace and its LDS image leaves room for a side-stream GEMM
+    // workgroup (96 KB) and a BPTT workgroup on the same CU (60 KB: L <= 208)
+    const DsDims dd = ds_dims(L);
+    const size_t sm_dsm = (size_t)(48 * dd.S16 * 4 + 6 * dd.LpI + dd.L4 + 4 * 256) * sizeof(float);
+    const bool ds_mfma = a->ws_bd != nullptr && L <= 256 && sm_dsm <= 60 * 1024 && dd.MT <= 2;
+    if (ds_mfma)
+        hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(NA, 20), dim3(64), 0, st, a->U, reinterpret_cast<unsigned*>(a->ws_bd), Ad);
     T2_REQUIRE(a->wtp_ctx && a->wtp_h, "t2_attn_seq_bwd: packed weight streams (t2_lstm_pack_bwd) are required");
     // Z[s][b] = [ dgates_s (4A) | dq_{s-1} (Ad) ], s = 0..T; slot T's dgates part is zero-filled by the caller, so the
     // backward step of frame t always reads ONE contiguous row Z[t+1] (no special case for the last frame).
@@ -1093,7 +1355,9 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         k.dv_part = a->dv_part; k.dU_part = a->dU_part; k.din_part_out = a->din_part;
         k.clk = (unsigned long long*)a->clk;
         hipLaunchKernelGGL(attn_bwd_dw_kernel, dim3(B, t2_cdiv(L, 32)), dim3(256), sm_dw, st, k);
-        hipLaunchKernelGGL(attn_bwd_ds_kernel, dim3(B, NA), dim3(ENT), sm_ds, st, k);
+        k.bd = reinterpret_cast<const unsigned*>(a->ws_bd);
+        if (ds_mfma) hipLaunchKernelGGL(attn_bwd_ds_mfma_kernel, dim3(B, NA), dim3(ENT), sm_dsm, st, k);
+        else hipLaunchKernelGGL(attn_bwd_ds_kernel, dim3(B, NA), dim3(ENT), sm_ds, st, k);
         // (4) attention-LSTM cell backward: dh = (dh_ext + dgates_{t+1}.W_hh) + dq_t.Wq  (short K = Ad product + pointwise)
         T2LstmBwdStep c;
         memset(&c, 0, sizeof(c));

@@ -122,6 +122,7 @@ class Engine:
         self.ramp_chunks = True       # short chunks at the un-overlapped end of the forward / start of the backward pipeline
         self.share_cu = 1             # side-stream GEMMs next to the chains at ONE workgroup per CU: two 73 KB-LDS workgroups
                                       # per CU lock the attention kernels out (84.3 -> 83.2 ms)
+        self.attn_bwd_mfma = True     # attention backward: the per-slice kernel's correlations (dU, d_in) on the bf16 matrix pipe (T2AttnSeqBwd.ws_bd)
         self.bptt_off_chain = True    # the decoder-LSTM BPTT launches (side stream, a chunk ahead) keep the default wave priority
         self.sync_bn_group = None     # torch.distributed group: BatchNorm statistics over all ranks' shards (Trainer(sync_bn=True))
         self.grad_tail_hook = None    # called on the side stream once the gradients from prenet.0.weight onwards are enqueued
@@ -739,7 +740,8 @@ class Engine:
                   cum=ctx["cum"], th=ctx["th"], att_drop=masks.get("att_drop"),
                   dh_ext=dxdec, ld_dh=ldx, dctx_ext1=_ptr(dxdec, A), ld_dc1=ldx, dctx_ext2=_ptr(dxproj, D), ld_dc2=ldp,
                   dgates=Z, dctx_tot=dctx_tot, dq=None, dpmT=dpmT, dv_part=dv_part, dU_part=dU_part,
-                  dc=dc_att, G=Gc, de=de, din_part=din_part, dgates_t=Zt, clk=getattr(self, "clk_bwd", None))
+                  dc=dc_att, G=Gc, de=de, din_part=din_part, dgates_t=Zt, clk=getattr(self, "clk_bwd", None),
+                  ws_bd=self.buf("attn.ws_bd", Ad // 16 * 15360) if self.attn_bwd_mfma else None)
         self.mark("bwd.dec.proj")
         main, side = torch.cuda.current_stream(), self.side_stream()
         side.wait_stream(main)
