@@ -1109,26 +1109,29 @@ __global__ __launch_bounds__(ENT, 4) void attn_bwd_ds_mfma_kernel(AttnBwdK p) {
     const int n = lane & 15, q = lane >> 4;
     const int L = p.L;
     const DsDims dd = ds_dims(L);
-    const int NG = dd.NG, L4 = dd.L4, M8 = dd.M8, MT = dd.MT, KS = dd.KS, S16 = dd.S16, LpI = dd.LpI;
+    const int L4 = dd.L4, M8 = dd.M8, MT = dd.MT, KS = dd.KS, S16 = dd.S16, LpI = dd.LpI;
+    // position groups of phase A: group g = positions 4g - 1 .. 4g + 2, i.e. elements x = 24 + 4g .. 27 + 4g of a ds row: one aligned
+    // 8-byte store per plane (the tanh stash rows are read from 4 g - 1: dword-aligned 16-byte global loads)
+    const int NGA = (L + 4) >> 2;                            // groups 0 .. NGA - 1 cover positions -1 .. L - 1 (<= 64 for L <= 252)
     u32x4v* DX = reinterpret_cast<u32x4v*>(sm);              // [3][16][S16] items of 8 bf16
     unsigned* PX = reinterpret_cast<unsigned*>(DX + 48 * S16);   // [3][2*LpI] neighbour pairs, in[c][l'] at index l' + 40
-    float* des = reinterpret_cast<float*>(PX + 6 * LpI);     // [L4]
-    float* redC = des + L4;                                  // [4][256]   phase C: second K half of each (c,k) tile
+    float* des = reinterpret_cast<float*>(PX + 6 * LpI);     // [4 + L4 + 4]: de[l] at index l + 1 (zero at 0 and past L)
+    float* redC = des + L4 + 8;                              // [4][256]   phase C: second K half of each (c,k) tile
     float* red = reinterpret_cast<float*>(DX);               // [8][MT][256] phase D: the waves' K shares (aliases DX after the MFMAs)
     const long rowoff = ((long)b * p.Ad + a) * L;
-    // ---- issue: tanh stash + old dpmT, de, location inputs, old accumulator values ----
+    // ---- issue: tanh stash + old dpmT, de, location inputs, old accumulator values, the d_in filter fragments ----
     float thv[EMAXI][4], dpv[EMAXI][4];
     const float va = p.v[a];
     const float* th_row = p.th + ((long)b * p.Ad + a) * L4;
 #pragma unroll
     for (int it = 0; it < EMAXI; ++it) {
-        const int lg = imin(sub + 32 * it, NG - 1);
-        const f32x4 t4 = *reinterpret_cast<const f32x4*>(th_row + 4 * lg);
+        const int g = imin(sub + 32 * it, NGA - 1);
+        // positions 4g - 1 .. 4g + 2: one scalar + the aligned quad of positions 4g .. 4g + 3 (clamped; unused elements are guarded)
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(th_row + imin(4 * g, L4 - 4));
+        thv[it][0] = th_row[imax(4 * g - 1, 0)];
+        thv[it][1] = t4[0]; thv[it][2] = t4[1]; thv[it][3] = t4[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            thv[it][i] = t4[i];
-            dpv[it][i] = p.dpmT[rowoff + imin(4 * lg + i, L - 1)];
-        }
+        for (int i = 0; i < 4; ++i) dpv[it][i] = p.dpmT[rowoff + imin(imax(4 * g - 1 + i, 0), L - 1)];
     }
     // phase C result ownership of waves 0..3: tile nt = w, lane holds dims 4q + r, column n -> (c, k)
     const int c_nt = w & 3, c_c = c_nt >> 1, c_k = 16 * (c_nt & 1) + n;
@@ -1143,53 +1146,6 @@ __global__ __launch_bounds__(ENT, 4) void attn_bwd_ds_mfma_kernel(AttnBwdK p) {
     for (int i = 0; i < 2; ++i) dev[i] = p.de[(long)b * L + imin(tid + ENT * i, L - 1)];
     StageRegs<ENT> sr;
     stage_issue<ENT, true, false>(sr, p.w_prev, p.ldwp, p.cum_prev, p.ldcp, p.U, p.th, b, j, L, LpI, tid, 40);
-    for (int i = tid; i < 48 * S16; i += ENT) DX[i] = (u32x4v){0u, 0u, 0u, 0u};     // halo and tail of the ds planes
-    stage_commit_split<ENT, false>(sr, PX, nullptr, p.w_prev, p.ldwp, p.cum_prev, p.ldcp, p.th, b, L, LpI, tid, 40);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int l = tid + ENT * i;
-        if (l < L4) des[l] = l < L ? dev[i] : 0.f;
-    }
-    __syncthreads();
-    T2_STAMP(p, stamp, 25);
-
-    // ---- phase A: ds -> its bf16 planes, dpmT accumulation; phase B sums in registers ----
-    float sq = 0.f, sv = 0.f;
-    {
-        unsigned short* dx16 = reinterpret_cast<unsigned short*>(DX);
-#pragma unroll
-        for (int it = 0; it < EMAXI; ++it) {
-            const int lg = sub + 32 * it;
-            if (lg >= NG) continue;
-            f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 de4 = *reinterpret_cast<const f32x4*>(des + 4 * lg);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int l = 4 * lg + i;
-                if (l < L) {
-                    const float th = thv[it][i];
-                    d4[i] = de4[i] * va * (1.f - th * th);
-                    sv += de4[i] * th;
-                    p.dpmT[rowoff + l] = dpv[it][i] + d4[i];
-                }
-            }
-            sq += (d4[0] + d4[1]) + (d4[2] + d4[3]);
-            const Split3 s3 = split3_attn(d4);     // packed (d0,d1), (d2,d3) of every plane
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                const uint2 pk = pl == 0 ? s3.h : (pl == 1 ? s3.m : s3.l);
-                unsigned short* row = dx16 + (pl * 16 + al) * S16 * 8 + DSH + 4 * lg;     // x = 25 + 4 lg: odd
-                row[0] = (unsigned short)(pk.x & 0xffffu);
-                *reinterpret_cast<unsigned*>(row + 1) = (pk.x >> 16) | (pk.y << 16);
-                row[3] = (unsigned short)(pk.y >> 16);
-            }
-        }
-    }
-    sq = t2_half_sum_hi(sq); sv = t2_half_sum_hi(sv);   // totals of the dim's 32 lanes land in its upper 16 lanes
-    if (sub == 31) {
-        p.dq[(long)b * p.lddq + a] = sq;
-        p.dv_part[(long)b * p.Ad + a] = dv_old + sv;
-    }
     // this wave's d_in filter fragments (k-steps w, w + 8, w + 16 < 20): from L2, independent of the chain
     u32x4v bdv[3][3];
     const u32x4v* bdp = reinterpret_cast<const u32x4v*>(p.bd) + (long)j * 20 * 3 * 64 + lane;
@@ -1198,6 +1154,48 @@ __global__ __launch_bounds__(ENT, 4) void attn_bwd_ds_mfma_kernel(AttnBwdK p) {
         const int ks = imin(w + 8 * ki, 19);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) bdv[ki][pl] = bdp[(ks * 3 + pl) * 64];
+    }
+    for (int i = tid; i < 48 * S16; i += ENT) DX[i] = (u32x4v){0u, 0u, 0u, 0u};     // halo and tail of the ds planes
+    stage_commit_split<ENT, false>(sr, PX, nullptr, p.w_prev, p.ldwp, p.cum_prev, p.ldcp, p.th, b, L, LpI, tid, 40);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int l = tid + ENT * i;
+        if (l < L4 + 7) des[l + 1] = l < L ? dev[i] : 0.f;
+    }
+    if (tid == 0) des[0] = 0.f;
+    __syncthreads();
+    T2_STAMP(p, stamp, 25);
+
+    // ---- phase A: ds -> its bf16 planes, dpmT accumulation; phase B sums in registers ----
+    float sq = 0.f, sv = 0.f;
+    {
+        uint2* dx64 = reinterpret_cast<uint2*>(DX);
+#pragma unroll
+        for (int it = 0; it < EMAXI; ++it) {
+            const int g = sub + 32 * it;
+            if (g >= NGA) continue;
+            f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 de4 = *reinterpret_cast<const f32x4*>(des + 4 * g);      // de[4g - 1 .. 4g + 2]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int l = 4 * g - 1 + i;
+                if (l >= 0 && l < L) {
+                    const float th = thv[it][i];
+                    d4[i] = de4[i] * va * (1.f - th * th);
+                    sv += de4[i] * th;
+                    p.dpmT[rowoff + l] = dpv[it][i] + d4[i];
+                }
+            }
+            sq += (d4[0] + d4[1]) + (d4[2] + d4[3]);
+            const Split3 s3 = split3_attn(d4);     // packed (d0,d1), (d2,d3) of every plane: elements x = 24 + 4g .. 27 + 4g
+            const int o = al * S16 * 2 + 6 + g;    // 8-byte items: row base + (24 + 4 g) / 4
+            dx64[o] = s3.h; dx64[16 * S16 * 2 + o] = s3.m; dx64[32 * S16 * 2 + o] = s3.l;
+        }
+    }
+    sq = t2_half_sum_hi(sq); sv = t2_half_sum_hi(sv);   // totals of the dim's 32 lanes land in its upper 16 lanes
+    if (sub == 31) {
+        p.dq[(long)b * p.lddq + a] = sq;
+        p.dv_part[(long)b * p.Ad + a] = dv_old + sv;
     }
     __syncthreads();
     T2_STAMP(p, stamp, 26);
@@ -1301,8 +1299,8 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
     // matrix-pipe build of the ds kernel: when the caller gives the workspace and its LDS image leaves room for a side-stream GEMM
     // workgroup (96 KB) and a BPTT workgroup on the same CU (60 KB: L <= 208)
     const DsDims dd = ds_dims(L);
-    const size_t sm_dsm = (size_t)(48 * dd.S16 * 4 + 6 * dd.LpI + dd.L4 + 4 * 256) * sizeof(float);
-    const bool ds_mfma = a->ws_bd != nullptr && L <= 256 && sm_dsm <= 60 * 1024 && dd.MT <= 2;
+    const size_t sm_dsm = (size_t)(48 * dd.S16 * 4 + 6 * dd.LpI + dd.L4 + 8 + 4 * 256) * sizeof(float);
+    const bool ds_mfma = a->ws_bd != nullptr && L <= 252 && sm_dsm <= 60 * 1024 && dd.MT <= 2;
     if (ds_mfma)
         hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(NA, 20), dim3(64), 0, st, a->U, reinterpret_cast<unsigned*>(a->ws_bd), Ad);
     T2_REQUIRE(a->wtp_ctx && a->wtp_h, "t2_attn_seq_bwd: packed weight streams (t2_lstm_pack_bwd) are required");
