@@ -637,3 +637,33 @@ def test_inference_above_64_utterances_is_one_loop_like_the_reference():
     assert mels.shape == ref[0].shape and (lengths.cpu() == trace["lengths"]).all()
     assert l1(mels, ref[0]) < MEL_L1_TOL and l1(post, ref[1]) < MEL_L1_TOL and mx(al, ref[3]) < 5e-5
     assert ((gates.cpu() == -1000.0) == (ref[2] == -1000.0)).all()
+
+
+@pytest.mark.parametrize("L", [1, 2, 15, 16, 17, 31, 33, 64, 97, 188, 231, 252, 253])
+def test_attention_backward_matrix_pipe_kernel_equals_packed_fma_kernel(L):
+    """The per-slice kernel of the attention backward exists twice: correlations (dU, d_in) as packed-FMA loops (any L <= 768) and on
+    the bf16 matrix pipe with exactly split operands (L <= 252, Engine.attn_bwd_mfma / T2AttnSeqBwd.ws_bd).  Same inputs through both:
+    every gradient agrees to fp32 re-association level, over text lengths around the tile edges of the matrix-pipe build (16-row
+    position tiles, 32-deep k-steps, 8-position d_in rows) and at its dispatch limit (L = 253 takes the packed-FMA kernel either way)."""
+    dev = _dev()
+    d = R.default_dims(num_chars=39, encoded_dim=64, prenet_dim=32, att_rnn_dim=64, att_dim=32, rnn_hidden_dim=64,
+                       postnet_dim=64, num_mels=16, dropout=0.5)
+    P = R.init_params(d, seed=21)
+    ci, lens, mel, tl, gate, masks = random_case(d, 3, L, 11, 300 + L, dev)
+    grads = []
+    for mfma in (False, True):
+        eng, ps = build_engine(d, P, dev)
+        eng.attn_bwd_mfma = mfma
+        outs, ctx = eng.forward_tf(ci.to(dev), lens.to(dev), mel.to(dev), tl.to(dev), training=True, masks=masks_to_device(masks, dev))
+        ps.grad.zero_()
+        eng.loss_and_grads(outs, ctx, mel.to(dev), gate.to(dev))
+        torch.cuda.synchronize()
+        grads.append(ps.grad.clone())
+    gmax = float(grads[0].abs().max())
+    for name in ps.P:
+        if name in ("encoder.convolutions.0.bias", "encoder.convolutions.4.bias", "encoder.convolutions.8.bias"):
+            continue      # a bias in front of BatchNorm: its gradient is identically zero, what is stored is cancellation noise
+        o, k = ps.offsets[name], ps.P[name].numel()
+        a, b = grads[0][o:o + k].double(), grads[1][o:o + k].double()
+        scale = max(float(a.abs().max()), 1e-3 * gmax)      # (tensors whose gradient is analytically zero carry rounding noise only)
+        assert float((a - b).abs().max()) < 2e-5 * scale, (name, float((a - b).abs().max()), scale)

@@ -23,5 +23,6 @@ c = clk.cpu().tolist()
 GHZ = 2.38
 f = lambda a, b0: (c[a] - c[b0]) / GHZ / 1e3
 print("dw kernel, workgroup (0,0), us from entry: small loads consumed %.2f | sigma %.2f | exit %.2f" % (f(17, 16), f(18, 16), f(19, 16)))
-print("ds kernel, workgroup (0,0), us from entry: staged %.2f | phase A (ds, dpmT) %.2f | phase B (dq, dv) %.2f | phase C (dU) %.2f | "
-      "phase D (d_in) %.2f | exit %.2f" % (f(25, 24), f(26, 24), f(27, 24), f(28, 24), f(29, 24), f(30, 24)))
+# (matrix-pipe build, L <= 252: stamp 28 = dU MFMAs done, 27 = d_in MFMAs done and every wave past the barrier, 29 = K shares summed)
+print("ds kernel, workgroup (0,0), us from entry: staged %.2f | phases A/B (ds, dpmT, dq, dv) %.2f | dU products %.2f | d_in products "
+      "+ barrier %.2f | shares reduced %.2f | exit %.2f" % (f(25, 24), f(26, 24), f(28, 24), f(27, 24), f(29, 24), f(30, 24)))
