@@ -478,17 +478,28 @@ __device__ __forceinline__ void attn_context_body(const AttnK& p, const int b, c
         for (int r = 0; r < 2; ++r) cprev[r] = p.cum_prev[(long)b * p.ldcum + imin(tid + 256 * r, L - 1)];
     }
     T2_STAMP(p, stamp, 9);
-    mx = t2_block_max(mx, red);
+    // Softmax with ONE workgroup exchange: every wave exponentiates against its own maximum and publishes (max, sum); the global
+    // maximum M and sum S follow from the four pairs, and a wave's weights are exp(e - m_w) * exp(m_w - M) / S (two block
+    // reductions - four barriers - before).  A wave of masked positions only has m_w = -inf: its terms are zero.
+    const float mw = t2_wave_max(mx);
+    const float mws = mw == -INFINITY ? 0.f : mw;
     float sum = 0.f;
     for (int l = tid; l < L; l += 256) {
-        const float pe = expf(ws[l] - mx);
+        const float pe = expf(ws[l] - mws);
         ws[l] = pe;
         sum += pe;
     }
-    sum = t2_block_sum(sum, red);
+    sum = t2_wave_sum(sum);
+    if ((tid & 63) == 0) { red[tid >> 6] = mw; red[4 + (tid >> 6)] = sum; }
+    __syncthreads();
+    const float M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float S = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) S += red[4 + ww] * (red[ww] == -INFINITY ? 0.f : expf(red[ww] - M));
+    const float scale = (mw == -INFINITY ? 0.f : expf(mw - M)) / S;
     T2_STAMP(p, stamp, 10);
     for (int l = tid, r = 0; l < L; l += 256, ++r) {
-        const float wv = ws[l] / sum;
+        const float wv = ws[l] * scale;
         ws[l] = wv;
         if (es0 == 0) {
             p.w_out[(long)b * p.ldwo + l] = wv;

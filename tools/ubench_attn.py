@@ -65,8 +65,7 @@ _lib.lib().t2_debug_clock(0, out8)
 cc = list(out8)
 c = clk.cpu().tolist()
 GHZ = 2.38   # shader clock during the loop (s_memtime ticks / s_memrealtime), DESIGN.md section 4.1
-e = [(c[i] - c[0]) / GHZ / 1e3 for i in range(8)]
-print("energies  kernel extra stamps: split pass done %.2f | planes visible (barrier) %.2f" % (e[6], e[7]))
+e = [(c[i] - c[0]) / GHZ / 1e3 for i in range(6)]
 k = [(c[i] - c[8]) / GHZ / 1e3 for i in range(8, 14)]
 print("energies  kernel, workgroup (0,0), us from entry: staging done %.2f | conv done %.2f | query ready %.2f | tanh done %.2f | exit %.2f"
       % (e[1], e[4], e[5], e[2], e[3]))
