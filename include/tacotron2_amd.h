@@ -205,6 +205,7 @@ typedef struct {
     const float* cum_prev; int64_t ldcum;    /* NULL = zeros */
     const float* pmT; const float* memory; const int32_t* len;
     float* e_part; float* th_out;
+    float* q_out;                            /* optional [B][Ad]: the query projection Wq.att_h of this frame (stash for backward) */
     float* w_out; int64_t ldwo; float* cum_out; int64_t ldco;
     float* ctx_out; int64_t ldctx; float* ctx_out2; int64_t ldctx2;
     float* ctxt_out; int ctxt_col0;          /* optional x16-tiled copy of the context (see T2LstmStep) */
@@ -231,6 +232,8 @@ typedef struct {
     const float* pre; const float* pmT; const float* memory; const int32_t* len;
     const float* att_drop;
     float* xdec; float* att_c; float* gates; float* align; float* cum; float* th;
+    float* qproj;                    /* optional [T][B][Ad]: query projections of all frames (the backward recomputes the tanh terms
+                                        from them when th is not kept, see t2_attn_bwd_recomputes_th) */
     float* xproj_ctx; int64_t ld_xproj;
     float* e_part;
     int t_begin, t_end;              /* frame range [t_begin, t_end) of this call; 0,0 = all T frames */
@@ -276,12 +279,19 @@ typedef struct {
                                         zero-filled by the caller; read by the per-frame products of dgates[t+1] */
     uint64_t* clk;                   /* diagnostic, normally NULL: 32 device words, s_memtime stamps of workgroup (0,0) at phase
                                         boundaries of the dw kernel [16..19] and the ds kernel [24..30] */
-    float* ws_bd;                    /* optional workspace of (Ad/16) * 15360 floats: with it (and L <= 208) the per-slice kernel runs its
-                                        two correlations (dU, d_in) on the bf16 matrix pipe with exactly split operands; the workspace
-                                        receives the filter operand of d_in in fragment layout, rewritten by every call (same results
-                                        to fp32 rounding; NULL = the packed-FMA kernel) */
+    float* ws_bd;                    /* optional workspace of (Ad/16) * 16896 floats: with it (and L <= 252 while the kernel's LDS image
+                                        stays under 60 KB) the per-slice kernel runs its two correlations (dU, d_in) on the bf16 matrix
+                                        pipe with exactly split operands; the workspace receives the filter operands in fragment
+                                        layout, rewritten by every call (same results to fp32 rounding; NULL = the packed-FMA kernel) */
+    const float* pmT;                /* processed memory [B][Ad][L] of the forward: needed when th == NULL */
+    const float* qproj;              /* query projections [T][B][Ad] of the forward (T2AttnSeq.qproj): needed when th == NULL */
 } T2AttnSeqBwd;
 int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream);
+/* 1 when t2_attn_seq_bwd (with ws_bd) can run WITHOUT the tanh stash for texts of padded length L: its matrix-pipe kernel then
+ * recomputes tanh(query + location + processed memory) from qproj, U, align, cum and pmT - the location convolution on the
+ * matrix pipe, as in the forward - and the forward (T2AttnSeq.th = NULL, qproj given) neither writes nor keeps [T][B][Ad][L4]
+ * floats.  0: pass the stash. */
+int t2_attn_bwd_recomputes_th(int L, int Ad, int A);
 
 /* ------------------------------------------------------------------------------------------------
  * Conv stacks (encoder model/encoder.py:31-46,57; postnet model/postnet.py:8-49).

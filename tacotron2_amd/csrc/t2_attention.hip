@@ -33,7 +33,7 @@ struct AttnK {
     const float* Wq; const float* U; const float* v;
     const float* w_prev; long ldw; const float* cum_prev; long ldcum;
     const float* pmT; const float* memory; const int32_t* len;
-    float* e_part; float* th_out;
+    float* e_part; float* th_out; float* q_out;
     float* w_out; long ldwo; float* cum_out; long ldco;
     float* ctx_out; long ldctx; float* ctx_out2; long ldctx2;
     float* ctxt_out; int ctxt_col0; long ctxt_cs;
@@ -372,7 +372,10 @@ __device__ __forceinline__ void attn_energy_body(const AttnK& p, const int b, co
             }
         }
         const float sq0 = t2_wave_sum(qacc[0]), sq1 = t2_wave_sum(qacc[1]);
-        if (lane == 0) { qs[2 * w] = sq0; qs[2 * w + 1] = sq1; }
+        if (lane == 0) {
+            qs[2 * w] = sq0; qs[2 * w + 1] = sq1;
+            if (p.q_out) *reinterpret_cast<f32x2*>(p.q_out + (long)b * p.Ad + j * 16 + 2 * w) = (f32x2){sq0, sq1};
+        }
         T2_STAMP(p, stamp, 5);
     }
     __syncthreads();   // qs visible
@@ -564,7 +567,7 @@ void to_ak(const T2AttnStep& s, AttnK& k) {
     k.B = s.B; k.L = s.L; k.A = s.A; k.Ad = s.Ad; k.Ef = s.Ef;
     k.att_h = s.att_h; k.ldh = s.ldh; k.Wq = s.Wq; k.U = s.U; k.v = s.v;
     k.w_prev = s.w_prev; k.ldw = s.ldw; k.cum_prev = s.cum_prev; k.ldcum = s.ldcum;
-    k.pmT = s.pmT; k.memory = s.memory; k.len = s.len; k.e_part = s.e_part; k.th_out = s.th_out;
+    k.pmT = s.pmT; k.memory = s.memory; k.len = s.len; k.e_part = s.e_part; k.th_out = s.th_out; k.q_out = s.q_out;
     k.w_out = s.w_out; k.ldwo = s.ldwo; k.cum_out = s.cum_out; k.ldco = s.ldco;
     k.ctx_out = s.ctx_out; k.ldctx = s.ldctx; k.ctx_out2 = s.ctx_out2; k.ldctx2 = s.ldctx2;
     k.ctxt_out = s.ctxt_out; k.ctxt_col0 = s.ctxt_col0; k.ctxt_cs = (long)((s.B + 15) / 16 * 16) * 16;
@@ -688,6 +691,7 @@ extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
         q.cum_prev = a->cum + (long)t * B * L; q.ldcum = L;
         q.pmT = a->pmT; q.memory = a->memory; q.len = a->len; q.e_part = a->e_part;
         if (a->th) q.th_out = a->th + (long)t * B * Ad * ((L + 3) & ~3);
+        if (a->qproj) q.q_out = a->qproj + (long)t * B * Ad;
         q.w_out = a->align + (long)t * L; q.ldwo = (long)T * L;
         q.cum_out = a->cum + (long)(t + 1) * B * L; q.ldco = L;
         q.ctx_out = slot1 + A; q.ldctx = ldx;
@@ -736,6 +740,8 @@ struct AttnBwdK {
     float* dpmT; float* dq; long lddq; float* dv_part; float* dU_part; float* din_part_out;
     unsigned long long* clk;   // diagnostic stamps (T2AttnSeqBwd.clk) or null
     const unsigned* bd;        // matrix-pipe ds kernel: fragment-ready bf16 planes of the d_in filter operand (attn_bwd_prep_kernel)
+    // recomputation of the tanh terms in the matrix-pipe ds kernel (th == nullptr): operands of the forward energies kernel
+    const unsigned* ub; const float* pmT; const float* qproj;
 };
 
 namespace {
@@ -1094,6 +1100,15 @@ __global__ void attn_bwd_prep_kernel(const float* U, unsigned* bd, int Ad) {
     const Split8 sp = t2_split8(v);
     u32x4v* o = reinterpret_cast<u32x4v*>(bd) + ((long)(j * 20 + ks) * 3) * 64 + lane;
     o[0] = __builtin_bit_cast(u32x4v, sp.h); o[64] = __builtin_bit_cast(u32x4v, sp.m); o[128] = __builtin_bit_cast(u32x4v, sp.l);
+    if (ks < 2) {      // filter rows of the forward convolution as its B operand (recomputation of the tanh terms): channel c = ks,
+        const int c2 = ks;   // lane (n = dim, q) holds U[a = n][c][8 q + jj], tap 31 = 0; stored behind the d_in planes
+        float u[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) u[jj] = (8 * q + jj) < KL ? U[((long)(j * 16 + n) * 2 + c2) * KL + 8 * q + jj] : 0.f;
+        const Split8 su = t2_split8(u);
+        u32x4v* ou = reinterpret_cast<u32x4v*>(bd) + (long)(Ad >> 4) * 20 * 3 * 64 + ((long)(j * 2 + c2) * 3) * 64 + lane;
+        ou[0] = __builtin_bit_cast(u32x4v, su.h); ou[64] = __builtin_bit_cast(u32x4v, su.m); ou[128] = __builtin_bit_cast(u32x4v, su.l);
+    }
 }
 
 struct DsDims { int NG, L4, M8, MT, KS, S16, LpI; };
@@ -1104,10 +1119,15 @@ __host__ __device__ inline DsDims ds_dims(int L) {
     if (4 * d.KS + 4 > g) g = 4 * d.KS + 4;             // dU fragments: items 4 ks + q, ks <= KS
     if ((DSH + d.L4 + 7) / 8 + 1 > g) g = (DSH + d.L4 + 7) / 8 + 1;
     d.S16 = g | 1;                                      // odd row stride (in 16-byte items): the 16 dims of a lane group hit 16 slots
-    d.LpI = 32 * d.KS + 64;
+    d.LpI = 32 * d.KS + 96;
     return d;
 }
 
+// RECOMP: the tanh terms are not read from a stash of the forward but recomputed here - query projection, location convolution (on
+// the matrix pipe, as attn_energy_body), + processed memory, tanh - from operands that do NOT depend on the backward chain, in the
+// ~2 us this kernel otherwise waits for the energy gradients of the dw launch.  The forward then stores no tanh stash: 1.5 us per
+// frame of end-of-kernel write-back in the energies launch, 2.7 GB of HBM writes and as many reads per training step.
+template <bool RECOMP>
 __global__ __launch_bounds__(ENT, 4) void attn_bwd_ds_mfma_kernel(AttnBwdK p) {
     T2_CHAIN_PRIO();
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -1129,45 +1149,106 @@ __global__ __launch_bounds__(ENT, 4) void attn_bwd_ds_mfma_kernel(AttnBwdK p) {
     float* des = reinterpret_cast<float*>(PX + 6 * LpI);     // [4 + L4 + 4]: de[l] at index l + 1 (zero at 0 and past L)
     float* redC = des + L4 + 8;                              // [4][256]   phase C: second K half of each (c,k) tile
     float* red = reinterpret_cast<float*>(DX);               // [8][MT][256] phase D: the waves' K shares (aliases DX after the MFMAs)
+    const int TS = 4 * (((L4 >> 2) + 3) | 1);                // RECOMP: row stride of the recomputed tanh terms (an odd number of 16-byte items)
+    float* th_s = redC + 4 * 256;                            // RECOMP: [16][TS]
     const long rowoff = ((long)b * p.Ad + a) * L;
-    // ---- issue: tanh stash + old dpmT, de, location inputs, old accumulator values, the d_in filter fragments ----
-    float thv[EMAXI][4], dpv[EMAXI][4];
-    const float va = p.v[a];
-    const float* th_row = p.th + ((long)b * p.Ad + a) * L4;
-#pragma unroll
-    for (int it = 0; it < EMAXI; ++it) {
-        const int g = imin(sub + 32 * it, NGA - 1);
-        // positions 4g - 1 .. 4g + 2: one scalar + the aligned quad of positions 4g .. 4g + 3 (clamped; unused elements are guarded)
-        const f32x4 t4 = *reinterpret_cast<const f32x4*>(th_row + imin(4 * g, L4 - 4));
-        thv[it][0] = th_row[imax(4 * g - 1, 0)];
-        thv[it][1] = t4[0]; thv[it][2] = t4[1]; thv[it][3] = t4[2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dpv[it][i] = p.dpmT[rowoff + imin(imax(4 * g - 1 + i, 0), L - 1)];
-    }
-    // phase C result ownership of waves 0..3: tile nt = w, lane holds dims 4q + r, column n -> (c, k)
-    const int c_nt = w & 3, c_c = c_nt >> 1, c_k = 16 * (c_nt & 1) + n;
-    float dU_old[4] = {0.f, 0.f, 0.f, 0.f};
-    if (w < 4 && c_k < KL) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dU_old[r] = p.dU_part[(((long)b * p.Ad + j * 16 + 4 * q + r) * 2 + c_c) * KL + c_k];
-    }
-    const float dv_old = p.dv_part[(long)b * p.Ad + a];
+    // ---- issue: the energy gradients first (the only operand that depends on the previous launch), tanh stash / old dpmT,
+    //      location inputs, old accumulator values, the d_in filter fragments ----
     float dev[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) dev[i] = p.de[(long)b * L + imin(tid + ENT * i, L - 1)];
+    float thv[EMAXI][4], dpv[EMAXI][4];
+    const float va = p.v[a];
+#pragma unroll
+    for (int it = 0; it < EMAXI; ++it) {
+        const int g = imin(sub + 32 * it, NGA - 1);
+        if (!RECOMP) {
+            // positions 4g - 1 .. 4g + 2: one scalar + the aligned quad of positions 4g .. 4g + 3 (clamped; unused elements are guarded)
+            const float* th_row = p.th + ((long)b * p.Ad + a) * L4;
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(th_row + imin(4 * g, L4 - 4));
+            thv[it][0] = th_row[imax(4 * g - 1, 0)];
+            thv[it][1] = t4[0]; thv[it][2] = t4[1]; thv[it][3] = t4[2];
+        }
+    }
+    auto load_dp = [&]() {      // old dpmT values of this thread's positions (written by the previous frame's launch: L2)
+#pragma unroll
+        for (int it = 0; it < EMAXI; ++it) {
+            const int g = imin(sub + 32 * it, NGA - 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dpv[it][i] = p.dpmT[rowoff + imin(imax(4 * g - 1 + i, 0), L - 1)];
+        }
+    };
+    load_dp();
+    // phase C result ownership of waves 0..3: tile nt = w, lane holds dims 4q + r, column n -> (c, k)
+    const int c_nt = w & 3, c_c = c_nt >> 1, c_k = 16 * (c_nt & 1) + n;
+    const float dv_old = p.dv_part[(long)b * p.Ad + a];
     StageRegs<ENT> sr;
-    stage_issue<ENT, true, false>(sr, p.w_prev, p.ldwp, p.cum_prev, p.ldcp, p.U, p.th, b, j, L, LpI, tid, 40);
-    // this wave's d_in filter fragments (k-steps w, w + 8, w + 16 < 20): from L2, independent of the chain
+    stage_issue<ENT, true, false>(sr, p.w_prev, p.ldwp, p.cum_prev, p.ldcp, p.U, p.dpmT, b, j, L, LpI, tid, 40);
     u32x4v bdv[3][3];
     const u32x4v* bdp = reinterpret_cast<const u32x4v*>(p.bd) + (long)j * 20 * 3 * 64 + lane;
+    auto load_bd = [&]() {     // this wave's d_in filter fragments (k-steps w, w + 8, w + 16 < 20): from L2, independent of the chain
 #pragma unroll
-    for (int ki = 0; ki < 3; ++ki) {
-        const int ks = imin(w + 8 * ki, 19);
+        for (int ki = 0; ki < 3; ++ki) {
+            const int ks = imin(w + 8 * ki, 19);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bdv[ki][pl] = bdp[(ks * 3 + pl) * 64];
+            for (int pl = 0; pl < 3; ++pl) bdv[ki][pl] = bdp[(ks * 3 + pl) * 64];
+        }
+    };
+    if (!RECOMP) load_bd();
+    // RECOMP operands: filter fragments of the convolution, processed memory of this wave's two position tiles, query operands
+    const int an = j * 16 + n;                                  // the dim this lane holds in the MFMA layouts
+    u32x4v ubv[2][3];
+    float pmv[2][4];
+    float qa = 0.f;
+    if (RECOMP) {
+        const u32x4v* ubp = reinterpret_cast<const u32x4v*>(p.ub) + (long)j * 2 * 3 * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) ubv[c][pl] = ubp[(c * 3 + pl) * 64];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int lg = imin(4 * (w + 8 * it) + q, dd.NG - 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pmv[it][i] = p.pmT[((long)b * p.Ad + an) * L + imin(4 * lg + i, L - 1)];
+        }
+        qa = p.qproj[(long)b * p.Ad + an];
     }
     for (int i = tid; i < 48 * S16; i += ENT) DX[i] = (u32x4v){0u, 0u, 0u, 0u};     // halo and tail of the ds planes
-    stage_commit_split<ENT, false>(sr, PX, nullptr, p.w_prev, p.ldwp, p.cum_prev, p.ldcp, p.th, b, L, LpI, tid, 40);
+    stage_commit_split<ENT, false>(sr, PX, nullptr, p.w_prev, p.ldwp, p.cum_prev, p.ldcp, p.dpmT, b, L, LpI, tid, 40);
+    if (RECOMP) {
+        __syncthreads();     // input planes visible (none of this depends on the previous launch)
+        // location convolution of this wave's position tiles mt = w, w + 8: IN[l = 16 mt + n][(c, 8 q + jj)] = in[c][l + 8q + jj - 15]
+        // = input index c*LpI + l + 8q + jj + 25
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int mt = w + 8 * it;
+            if (16 * mt < L) {
+                f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, l0 = h0, l1 = h0, l2 = h0;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const unsigned* ap = PX + c * LpI + 16 * mt + n + 8 * q + 25;
+                    Split8 fa, fb;
+                    fa.h = __builtin_bit_cast(bf16x8, (u32x4v){ap[0], ap[2], ap[4], ap[6]});
+                    fa.m = __builtin_bit_cast(bf16x8, (u32x4v){ap[2 * LpI], ap[2 * LpI + 2], ap[2 * LpI + 4], ap[2 * LpI + 6]});
+                    fa.l = __builtin_bit_cast(bf16x8, (u32x4v){ap[4 * LpI], ap[4 * LpI + 2], ap[4 * LpI + 4], ap[4 * LpI + 6]});
+                    fb.h = __builtin_bit_cast(bf16x8, ubv[c][0]); fb.m = __builtin_bit_cast(bf16x8, ubv[c][1]); fb.l = __builtin_bit_cast(bf16x8, ubv[c][2]);
+                    l0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.l, fb.h, l0, 0, 0, 0);
+                    l1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.l, l1, 0, 0, 0);
+                    l2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.m, fb.m, l2, 0, 0, 0);
+                    l0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.m, fb.h, l0, 0, 0, 0);
+                    l1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.m, l1, 0, 0, 0);
+                    h0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.h, h0, 0, 0, 0);
+                }
+                const f32x4 loc = h0 + ((l0 + l1) + l2);
+                f32x4 t4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t4[i] = t2_tanh(qa + loc[i] + pmv[it][i]);
+                *reinterpret_cast<f32x4*>(th_s + n * TS + 16 * mt + 4 * q) = t4;      // positions 16 mt + 4 q + i of dim n
+            }
+        }
+        load_bd();
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int l = tid + ENT * i;
@@ -1191,7 +1272,7 @@ __global__ __launch_bounds__(ENT, 4) void attn_bwd_ds_mfma_kernel(AttnBwdK p) {
             for (int i = 0; i < 4; ++i) {
                 const int l = 4 * g - 1 + i;
                 if (l >= 0 && l < L) {
-                    const float th = thv[it][i];
+                    const float th = RECOMP ? th_s[al * TS + l] : thv[it][i];
                     d4[i] = de4[i] * va * (1.f - th * th);
                     sv += de4[i] * th;
                     p.dpmT[rowoff + l] = dpv[it][i] + d4[i];
@@ -1210,6 +1291,11 @@ __global__ __launch_bounds__(ENT, 4) void attn_bwd_ds_mfma_kernel(AttnBwdK p) {
     }
     __syncthreads();
     T2_STAMP(p, stamp, 26);
+    float dU_old[4] = {0.f, 0.f, 0.f, 0.f};      // old accumulator values: consumed after both MFMA phases
+    if (w < 4 && c_k < KL) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dU_old[r] = p.dU_part[(((long)b * p.Ad + j * 16 + 4 * q + r) * 2 + c_c) * KL + c_k];
+    }
 
     // ---- phase C: dU tile c_nt, k-steps (w >> 2), +2, +4, ...: A[a = n][x = 32 ks + 8 q + jj] (ds[l = x - 25]),
     //      B[x][(c,k)] = in[c][l + k - 15] = input index x + k ----
@@ -1293,7 +1379,21 @@ __global__ __launch_bounds__(ENT, 4) void attn_bwd_ds_mfma_kernel(AttnBwdK p) {
     T2_STAMP(p, stamp, 30);
 }
 
+// dynamic LDS of the matrix-pipe ds kernel (floats: ds planes | input planes | de | phase-C exchange [| query | tanh terms])
+size_t ds_mfma_lds(const DsDims& dd, bool recomp) {
+    size_t f = (size_t)48 * dd.S16 * 4 + 6 * dd.LpI + dd.L4 + 8 + 4 * 256;
+    if (recomp) f += (size_t)16 * 4 * (((dd.L4 >> 2) + 3) | 1);
+    return f * sizeof(float);
+}
+
 }  // namespace
+
+extern "C" int t2_attn_bwd_recomputes_th(int L, int Ad, int A) {
+    (void)A;
+    if (L < 1 || L > 252 || Ad % 16 != 0) return 0;
+    const DsDims dd = ds_dims(L);
+    return ds_mfma_lds(dd, true) <= 60 * 1024 && dd.MT <= 2 ? 1 : 0;
+}
 
 extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
     (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
@@ -1310,8 +1410,11 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
     // matrix-pipe build of the ds kernel: when the caller gives the workspace and its LDS image leaves room for a side-stream GEMM
     // workgroup (96 KB) and a BPTT workgroup on the same CU (60 KB: L <= 208)
     const DsDims dd = ds_dims(L);
-    const size_t sm_dsm = (size_t)(48 * dd.S16 * 4 + 6 * dd.LpI + dd.L4 + 8 + 4 * 256) * sizeof(float);
+    const bool recomp = a->th == nullptr;      // no tanh stash: the matrix-pipe ds kernel recomputes the terms
+    const size_t sm_dsm = ds_mfma_lds(dd, recomp);
     const bool ds_mfma = a->ws_bd != nullptr && L <= 252 && sm_dsm <= 60 * 1024 && dd.MT <= 2;
+    T2_REQUIRE(!recomp || (ds_mfma && a->pmT && a->qproj), "t2_attn_seq_bwd: without a tanh stash (th) the matrix-pipe kernel must "
+               "apply (t2_attn_bwd_recomputes_th) and pmT, qproj are required");
     if (ds_mfma)
         hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(NA, 20), dim3(64), 0, st, a->U, reinterpret_cast<unsigned*>(a->ws_bd), Ad);
     T2_REQUIRE(a->wtp_ctx && a->wtp_h, "t2_attn_seq_bwd: packed weight streams (t2_lstm_pack_bwd) are required");
@@ -1357,7 +1460,7 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         k.G_in = last ? nullptr : a->G + (long)((t + 1) & 1) * B * L;
         k.G_out = a->G + (long)(t & 1) * B * L;
         k.de = a->de;
-        k.th = a->th + (long)t * B * Ad * ((L + 3) & ~3); k.v = a->v; k.U = a->U;
+        k.th = a->th ? a->th + (long)t * B * Ad * ((L + 3) & ~3) : nullptr; k.v = a->v; k.U = a->U;
         if (t > 0) { k.w_prev = a->align + (long)(t - 1) * L; k.ldwp = (long)T * L; }
         k.cum_prev = a->cum + (long)t * B * L; k.ldcp = L;
         k.dpmT = a->dpmT; k.dq = Z + (long)(t + 1) * B * ldz + 4 * A; k.lddq = ldz;
@@ -1365,7 +1468,11 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         k.clk = (unsigned long long*)a->clk;
         hipLaunchKernelGGL(attn_bwd_dw_kernel, dim3(B, t2_cdiv(L, 32)), dim3(256), sm_dw, st, k);
         k.bd = reinterpret_cast<const unsigned*>(a->ws_bd);
-        if (ds_mfma) hipLaunchKernelGGL(attn_bwd_ds_mfma_kernel, dim3(B, NA), dim3(ENT), sm_dsm, st, k);
+        if (recomp) {
+            k.th = nullptr;
+            k.ub = k.bd + (long)NA * 20 * 3 * 64 * 4; k.pmT = a->pmT; k.qproj = a->qproj + (long)t * B * Ad;
+            hipLaunchKernelGGL(attn_bwd_ds_mfma_kernel<true>, dim3(B, NA), dim3(ENT), sm_dsm, st, k);
+        } else if (ds_mfma) hipLaunchKernelGGL(attn_bwd_ds_mfma_kernel<false>, dim3(B, NA), dim3(ENT), sm_dsm, st, k);
         else hipLaunchKernelGGL(attn_bwd_ds_kernel, dim3(B, NA), dim3(ENT), sm_ds, st, k);
         // (4) attention-LSTM cell backward: dh = (dh_ext + dgates_{t+1}.W_hh) + dq_t.Wq  (short K = Ad product + pointwise)
         T2LstmBwdStep c;

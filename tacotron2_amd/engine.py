@@ -122,6 +122,10 @@ class Engine:
         self.ramp_chunks = True       # short chunks at the un-overlapped end of the forward / start of the backward pipeline
         self.share_cu = 1             # side-stream GEMMs next to the chains at ONE workgroup per CU: two 73 KB-LDS workgroups
                                       # per CU lock the attention kernels out (84.3 -> 83.2 ms)
+        # ... and recomputes the tanh terms (location convolution on the matrix pipe + stashed query projection + processed memory)
+        # instead of reading the forward's stash: 2.7 GB less memory per step at the bench shape, but +1.2 us per backward frame
+        # against -0.2 us per forward frame (measured: 64.0 vs 63.0 ms per step) - off by default, DESIGN.md section 4.4
+        self.attn_bwd_recompute = False
         self.attn_bwd_mfma = True     # attention backward: the per-slice kernel's correlations (dU, d_in) on the bf16 matrix pipe (T2AttnSeqBwd.ws_bd)
         self.bptt_off_chain = True    # the decoder-LSTM BPTT launches (side stream, a chunk ahead) keep the default wave priority
         self.sync_bn_group = None     # torch.distributed group: BatchNorm statistics over all ranks' shards (Trainer(sync_bn=True))
@@ -130,6 +134,10 @@ class Engine:
                                       # so only the LATEST forward can be back-propagated (checked in backward_tf)
         self.profile = False          # when True, mark() records HIP events at segment boundaries
         self.marks = []; self.spans = []               # [(name, event)] of the current step
+
+    def attn_bwd_recomputes_th(self, L: int, Ad: int, A: int) -> bool:
+        """True when the attention backward runs without the forward's tanh stash (t2_attn_bwd_recomputes_th)."""
+        return bool(self.attn_bwd_mfma and self.attn_bwd_recompute and _lib.call_value("t2_attn_bwd_recomputes_th", L, Ad, A) == 1)
 
     def persist_resident(self, D: int, B: int) -> bool:
         """True when the persistent decoder-LSTM launch (H/4 workgroups that wait for each other) is fully co-resident on this
@@ -437,7 +445,14 @@ class Engine:
         dech_t = self.buf("dech_t", T + 1, D // 16, Bp, 16, zero=(B != Bp))
         dech_t[0].zero_()
         gates_att = self.buf("gates_att", T, B, 4 * A) if save_for_backward else None
-        th = self.buf("th", T, B, Ad, (L + 3) // 4 * 4) if save_for_backward else None
+        # tanh terms of the energies: kept for the backward only when its per-slice kernel cannot recompute them (long texts, or
+        # the packed-FMA kernel) - the stash is [T][B][Ad][L4] floats, 2.7 GB per step at b=32, T=870, L=188
+        th = qproj = None
+        if save_for_backward:
+            if self.attn_bwd_recomputes_th(L, Ad, A):
+                qproj = self.buf("qproj", T, B, Ad)
+            else:
+                th = self.buf("th", T, B, Ad, (L + 3) // 4 * 4)
         align = torch.empty(B, T, L, dtype=torch.float32, device=self.dev)
         e_part = self.buf("e_part", B, Ad // 16, L)
         # packed in the column order of the xdec row [att_h | ctx], so each step reads ONE contiguous activation segment
@@ -447,7 +462,7 @@ class Engine:
                    W_ih_ctx=_ptr(P["decoder.att_rnn.weight_ih"], Pd), ld_wih=Pd + Ef,
                    W_hh=P["decoder.att_rnn.weight_hh"], Wq=P["decoder.attention.query_layer.weight"], U=U,
                    v=P["decoder.attention.v.weight"], pre=pre_att, pmT=pmT, memory=memory, len=len32,
-                   att_drop=masks.get("att_drop"), xdec=xdec, att_c=att_c, gates=gates_att, align=align, cum=cum, th=th,
+                   att_drop=masks.get("att_drop"), xdec=xdec, att_c=att_c, gates=gates_att, align=align, cum=cum, th=th, qproj=qproj,
                    xproj_ctx=_ptr(xproj, B * (D + Ef) + D), ld_xproj=D + Ef, e_part=e_part, xdec_t=xdec_t)
         # decoder-LSTM chain operands (prepared before the pipeline below)
         pre_dec = self.buf("pre_dec", T, B, 4 * D)
@@ -587,7 +602,7 @@ class Engine:
                                  length=mlen32 if last else None, fill=0.0)
         self.mark("fwd.postnet")
         ctx.update(controls=ctl, pmT=pmT, mel_tm=mel_tm, p1=p1, p2=p2, pd=pd, pre_att=pre_att, U=U, xdec=xdec, att_c=att_c, cum=cum,
-                   xproj=xproj, gates_att=gates_att, th=th, align=align, pre_dec=pre_dec, dec_c=dec_c,
+                   xproj=xproj, gates_att=gates_att, th=th, qproj=qproj, align=align, pre_dec=pre_dec, dec_c=dec_c,
                    gates_dec=gates_dec, proj=proj, post_in=post_in, masks=masks, training=training)
         return (mels, post, gates, align), ctx
 
@@ -741,7 +756,8 @@ class Engine:
                   dh_ext=dxdec, ld_dh=ldx, dctx_ext1=_ptr(dxdec, A), ld_dc1=ldx, dctx_ext2=_ptr(dxproj, D), ld_dc2=ldp,
                   dgates=Z, dctx_tot=dctx_tot, dq=None, dpmT=dpmT, dv_part=dv_part, dU_part=dU_part,
                   dc=dc_att, G=Gc, de=de, din_part=din_part, dgates_t=Zt, clk=getattr(self, "clk_bwd", None),
-                  ws_bd=self.buf("attn.ws_bd", Ad // 16 * 15360) if self.attn_bwd_mfma else None)
+                  ws_bd=self.buf("attn.ws_bd", Ad // 16 * 16896) if self.attn_bwd_mfma else None, pmT=ctx["pmT"],
+                  qproj=ctx["qproj"])
         self.mark("bwd.dec.proj")
         main, side = torch.cuda.current_stream(), self.side_stream()
         side.wait_stream(main)

@@ -642,7 +642,8 @@ def test_inference_above_64_utterances_is_one_loop_like_the_reference():
 @pytest.mark.parametrize("L", [1, 2, 15, 16, 17, 31, 33, 64, 97, 188, 231, 252, 253])
 def test_attention_backward_matrix_pipe_kernel_equals_packed_fma_kernel(L):
     """The per-slice kernel of the attention backward exists twice: correlations (dU, d_in) as packed-FMA loops (any L <= 768) and on
-    the bf16 matrix pipe with exactly split operands (L <= 252, Engine.attn_bwd_mfma / T2AttnSeqBwd.ws_bd).  Same inputs through both:
+    the bf16 matrix pipe with exactly split operands (L <= 252, Engine.attn_bwd_mfma / T2AttnSeqBwd.ws_bd) - the latter reading the
+    forward's tanh stash or recomputing the terms (Engine.attn_bwd_recompute, T2AttnSeqBwd.th = NULL).  Same inputs through all three:
     every gradient agrees to fp32 re-association level, over text lengths around the tile edges of the matrix-pipe build (16-row
     position tiles, 32-deep k-steps, 8-position d_in rows) and at its dispatch limit (L = 253 takes the packed-FMA kernel either way)."""
     dev = _dev()
@@ -651,19 +652,22 @@ def test_attention_backward_matrix_pipe_kernel_equals_packed_fma_kernel(L):
     P = R.init_params(d, seed=21)
     ci, lens, mel, tl, gate, masks = random_case(d, 3, L, 11, 300 + L, dev)
     grads = []
-    for mfma in (False, True):
+    for mfma, recompute in ((False, False), (True, False), (True, True)):
         eng, ps = build_engine(d, P, dev)
-        eng.attn_bwd_mfma = mfma
+        eng.attn_bwd_mfma, eng.attn_bwd_recompute = mfma, recompute
         outs, ctx = eng.forward_tf(ci.to(dev), lens.to(dev), mel.to(dev), tl.to(dev), training=True, masks=masks_to_device(masks, dev))
         ps.grad.zero_()
         eng.loss_and_grads(outs, ctx, mel.to(dev), gate.to(dev))
         torch.cuda.synchronize()
+        assert (ctx["th"] is None) == (mfma and recompute and L <= 252)      # the forward keeps no tanh stash exactly then
         grads.append(ps.grad.clone())
     gmax = float(grads[0].abs().max())
     for name in ps.P:
         if name in ("encoder.convolutions.0.bias", "encoder.convolutions.4.bias", "encoder.convolutions.8.bias"):
             continue      # a bias in front of BatchNorm: its gradient is identically zero, what is stored is cancellation noise
         o, k = ps.offsets[name], ps.P[name].numel()
-        a, b = grads[0][o:o + k].double(), grads[1][o:o + k].double()
+        a = grads[0][o:o + k].double()
         scale = max(float(a.abs().max()), 1e-3 * gmax)      # (tensors whose gradient is analytically zero carry rounding noise only)
-        assert float((a - b).abs().max()) < 2e-5 * scale, (name, float((a - b).abs().max()), scale)
+        for other in grads[1:]:
+            b = other[o:o + k].double()
+            assert float((a - b).abs().max()) < 2e-5 * scale, (name, float((a - b).abs().max()), scale)
