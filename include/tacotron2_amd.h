@@ -134,16 +134,22 @@ int t2_lstm_seq_fwd(const T2LstmStep* base, const T2LstmStride* inc, int n, int 
  * counters, sc1 loads), so the launch can run on its own stream next to other work without streaming weights every step.
  * Needs: packed single-segment path with K = H, `pre` (hoisted input projection), B <= 64 (rows are independent: blocks of
  * 32 rows run as consecutive launches), H/4 <= 256 workgroups, base->ht_out == base->xt + inc->xt (step s+1 reads the tiled h
- * of step s), inc->xt == inc->ht_out.
+ * of step s), inc->xt == inc->ht_out.  h_out2 (a second plain copy of h with its own stride) is written when given.
  * sync: >= 272 device words of scratch; words [0, 256) are the arrival counters (zeroed by every launch), word 256 is the
  * timeout flag: zeroed by the CALLER before first use and sticky - a wait that timed out (bounded spins) sets it, every launch
  * that sees it ends early (outputs unusable) until the caller has read and cleared it. */
 int t2_lstm_seq_fwd_persist(const T2LstmStep* base, const T2LstmStride* inc, int S, uint32_t* sync, void* stream);
+/* n = 1 or 2 INDEPENDENT cells of the same B and H in one persistent launch (grid.y = n; base[i], inc[i]): the two directions of
+ * the encoder BiLSTM (model/encoder.py:47-52), each walking its own way through time (inc[i] may be negative; base[i].len and
+ * base[i].t + s * inc[i].dt give the packed-sequence masking).  n * H/4 <= 256 workgroups; cell i counts arrivals in words
+ * [128 i, 128 i + 128) of `sync`, the timeout flag is word 256 for all. */
+int t2_lstm_seq_fwd_persist_n(const T2LstmStep* base, const T2LstmStride* inc, int n, int S, uint32_t* sync, void* stream);
 /* Residency check of the persistent launch above, without launching anything: T2_OK when H/4 workgroups with this K's weight
  * slice in LDS are all co-resident (compute units of the current device x hipOccupancyMaxActiveBlocksPerMultiprocessor),
  * T2_ERR_RESIDENCY otherwise - the caller then runs the same steps as t2_lstm_seq_fwd launches.  t2_lstm_seq_fwd_persist makes
  * the same check itself and returns the same code. */
 int t2_lstm_persist_resident(int H, int K, int B);
+int t2_lstm_persist_resident_n(int H, int K, int B, int n);      /* the same for n cells per launch (n * H/4 workgroups) */
 /* Debug / test hook: bound of the inter-workgroup waits of t2_lstm_seq_fwd_persist in polls (default 1 << 21; < 0: every wait
  * is treated as timed out, which raises the sticky flag sync[256] deterministically).  Returns the previous value. */
 int t2_debug_persist_spin_limit(int polls);

@@ -213,11 +213,13 @@ int launch_fwd(const T2LstmStep* steps, int n, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------
 struct PersistK {
     LstmK s;                 // operand block of step 0
-    long i_pre, i_drop, i_h_out, i_c_out, i_gates, i_xt, i_ht;    // element increments per step
+    long i_pre, i_drop, i_h_out, i_h_out2, i_c_out, i_gates, i_xt, i_ht;    // element increments per step
     int i_dt, steps;
-    unsigned* sync;          // [8 shards] x 16 words (room for 16), then at word 256: the timeout flag
+    unsigned* sync;          // this cell's arrival counters: [8 shards] x 16 words
+    unsigned* tmo;           // the timeout flag (shared by all persistent launches of an engine, sticky)
     int spin_limit;
 };
+struct PersistK2 { PersistK c[2]; };     // up to two independent cells per launch (grid.y): the two directions of the encoder BiLSTM
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // (Measured alternatives, profiles/r02_ab_fwd_dec_chain.txt: the two 16-row groups of a batch as two interleaved pipelines
@@ -225,9 +227,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // either way; one workgroup per group, two per CU - the 136 KB of LDS lock the attention kernels out of the CUs, the whole
 // forward gets 6 ms slower.)
 template <int MT>
-__global__ __launch_bounds__(256, 1) void lstm_seq_persist_fwd_kernel(PersistK pp) {
+__global__ __launch_bounds__(256, 1) void lstm_seq_persist_fwd_kernel(PersistK2 pq) {
     T2_CHAIN_PRIO();      // (default priority for this launch: +0.25 ms per step, profiles/r03_ab_bptt_priority_chunks.txt)
     extern __shared__ __attribute__((aligned(16))) float plds[];
+    const PersistK& pp = pq.c[blockIdx.y];
     const LstmK& p = pp.s;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_persist_fwd_kernel(PersistK p
     }
     const int nwg = gridDim.x;
     unsigned* my_shard = pp.sync + (bx & 7) * 16;
-    unsigned* tmo = pp.sync + 16 * 16;
+    unsigned* tmo = pp.tmo;
     const unsigned want_per_step = lane < 8 ? (unsigned)((nwg + 7 - lane) >> 3) : 0u;     // workgroups that add to shard `lane`
     const int eb = tid >> 2, euu = tid & 3, eu = u0 + euu;
     const long ebc = eb < p.B ? eb : p.B - 1;
@@ -296,7 +299,8 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_persist_fwd_kernel(PersistK p
                 const int c = (c0 + 4 * j) < NT ? (c0 + 4 * j) : NT - 1;
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    const unsigned off = (unsigned)((((long)c * p.xt_cs) + (m * 16 + r) * 16 + 4 * q) * 4);
+                    const int row = (m * 16 + r) < p.B ? (m * 16 + r) : p.B - 1;     // (padding rows are never written: read a real one)
+                    const unsigned off = (unsigned)((((long)c * p.xt_cs) + row * 16 + 4 * q) * 4);
                     ax[j][m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
                 }
                 bw[j] = *reinterpret_cast<const f32x4*>(wl + ((long)c * 64 + lane) * 4);
@@ -332,6 +336,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_persist_fwd_kernel(PersistK p
             if (!active) { hn = 0.f; cn = 0.f; gi = gf = gg = go = 0.f; }
             c_reg = cn;
             (p.h_out + (long)s * pp.i_h_out)[(long)eb * p.ldh + eu] = hn;
+            if (p.h_out2) (p.h_out2 + (long)s * pp.i_h_out2)[(long)eb * p.ldh2 + eu] = hn;
             {   // the exchanged copy: write-through
                 float* ht = p.ht_out + (long)s * pp.i_ht;
                 const int col = p.ht_col0 + eu;
@@ -638,46 +643,61 @@ static size_t persist_lds_bytes(int K) {
     return ((size_t)NTpad * 256 + (size_t)4 * 2 * 256 + 4) * sizeof(float);
 }
 
-extern "C" int t2_lstm_persist_resident(int H, int K, int B) {
+extern "C" int t2_lstm_persist_resident_n(int H, int K, int B, int n) {
     (void)hipGetLastError();
-    T2_REQUIRE(H >= 4 && H % 4 == 0 && K >= 16 && K % 16 == 0 && B >= 1, "t2_lstm_persist_resident: bad arguments");
+    T2_REQUIRE(H >= 4 && H % 4 == 0 && K >= 16 && K % 16 == 0 && B >= 1 && n >= 1, "t2_lstm_persist_resident: bad arguments");
     const size_t lds = persist_lds_bytes(K);
     T2_REQUIRE(t2_allow_lds(lstm_seq_persist_fwd_kernel<1>, lds) && t2_allow_lds(lstm_seq_persist_fwd_kernel<2>, lds),
                "t2_lstm_persist_resident: weight slice does not fit the LDS");
-    return persist_resident(H / 4, B <= 16 ? 1 : 2, lds);
+    return persist_resident(n * (H / 4), B <= 16 ? 1 : 2, lds);
 }
+extern "C" int t2_lstm_persist_resident(int H, int K, int B) { return t2_lstm_persist_resident_n(H, K, B, 1); }
 
-extern "C" int t2_lstm_seq_fwd_persist(const T2LstmStep* base, const T2LstmStride* inc, int S, uint32_t* sync, void* stream) {
+extern "C" int t2_lstm_seq_fwd_persist_n(const T2LstmStep* base, const T2LstmStride* inc, int n, int S, uint32_t* sync, void* stream) {
     (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
-    T2_REQUIRE(base && inc && sync && S >= 0, "t2_lstm_seq_fwd_persist: bad arguments");
+    T2_REQUIRE(base && inc && sync && S >= 0 && (n == 1 || n == 2), "t2_lstm_seq_fwd_persist: bad arguments");
     if (S == 0) return T2_OK;
-    T2_TRY(t2_lstm_check_step(*base));
-    const T2LstmStep& b = *base;
-    T2_REQUIRE(b.wpacked && b.nseg == 1 && b.xt && b.ht_out && b.B <= 64 && b.pre && b.H % 4 == 0,
-               "t2_lstm_seq_fwd_persist: needs the packed single-segment path with x16-tiled h exchange and B <= 64");
-    T2_REQUIRE(b.seg[0].K == b.H && b.ht_col0 == 0 && inc->xt == inc->ht_out && b.ht_out == b.xt + inc->xt,
-               "t2_lstm_seq_fwd_persist: the input of step s+1 must be the tiled h of step s (K = H)");
-    T2_REQUIRE(b.H / 4 <= 256 && !b.h_out2, "t2_lstm_seq_fwd_persist: at most 256 workgroups (one per CU), no second h copy");
+    for (int i = 0; i < n; ++i) {
+        T2_TRY(t2_lstm_check_step(base[i]));
+        const T2LstmStep& b = base[i];
+        T2_REQUIRE(b.wpacked && b.nseg == 1 && b.xt && b.ht_out && b.B <= 64 && b.pre && b.H % 4 == 0,
+                   "t2_lstm_seq_fwd_persist: needs the packed single-segment path with x16-tiled h exchange and B <= 64");
+        T2_REQUIRE(b.seg[0].K == b.H && b.ht_col0 == 0 && inc[i].xt == inc[i].ht_out && b.ht_out == b.xt + inc[i].xt,
+                   "t2_lstm_seq_fwd_persist: the input of step s+1 must be the tiled h of step s (K = H)");
+        T2_REQUIRE(b.B == base[0].B && b.H == base[0].H, "t2_lstm_seq_fwd_persist: the cells of one launch share B and H");
+    }
+    const T2LstmStep& b = base[0];
+    T2_REQUIRE(n * (b.H / 4) <= 256, "t2_lstm_seq_fwd_persist: at most 256 workgroups (one per CU)");
     const size_t lds = persist_lds_bytes(b.seg[0].K);
     T2_REQUIRE(t2_allow_lds(lstm_seq_persist_fwd_kernel<1>, lds) && t2_allow_lds(lstm_seq_persist_fwd_kernel<2>, lds),
                "t2_lstm_seq_fwd_persist: weight slice does not fit the LDS");
-    T2_TRY(persist_resident(b.H / 4, (b.B < 32 ? b.B : 32) <= 16 ? 1 : 2, lds));
+    T2_TRY(persist_resident(n * (b.H / 4), (b.B < 32 ? b.B : 32) <= 16 ? 1 : 2, lds));
     hipStream_t st = (hipStream_t)stream;
     // Rows are independent: blocks of up to 32 rows (two 16-row tiles) run as consecutive launches of the same chunk.  Each
-    // launch zeroes the arrival counters; the timeout flag (word 256) is sticky - only the host clears it.
+    // launch zeroes the arrival counters (128 words per cell); the timeout flag (word 256) is sticky - only the host clears it.
     for (int b0 = 0; b0 < b.B; b0 += 32) {
         const int bn = (b.B - b0) < 32 ? (b.B - b0) : 32;
-        PersistK k;
-        t2_lstm_to_k(b, k.s, b0, bn);
-        k.i_pre = inc->pre; k.i_drop = inc->drop; k.i_h_out = inc->h_out; k.i_c_out = inc->c_out; k.i_gates = inc->gates_out;
-        k.i_xt = inc->xt; k.i_ht = inc->ht_out; k.i_dt = inc->dt; k.steps = S; k.sync = sync; k.spin_limit = g_persist_spin_limit;
+        PersistK2 kk;
+        for (int i = 0; i < n; ++i) {
+            PersistK& k = kk.c[i];
+            t2_lstm_to_k(base[i], k.s, b0, bn);
+            k.i_pre = inc[i].pre; k.i_drop = inc[i].drop; k.i_h_out = inc[i].h_out; k.i_h_out2 = inc[i].h_out2;
+            k.i_c_out = inc[i].c_out; k.i_gates = inc[i].gates_out;
+            k.i_xt = inc[i].xt; k.i_ht = inc[i].ht_out; k.i_dt = inc[i].dt; k.steps = S;
+            k.sync = sync + i * 128; k.tmo = sync + 256; k.spin_limit = g_persist_spin_limit;
+        }
+        if (n == 1) kk.c[1] = kk.c[0];
         (void)hipMemsetAsync(sync, 0, 16 * 16 * sizeof(uint32_t), st);
-        dim3 grid(b.H / 4), block(256);
-        if (bn <= 16) hipLaunchKernelGGL((lstm_seq_persist_fwd_kernel<1>), grid, block, lds, st, k);
-        else hipLaunchKernelGGL((lstm_seq_persist_fwd_kernel<2>), grid, block, lds, st, k);
+        dim3 grid(b.H / 4, n), block(256);
+        if (bn <= 16) hipLaunchKernelGGL((lstm_seq_persist_fwd_kernel<1>), grid, block, lds, st, kk);
+        else hipLaunchKernelGGL((lstm_seq_persist_fwd_kernel<2>), grid, block, lds, st, kk);
     }
     T2_CHECK_LAUNCH();
     return T2_OK;
+}
+
+extern "C" int t2_lstm_seq_fwd_persist(const T2LstmStep* base, const T2LstmStride* inc, int S, uint32_t* sync, void* stream) {
+    return t2_lstm_seq_fwd_persist_n(base, inc, 1, S, sync, stream);
 }
 
 extern "C" int t2_lstm_pack_fwd(const T2Seg* segs, int nseg, int H, float* out, void* stream) {

@@ -126,6 +126,7 @@ class Engine:
         # instead of reading the forward's stash: 2.7 GB less memory per step at the bench shape, but +1.2 us per backward frame
         # against -0.2 us per forward frame (measured: 64.0 vs 63.0 ms per step) - off by default, DESIGN.md section 4.4
         self.attn_bwd_recompute = False
+        self.enc_chain = "persistent"    # encoder BiLSTM recurrence: "persistent" (one launch, both directions) | "steps" (S launches)
         self.attn_bwd_mfma = True     # attention backward: the per-slice kernel's correlations (dU, d_in) on the bf16 matrix pipe (T2AttnSeqBwd.ws_bd)
         self.bptt_off_chain = True    # the decoder-LSTM BPTT launches (side stream, a chunk ahead) keep the default wave priority
         self.sync_bn_group = None     # torch.distributed group: BatchNorm statistics over all ranks' shards (Trainer(sync_bn=True))
@@ -139,16 +140,22 @@ class Engine:
         """True when the attention backward runs without the forward's tanh stash (t2_attn_bwd_recomputes_th)."""
         return bool(self.attn_bwd_mfma and self.attn_bwd_recompute and _lib.call_value("t2_attn_bwd_recomputes_th", L, Ad, A) == 1)
 
-    def persist_resident(self, D: int, B: int) -> bool:
-        """True when the persistent decoder-LSTM launch (H/4 workgroups that wait for each other) is fully co-resident on this
+    def persist_resident(self, D: int, B: int, n: int = 1) -> bool:
+        """True when the persistent LSTM launch (n cells x H/4 workgroups that wait for each other) is fully co-resident on this
         device (t2_lstm_persist_resident: compute units x occupancy); otherwise the chain runs as per-step launches."""
-        key = (D, min(B, 32) <= 16)
+        key = (D, min(B, 32) <= 16, n)
         if key not in self._persist_ok:
-            rc = _lib.call_value("t2_lstm_persist_resident", D, D, min(B, 32))
+            rc = _lib.call_value("t2_lstm_persist_resident_n", D, D, min(B, 32), n)
             if rc not in (0, 3):
                 raise _lib.T2Error(f"t2_lstm_persist_resident failed (rc={rc}): {_lib.lib().t2_last_error().decode()}")
             self._persist_ok[key] = rc == 0
         return self._persist_ok[key]
+
+    def persist_sync(self):
+        """Scratch of the persistent launches: arrival counters (words 0..255), sticky timeout flag (word 256)."""
+        if self._persist_sync is None:
+            self._persist_sync = torch.zeros(320, dtype=torch.int32, device=self.dev)
+        return self._persist_sync
 
     def check_persistent_kernels(self):
         """Host-synchronising check of the persistent launches' timeout flag (bounded spins end the launch early instead of
@@ -318,6 +325,14 @@ class Engine:
         enc = self.buf("enc.out", B, L, E)
         steps = (_lib.S["T2LstmStep"] * 2)()
         incs = (_lib.S["T2LstmStride"] * 2)()
+        # The recurrence as ONE persistent launch for both directions (t2_lstm_seq_fwd_persist_n: 2 x H/4 workgroups, W_hh slices in
+        # LDS, h exchanged through an x16-tiled stash) instead of S launches of ~8 us
+        persist = B <= 64 and self.enc_chain == "persistent" and H % 16 == 0 and self.persist_resident(H, B, 2)
+        ctx["enc_persist"] = persist
+        if persist:
+            Bp = (B + 15) // 16 * 16
+            ht = self.buf("enc.ht", 2, S + 1, H // 16, Bp, 16, zero=(B != Bp))
+            ht[0, 0].zero_(); ht[1, S].zero_()
         for dr in range(2):
             t0 = 0 if dr == 0 else S - 1
             sg = 1 if dr == 0 else -1
@@ -340,7 +355,17 @@ class Engine:
             ic.seg_x[0] = sg * B * H
             ic.pre = sg * 8 * H; ic.c_prev = sg * B * H; ic.h_out = sg * B * H; ic.h_out2 = sg * E
             ic.c_out = sg * B * H; ic.gates_out = sg * B * 4 * H; ic.dt = sg
-        call("t2_lstm_seq_fwd", steps, incs, 2, S, _stream())
+            if persist:
+                st.xt = _ptr(ht[dr, slot_in]); st.ht_out = _ptr(ht[dr, slot_out]); st.ht_col0 = 0
+                ic.xt = sg * H * Bp; ic.ht_out = sg * H * Bp
+        self.mark("fwd.enc.convs")
+        if persist:
+            call("t2_lstm_seq_fwd_persist_n", steps, incs, 2, S, self.persist_sync(), _stream())
+            # (a wait that timed out - sticky device flag - turns the encoder output into NaN: every later result of this forward,
+            #  training or inference, carries it; the host raises at its next check_persistent_kernels)
+            call("t2_guard_poison", self._persist_sync.data_ptr() + 4 * 256, enc, B * L * E, _stream())
+        else:
+            call("t2_lstm_seq_fwd", steps, incs, 2, S, _stream())
         ctx["enc_stash"] = dict(x3=x, pre=pre, hs=hs, cs=cs, gs=gs, B=B, L=L)
         return enc
 
@@ -405,7 +430,7 @@ class Engine:
                  bias=P["decoder.att_rnn.bias_ih"], bias2=P["decoder.att_rnn.bias_hh"])
             self.span_end("fwd.dec.pre_att_gemm.side_stream", sp0)   # part of the decoder step; runs next to the encoder
         enc = self.encoder_fwd(chars_idx, len32, training, masks, ctx)
-        self.mark("fwd.encoder")
+        self.mark("fwd.enc.bilstm")
 
         # conditioning (model/tacotron2.py:201-229)
         memory = self.buf("memory", B, L, Ef)
@@ -520,9 +545,7 @@ class Engine:
             # The decoder-LSTM chain of a chunk as ONE persistent, weight-stationary launch on the side stream
             # (t2_lstm_seq_fwd_persist): W_hh stays in LDS, the workgroups exchange h through the tiled stash, and the
             # attention chain on the main stream runs without hosted cells (energies launch 11 -> 7.5 us per frame).
-            if self._persist_sync is None:
-                self._persist_sync = torch.zeros(320, dtype=torch.int32, device=self.dev)   # (word 256: sticky timeout flag)
-            sync = self._persist_sync
+            sync = self.persist_sync()
             for i, (c0, c1) in enumerate(chunks):
                 seq.t_begin, seq.t_end = c0, c1
                 seq.co_step, seq.co_inc, seq.co_steps = None, None, 0
@@ -1168,6 +1191,7 @@ class Engine:
                     Bg=[G["B"] for G in groups] + [0] * (8 - len(groups)), ngroups=len(groups), ld_proj=ldo, M=M, nframes=t0)
         call("t2_stop_scan", scan, lengths, nfr, st)
         n = max(int(nfr.cpu()[0]), 1)
+        self.check_persistent_kernels()      # (the encoder recurrence is a persistent launch; the host has just synchronised anyway)
         # outputs: mask by the counted lengths, postnet on the unmasked mels (model/tacotron2.py:327-345)
         mlen32 = lengths.to(torch.int32)
         mels = torch.empty(B, n, M, dtype=torch.float32, device=self.dev)

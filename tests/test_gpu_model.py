@@ -671,3 +671,31 @@ def test_attention_backward_matrix_pipe_kernel_equals_packed_fma_kernel(L):
         for other in grads[1:]:
             b = other[o:o + k].double()
             assert float((a - b).abs().max()) < 2e-5 * scale, (name, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("B,L", [(5, 37), (16, 1), (33, 21), (64, 12)])
+def test_encoder_bilstm_persistent_launch_equals_step_launches(B, L):
+    """The encoder BiLSTM recurrence runs as ONE persistent launch for both directions (Engine.enc_chain = "persistent",
+    t2_lstm_seq_fwd_persist_n) or as L launches of the step kernel ("steps").  Same inputs through both - ragged lengths, so the
+    reverse direction starts inside the padding (packed-sequence masking, model/encoder.py:47-52), row blocks of 32 - give the same
+    encoder output and the same stashes for the backward (h, c, gates per direction and step)."""
+    dev = _dev()
+    d = R.default_dims(num_chars=39, encoded_dim=64, prenet_dim=32, att_rnn_dim=64, att_dim=32, rnn_hidden_dim=64,
+                       postnet_dim=64, num_mels=16, dropout=0.5)
+    P = R.init_params(d, seed=5)
+    ci, lens, mel, tl, gate, masks = random_case(d, B, L, 4, 500 + B, dev)
+    got = []
+    for mode in ("steps", "persistent"):
+        eng, ps = build_engine(d, P, dev)
+        eng.enc_chain = mode
+        ctx = {}
+        enc = eng.encoder_fwd(ci.to(dev), lens.to(torch.int32).to(dev), True, masks_to_device(masks, dev), ctx)
+        torch.cuda.synchronize()
+        eng.check_persistent_kernels()
+        assert ctx["enc_persist"] == (mode == "persistent")
+        e = ctx["enc_stash"]
+        got.append([enc.clone(), e["hs"].clone(), e["cs"].clone(), e["gs"].clone()])
+    for other in got[1:]:
+        for a, b in zip(got[0], other):
+            assert float((a - b).abs().max()) <= 2e-6 * max(float(a.abs().max()), 1.0)
+    assert float(got[0][0].abs().max()) > 0.01

@@ -1,4 +1,4 @@
-"""The persistent decoder-LSTM launch (t2_lstm_seq_fwd_persist) is a kernel whose workgroups wait for each other; every wait
+"""The persistent LSTM launches (t2_lstm_seq_fwd_persist: decoder LSTM per chunk, encoder BiLSTM) are kernels whose workgroups wait for each other; every wait
 is bounded, and a wait that gives up must stop the training run instead of feeding garbage decoder states into the
 optimiser.  These tests force the timeout path (debug bound < 0: every wait counts as timed out) and check the chain of
 consequences: sticky device flag -> outputs and loss NaN (t2_guard_poison) -> optimiser step skipped (t2_adam_step with a
@@ -50,7 +50,8 @@ def test_engine_falls_back_to_step_launches_without_residency():
     torch.cuda.synchronize()
     assert tr.engine._persist_sync is not None                     # the persistent path ran
     tr2, ps2, _ = _small_trainer(dev)
-    tr2.engine._persist_ok = {(64, True): False}                   # as if t2_lstm_persist_resident had said no
+    tr2.engine._persist_ok = {(64, True, 1): False, (32, True, 2): False}     # as if t2_lstm_persist_resident had said no (decoder
+                                                                                # LSTM H = 64; encoder BiLSTM 2 x H = 32)
     loss_s, _ = tr2.train_step(batch)
     torch.cuda.synchronize()
     assert tr2.engine._persist_sync is None                        # per-step launches on the side stream instead

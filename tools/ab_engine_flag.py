@@ -43,5 +43,5 @@ for rep in range(2):
             dt = (time.perf_counter() - t0) / 8 * 1e3
             tr.engine.profile = False
         seg = tr.engine.segment_times_ms()
-        keys = ("fwd.encoder", "fwd.dec.attn_chain", "fwd.postnet", "bwd.postnet", "bwd.dec.chains", "bwd.bilstm", "bwd.encoder_convs")
+        keys = ("fwd.enc.convs", "fwd.enc.bilstm", "fwd.dec.attn_chain", "fwd.postnet", "bwd.postnet", "bwd.dec.chains", "bwd.bilstm", "bwd.encoder_convs")
         print(f"{var}{' [hiprio]' if hiprio else ''}: {dt:.2f} ms/step  " + "  ".join(f"{k} {seg.get(k, 0):.2f}" for k in keys) + f"  loss {float(loss3.sum()):.4f}", flush=True)
