@@ -475,6 +475,15 @@ __global__ __launch_bounds__(256, 1) void lstm_step_bwd_fast_kernel(BwdK2 pp) {
     t2_lstm_bwd_fast_body<4, 4>(pp.s[blockIdx.z], blockIdx.x, blockIdx.y, red);
 }
 
+// The same with eight waves splitting K, for launches of few workgroups (the encoder BiLSTM backward: 64 workgroups with K = 1024
+// on a chip of 256 compute units): half the chunks, loads and MFMAs per wave.
+__global__ __launch_bounds__(512, 1) void lstm_step_bwd_fast8_kernel(BwdK2 pp) {
+    if (!pp.s[blockIdx.z].off_chain) T2_CHAIN_PRIO();
+    __shared__ float red[8 * 256];
+    t2_lstm_bwd_fast_body<8, 2>(pp.s[blockIdx.z], blockIdx.x, blockIdx.y, red);
+}
+static int g_bwd8_max_wgs = getenv("T2_BWD8_MAX_WGS") ? atoi(getenv("T2_BWD8_MAX_WGS")) : 64;
+
 int launch_bwd(const T2LstmBwdStep* steps, int n, hipStream_t st) {
     T2_REQUIRE(n == 1 || n == 2, "lstm bwd step: n must be 1 or 2");
     BwdK2 kk;
@@ -490,7 +499,8 @@ int launch_bwd(const T2LstmBwdStep* steps, int n, hipStream_t st) {
     int maxcols = steps[0].ncols;
     for (int i = 1; i < n; ++i) maxcols = steps[i].ncols > maxcols ? steps[i].ncols : maxcols;
     dim3 grid(t2_cdiv(maxcols, 16), t2_cdiv(steps[0].B, 16), n), block(256);
-    if (fast) hipLaunchKernelGGL(lstm_step_bwd_fast_kernel, grid, block, 0, st, kk);
+    if (fast && (int)(grid.x * grid.y * grid.z) <= g_bwd8_max_wgs) hipLaunchKernelGGL(lstm_step_bwd_fast8_kernel, grid, dim3(512), 0, st, kk);
+    else if (fast) hipLaunchKernelGGL(lstm_step_bwd_fast_kernel, grid, block, 0, st, kk);
     else hipLaunchKernelGGL(lstm_step_bwd_kernel, grid, block, 0, st, kk);
     T2_CHECK_LAUNCH();
     return T2_OK;

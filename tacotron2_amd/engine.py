@@ -126,6 +126,7 @@ class Engine:
         # instead of reading the forward's stash: 2.7 GB less memory per step at the bench shape, but +1.2 us per backward frame
         # against -0.2 us per forward frame (measured: 64.0 vs 63.0 ms per step) - off by default, DESIGN.md section 4.4
         self.attn_bwd_recompute = False
+        self.splitk_small_chunks = True  # forward pipeline: the hoisted decoder-LSTM input GEMM of short chunks runs split-K
         self.enc_chain = "persistent"    # encoder BiLSTM recurrence: "persistent" (one launch, both directions) | "steps" (S launches)
         self.attn_bwd_mfma = True     # attention backward: the per-slice kernel's correlations (dU, d_in) on the bf16 matrix pipe (T2AttnSeqBwd.ws_bd)
         self.bptt_off_chain = True    # the decoder-LSTM BPTT launches (side stream, a chunk ahead) keep the default wave priority
@@ -525,9 +526,15 @@ class Engine:
         def pre_dec_gemm(c0, c1):
             if cterm is not None:     # per-utterance controls term first, the projection accumulates on top
                 pre_dec[c0:c1].copy_(cterm.unsqueeze(0).expand(c1 - c0, B, 4 * D))
+            # the short chunks at the end of the ramp leave the chip under-filled (8 frames x 32 rows: 64 tiles of 128 x 128) and
+            # sit on the exposed tail of the forward: K slices accumulate into the pre-filled block with atomics
+            tiles = (((c1 - c0) * B + 127) // 128) * ((4 * D + 127) // 128)
+            sk = max(1, min(4, 256 // max(tiles, 1))) if self.splitk_small_chunks else 1
+            if sk > 1 and cterm is None:
+                pre_dec[c0:c1].zero_()
             gemm(_ptr(xdec, (c0 + 1) * B * (A + Ef)), P["decoder.lstm.weight_ih"], _ptr(pre_dec, c0 * B * 4 * D), (c1 - c0) * B,
                  4 * D, A + Ef, A + Ef, A + Ef, 4 * D, bias=P["decoder.lstm.bias_ih"], bias2=P["decoder.lstm.bias_hh"],
-                 accumulate=1 if cterm is not None else 0)
+                 accumulate=2 if sk > 1 else (1 if cterm is not None else 0), splitk=sk)
 
         main, side = torch.cuda.current_stream(), self.side_stream()
         side.wait_stream(main)
