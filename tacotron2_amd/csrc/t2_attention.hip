@@ -1123,10 +1123,11 @@ __host__ __device__ inline DsDims ds_dims(int L) {
     return d;
 }
 
-// RECOMP: the tanh terms are not read from a stash of the forward but recomputed here - query projection, location convolution (on
-// the matrix pipe, as attn_energy_body), + processed memory, tanh - from operands that do NOT depend on the backward chain, in the
-// ~2 us this kernel otherwise waits for the energy gradients of the dw launch.  The forward then stores no tanh stash: 1.5 us per
-// frame of end-of-kernel write-back in the energies launch, 2.7 GB of HBM writes and as many reads per training step.
+// RECOMP: the tanh terms are not read from a stash of the forward but recomputed here - stashed query projection (128 values per
+// frame and sample) + location convolution on the matrix pipe (as attn_energy_body, from the input planes this kernel stages anyway,
+// filter fragments from attn_bwd_prep_kernel) + processed memory, tanh.  The forward then neither writes nor keeps the stash
+// (2.7 GB per training step at the bench shape).  It is an OPTION (Engine.attn_bwd_recompute): this kernel reaches its first barrier
+// 1.1 us later, and the forward chain gains only 0.2 us per frame from the missing write-back.
 template <bool RECOMP>
 __global__ __launch_bounds__(ENT, 4) void attn_bwd_ds_mfma_kernel(AttnBwdK p) {
     T2_CHAIN_PRIO();
