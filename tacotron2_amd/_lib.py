@@ -12,7 +12,8 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(HERE, "..", "include", "tacotron2_amd.h")
-LIB_PATH = os.path.join(HERE, "libtacotron2_amd.so")
+# (T2_LIB_PATH: another build of the same C ABI, e.g. the diagnostic one with in-kernel phase stamps - tacotron2_amd/build.py)
+LIB_PATH = os.environ.get("T2_LIB_PATH") or os.path.join(HERE, "libtacotron2_amd.so")
 
 _SCALARS = {"int": C.c_int, "float": C.c_float, "int64_t": C.c_int64, "int32_t": C.c_int32, "uint64_t": C.c_uint64,
             "double": C.c_double}

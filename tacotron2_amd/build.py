@@ -23,6 +23,36 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+STAMPS_LIB = os.path.join(HERE, "libtacotron2_amd_stamps.so")
+
+
+def build_stamps(verbose: bool = True) -> str:
+    """The DIAGNOSTIC library: the same sources with -DT2_STAMPS, i.e. with the in-kernel phase stamps (s_memtime words of one
+    workgroup, read by tools/ubench_attn.py and tools/stamps_bwd.py) compiled in.  The product library has none: each stamp is a
+    branch that ends a basic block, and the kernels of the frame chains run 0.3-0.5 us longer per launch with them.  Select it with
+    T2_LIB_PATH (tacotron2_amd/_lib.py)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    if os.path.exists(STAMPS_LIB) and all(os.path.getmtime(os.path.join(CSRC, f)) < os.path.getmtime(STAMPS_LIB) for f in os.listdir(CSRC)):
+        return STAMPS_LIB
+    objdir = os.path.join(HERE, "..", "build", "obj_stamps")
+    os.makedirs(objdir, exist_ok=True)
+    procs, objs = [], []
+    for s in srcs:
+        o = os.path.join(objdir, os.path.basename(s) + ".o")
+        objs.append(o)
+        cmd = [hipcc] + FLAGS + ["-DT2_STAMPS"] + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", s, "-o", o]
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {s}:\n{out}")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", STAMPS_LIB] + objs)
+    if verbose:
+        print(f"built {STAMPS_LIB} (diagnostic, -DT2_STAMPS)")
+    return STAMPS_LIB
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not force and not _stale():
@@ -58,5 +88,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    if "--stamps" in sys.argv:
+        print(build_stamps())
+    else:
+        build(force="--force" in sys.argv)
+        print(LIB)

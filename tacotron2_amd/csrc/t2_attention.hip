@@ -39,7 +39,13 @@ struct AttnK {
     float* ctxt_out; int ctxt_col0; long ctxt_cs;
     unsigned long long* clk;   // diagnostic: shader-clock stamps of workgroup (0,0) (T2AttnStep.clk), or null
 };
+// In-kernel phase stamps exist in the DIAGNOSTIC build only (-DT2_STAMPS, tacotron2_amd/build.py --stamps): each one is a branch
+// that ends a basic block, and the instruction scheduler does not move loads or MFMAs of the next phase across it.
+#ifdef T2_STAMPS
 #define T2_STAMP(p, cond, i) do { if ((p).clk && (cond)) (p).clk[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define T2_STAMP(p, cond, i) do { } while (0)
+#endif
 
 // Load discipline for these one-workgroup-per-CU kernels: every global load of a phase is ISSUED (unconditionally, from a
 // clamped in-range address) before anything waits on one; out-of-range lanes are zeroed by a select afterwards.  A
@@ -268,7 +274,7 @@ __device__ __forceinline__ void stage_commit_split(const StageRegs<NTH>& r, unsi
 
 __device__ __forceinline__ void attn_energy_body(const AttnK& p, const int b, const int j, float* sm) {
     const int tid = threadIdx.x, lane = tid & 63;
-    const bool stamp = b == 0 && j == 0 && tid == 0;
+    [[maybe_unused]] const bool stamp = b == 0 && j == 0 && tid == 0;
     T2_STAMP(p, stamp, 0);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
     const int n = lane & 15, q = lane >> 4;                   // MFMA column = dim of the slice (also this lane's A row), row group
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(ENT, 4) void attn_energy_kernel(AttnK p) {
 
 __device__ __forceinline__ void attn_context_body(const AttnK& p, const int b, const int es0, float* sm) {
     const int tid = threadIdx.x;
-    const bool stamp = b == 0 && es0 == 0 && tid == 0;
+    [[maybe_unused]] const bool stamp = b == 0 && es0 == 0 && tid == 0;
     T2_STAMP(p, stamp, 8);
     const int L = p.L, NA = p.Ad >> 4;
     constexpr int NR = 24;
@@ -756,7 +762,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dw_kernel(AttnBwdK p) {
     float* dctx_s = sm;                    // [max(Ef, 640)] zero past Ef: the product loop below is branch-free
     float* dwx_s = dctx_s + DS;            // [L rounded]
     float* red = dwx_s + ((L + 3) & ~3);   // [8]
-    const bool stamp = b == 0 && blockIdx.y == 0 && tid == 0;
+    [[maybe_unused]] const bool stamp = b == 0 && blockIdx.y == 0 && tid == 0;
     T2_STAMP(p, stamp, 16);
     const int l = l0 + (tid >> 3), sub = tid & 7;
     // ---- issue FIRST the small loads that depend on the previous launches (upstream context gradient, location-path
@@ -869,7 +875,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dw_kernel(AttnBwdK p) {
 
 __device__ __forceinline__ void attn_bwd_ds_body(const AttnBwdK& p, const int b, const int j, float* sm) {
     const int tid = threadIdx.x;
-    const bool stamp = b == 0 && j == 0 && tid == 0;
+    [[maybe_unused]] const bool stamp = b == 0 && j == 0 && tid == 0;
     T2_STAMP(p, stamp, 24);
     const int al = tid >> 5, sub = tid & 31, a = j * 16 + al;
     const int L = p.L, NG = (L + 3) >> 2, Lp = 4 * NG + 36, L4 = 4 * NG;
@@ -1134,7 +1140,7 @@ __global__ __launch_bounds__(ENT, 4) void attn_bwd_ds_mfma_kernel(AttnBwdK p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x, j = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
-    const bool stamp = b == 0 && j == 0 && tid == 0;
+    [[maybe_unused]] const bool stamp = b == 0 && j == 0 && tid == 0;
     T2_STAMP(p, stamp, 24);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int al = tid >> 5, sub = tid & 31, a = j * 16 + al;

@@ -16,7 +16,7 @@
 #include "t2_common.hpp"
 #include "t2_lstm_step.hpp"
 
-// Diagnostic only (t2_debug_clock): when enabled, workgroup 0 of the forward fast kernel stamps the shader clock
+// Diagnostic build only (-DT2_STAMPS; t2_debug_clock): when enabled, workgroup 0 of the forward fast kernel stamps the shader clock
 // (s_memtime, words 0 and 6) and the 100 MHz reference (s_memrealtime, words 1 and 7) at entry and exit; nothing else
 // reads these words.
 __device__ unsigned long long g_t2_clk[8];
@@ -155,10 +155,14 @@ template <int MT, int U>
 __global__ __launch_bounds__(256, 1) void lstm_step_fwd_fast_kernel(LstmK2 pp) {
     T2_CHAIN_PRIO();
     __shared__ float red[4 * MT * 256];
+#ifdef T2_STAMPS      // diagnostic build only: every stamp is a branch the instruction scheduler does not move work across
     const bool stamp = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && g_t2_clk_enable;
     if (stamp) { g_t2_clk[0] = __builtin_amdgcn_s_memtime(); g_t2_clk[1] = __builtin_amdgcn_s_memrealtime(); }
     t2_lstm_fwd_fast_body<MT, U>(pp.s[blockIdx.y], blockIdx.x, red, stamp ? g_t2_clk : nullptr);
     if (stamp) { g_t2_clk[6] = __builtin_amdgcn_s_memtime(); g_t2_clk[7] = __builtin_amdgcn_s_memrealtime(); }
+#else
+    t2_lstm_fwd_fast_body<MT, U>(pp.s[blockIdx.y], blockIdx.x, red);
+#endif
 }
 
 int launch_fwd(const T2LstmStep* steps, int n, hipStream_t st) {

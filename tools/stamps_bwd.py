@@ -1,6 +1,8 @@
 """Phase stamps of the backward attention kernels inside a real training step (diagnostic, GPU box only)."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tacotron2_amd.build import build_stamps
+os.environ["T2_LIB_PATH"] = build_stamps()      # the diagnostic library: phase stamps are compiled out of the product build
 import bench
 from tacotron2_amd.params import ParamStore
 from tacotron2_amd.trainer import Trainer

@@ -1,6 +1,8 @@
 """Attention chain (forward) timing with and without the backward stashes (GPU box only)."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tacotron2_amd.build import build_stamps
+os.environ["T2_LIB_PATH"] = build_stamps()      # the diagnostic library: phase stamps are compiled out of the product build
 from tacotron2_amd import _lib
 from tacotron2_amd._lib import call, make
 
