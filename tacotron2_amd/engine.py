@@ -127,6 +127,7 @@ class Engine:
         # against -0.2 us per forward frame (measured: 64.0 vs 63.0 ms per step) - off by default, DESIGN.md section 4.4
         self.attn_bwd_recompute = False
         self.splitk_small_chunks = True  # forward pipeline: the hoisted decoder-LSTM input GEMM of short chunks runs split-K
+        self.enc_persist_max_rows = 32   # (the launch itself takes up to 64 rows, as two consecutive blocks)
         self.enc_chain = "persistent"    # encoder BiLSTM recurrence: "persistent" (one launch, both directions) | "steps" (S launches)
         self.attn_bwd_mfma = True     # attention backward: the per-slice kernel's correlations (dU, d_in) on the bf16 matrix pipe (T2AttnSeqBwd.ws_bd)
         self.bptt_off_chain = True    # the decoder-LSTM BPTT launches (side stream, a chunk ahead) keep the default wave priority
@@ -328,7 +329,8 @@ class Engine:
         incs = (_lib.S["T2LstmStride"] * 2)()
         # The recurrence as ONE persistent launch for both directions (t2_lstm_seq_fwd_persist_n: 2 x H/4 workgroups, W_hh slices in
         # LDS, h exchanged through an x16-tiled stash) instead of S launches of ~8 us
-        persist = B <= 64 and self.enc_chain == "persistent" and H % 16 == 0 and self.persist_resident(H, B, 2)
+        # (up to 32 rows: above, the persistent launch runs once per block of 32 rows and the step kernel's four row tiles win)
+        persist = B <= self.enc_persist_max_rows and self.enc_chain == "persistent" and H % 16 == 0 and self.persist_resident(H, B, 2)
         ctx["enc_persist"] = persist
         if persist:
             Bp = (B + 15) // 16 * 16

@@ -687,7 +687,7 @@ def test_encoder_bilstm_persistent_launch_equals_step_launches(B, L):
     got = []
     for mode in ("steps", "persistent"):
         eng, ps = build_engine(d, P, dev)
-        eng.enc_chain = mode
+        eng.enc_chain, eng.enc_persist_max_rows = mode, 64      # (the engine's own limit is 32 rows: above, step launches are faster)
         ctx = {}
         enc = eng.encoder_fwd(ci.to(dev), lens.to(torch.int32).to(dev), True, masks_to_device(masks, dev), ctx)
         torch.cuda.synchronize()
