@@ -111,7 +111,6 @@ class Engine:
         self.chunk_bwd = 64           # frames per chunk of the backward pipeline (r03: 64 beats 80 by 0.2 ms with the BPTT launches at default wave priority)
         self.dec_chain = "persistent" # forward decoder-LSTM chain: "persistent" (one weight-stationary launch per chunk on the side
                                       # stream) or "hosted" (its steps ride in the attention-energies launches)
-        self.share_cu_fwd = None      # (A/B knob) share_cu of the forward's chunk GEMMs; None = self.share_cu
         self.persist_gemm_side = True    # the hoisted pre_dec GEMM of a chunk runs on the side stream too, in front of the chunk's
                                          # persistent launch (70.0 against 71.3 ms per step on the main stream, profiles/r02_ab_fwd_dec_chain.txt)
         self._persist_sync = None
@@ -122,14 +121,14 @@ class Engine:
         self.ramp_chunks = True       # short chunks at the un-overlapped end of the forward / start of the backward pipeline
         self.share_cu = 1             # side-stream GEMMs next to the chains at ONE workgroup per CU: two 73 KB-LDS workgroups
                                       # per CU lock the attention kernels out (84.3 -> 83.2 ms)
-        # ... and recomputes the tanh terms (location convolution on the matrix pipe + stashed query projection + processed memory)
-        # instead of reading the forward's stash: 2.7 GB less memory per step at the bench shape, but +1.2 us per backward frame
-        # against -0.2 us per forward frame (measured: 64.0 vs 63.0 ms per step) - off by default, DESIGN.md section 4.4
-        self.attn_bwd_recompute = False
         self.splitk_small_chunks = True  # forward pipeline: the hoisted decoder-LSTM input GEMM of short chunks runs split-K
-        self.enc_persist_max_rows = 32   # (the launch itself takes up to 64 rows, as two consecutive blocks)
         self.enc_chain = "persistent"    # encoder BiLSTM recurrence: "persistent" (one launch, both directions) | "steps" (S launches)
+        self.enc_persist_max_rows = 32   # (the launch itself takes up to 64 rows, as two consecutive blocks)
         self.attn_bwd_mfma = True     # attention backward: the per-slice kernel's correlations (dU, d_in) on the bf16 matrix pipe (T2AttnSeqBwd.ws_bd)
+        # ... which can also recompute the tanh terms (location convolution on the matrix pipe + stashed query projection + processed
+        # memory) instead of reading the forward's stash: 2.7 GB less memory per step at the bench shape, but +1.2 us per backward
+        # frame against -0.2 us per forward frame (64.0 vs 63.0 ms per step) - off by default, DESIGN.md section 4.4
+        self.attn_bwd_recompute = False
         self.bptt_off_chain = True    # the decoder-LSTM BPTT launches (side stream, a chunk ahead) keep the default wave priority
         self.sync_bn_group = None     # torch.distributed group: BatchNorm statistics over all ranks' shards (Trainer(sync_bn=True))
         self.grad_tail_hook = None    # called on the side stream once the gradients from prenet.0.weight onwards are enqueued
@@ -565,7 +564,7 @@ class Engine:
                 with torch.cuda.stream(side):
                     side.wait_event(ev)
                     if self.persist_gemm_side:
-                        SHARE_CU[0] = self.share_cu if self.share_cu_fwd is None else self.share_cu_fwd
+                        SHARE_CU[0] = self.share_cu
                         pre_dec_gemm(c0, c1)
                         SHARE_CU[0] = 0
                     stp, inc = dec_chunk(c0, c1)
