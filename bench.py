@@ -178,7 +178,6 @@ def main():
         tr.train_step(batch, padded=True)
     sync()
     tr.engine.profile = True
-    seg_acc = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss3, _ = tr.train_step(batch, padded=True)

@@ -765,7 +765,6 @@ class Engine:
         Z = self.buf("Zatt", T + 1, B, ldz)       # Z[s][b] = [dgates_s | dq_{s-1}]
         Z[T, :, :4 * A].zero_()
         dga = Z                                   # dgates_t = Z[t][:, :4A]   (row stride ldz)
-        dq = _ptr(Z, B * ldz + 4 * A)             # dq_t     = Z[t+1][:, 4A:] (row stride ldz)
         dctx_tot = self.buf("dctx_tot", T, B, Ef)
         dpmT = self.buf("dpmT", B, Ad, L, zero=True)
         dv_part = self.buf("dv_part", B, Ad, zero=True)

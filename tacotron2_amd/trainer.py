@@ -86,8 +86,8 @@ class Trainer:
         dist.all_reduce(lt, op=dist.ReduceOp.MAX)
         Lg, Tg = int(lt[0]), int(lt[1])
         out = dict(batch)
-        B, L = batch["chars_idx"].shape
-        T, M = batch["mel_spectrogram"].shape[1:]
+        L = batch["chars_idx"].shape[1]
+        T = batch["mel_spectrogram"].shape[1]
         if L < Lg:
             out["chars_idx"] = torch.nn.functional.pad(batch["chars_idx"], (0, Lg - L))
         if T < Tg:
