@@ -24,6 +24,14 @@ VANILLA = dict(num_chars=39, encoded_dim=512, encoder_kernel_size=5, num_mels=80
                att_dim=128, rnn_hidden_dim=1024, postnet_dim=512, dropout=0.5, speaker_tokens=True, num_speakers=4,
                description_embeddings=False, description_embeddings_dim=0)
 
+# What the driver's 1/2/4/8-GPU curve should show, so that a shortfall is attributable: weak scaling, identical
+# work per rank; per-rank step = the 1-GPU step + the exposed part of the 112.5 MB gradient all-reduce (head bucket 22 MB after the
+# backward, ~0.3 ms at the ring rate of 7 xGMI links; the 90 MB tail runs next to the encoder backward) + RCCL's CU share while the
+# tail overlaps the encoder backward (bounded by the one-call variant: 112.5 MB exposed, ~1.5 ms).
+EXPECTED_SCALING = dict(ms_per_step_n1=62.5, exposed_allreduce_ms=dict(two_buckets=0.3, one_call=1.5),
+                        speedup=dict(n2=1.98, n4=3.96, n8=7.9), floor_speedup_n8_one_call=7.8,
+                        note="value(N) / value(1); below 7.5 at N=8 means the all-reduce is not overlapping or a rank waits for another")
+
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 
@@ -126,20 +134,24 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0 (needs --backend gloo)")
     ap.add_argument("--sync-bn", action="store_true", help="BatchNorm statistics over all ranks (training.sync_batchnorm)")
     ap.add_argument("--one-allreduce", action="store_true", help="a single gradient all-reduce after the backward instead of two buckets")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="run the data-parallel step (process group, both gradient all-reduce buckets, Work.wait, [sync-BN reduces]) "
+                         "also at --gpus 1: every RCCL call of the step on a single-GPU box; the sums are identities")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
-    torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1 or args.force_dp:        # (the process group first, before any GPU call of this process)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
+    torch.cuda.set_device(local)
 
     from tacotron2_amd.build import build
     if rank == 0:
@@ -156,7 +168,7 @@ def main():
     ps = ParamStore(VANILLA, dev)
     init_parameters(ps, seed=0)           # identical replicas on every rank
     tr = Trainer(ps, lr=1e-3, weight_decay=1e-6, scheduler_milestones=(50000, 75000), sync_bn=args.sync_bn,
-                 overlap_allreduce=not args.one_allreduce)
+                 overlap_allreduce=not args.one_allreduce, force_collectives=args.force_dp)
     cpu_batch = ljspeech_batch(args.batch, seed=1234 + rank, num_speakers=4,
                                fixed_shape=(160, 860) if args.fixed_shape else None)
     batch = {k: v.to(dev) for k, v in cpu_batch.items()}
@@ -168,7 +180,7 @@ def main():
         dist.all_reduce(frames)
 
     def sync():
-        if world > 1:
+        if tr.dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -198,12 +210,12 @@ def main():
     if rank == 0 and world == 1 and args.matmul_precision == "highest" and not args.no_high:
         set_float32_matmul_precision("high")
         for _ in range(2):
-            tr.train_step(batch)
+            tr.train_step(batch, padded=True)
         torch.cuda.synchronize()
         th0 = time.perf_counter()
         nh = min(args.steps, 5)
         for _ in range(nh):
-            tr.train_step(batch)
+            tr.train_step(batch, padded=True)
         torch.cuda.synchronize()
         dth = time.perf_counter() - th0
         set_float32_matmul_precision("highest")
@@ -268,8 +280,12 @@ def main():
                                global_batch=B * world, L=L, T=T, valid_frames_per_step=float(frames[0]),
                                padded_frames_per_step=float(frames[1]), parallelism=f"dp{world}",
                                sync_batchnorm=bool(tr.sync_bn),
-                               allreduce=("none" if world == 1 else "2 buckets, tail overlapped with the encoder backward"
-                                          if tr.overlap_allreduce else "1 call after the backward")),
+                               allreduce=("none" if not tr.dp else "2 buckets, tail overlapped with the encoder backward"
+                                          if tr.overlap_allreduce else "1 call after the backward"),
+                               shape_negotiation="none inside the timed region: one fixed batch, padded to the global shape before "
+                                                 "it (main.py train agrees the shape of step k+1 on the host, in the loader thread, "
+                                                 "over its own gloo group while step k runs: nothing on the step path either)",
+                               expected_scaling=EXPECTED_SCALING),
                    padded_frames_per_s=float(frames[1]) * args.steps / dt,
                    loss=[float(x) for x in loss3.cpu()],
                    roofline=dict(bound="hbm", kernel="teacher-forced decoder frame loop, forward (pre_att GEMM + attention "
@@ -291,7 +307,7 @@ def main():
             print("[bench] GPU timing done; timing the CPU oracle baseline (bounded sample)...", file=sys.stderr, flush=True)
             out["cpu_baseline"] = cpu_baseline(dims, cpu_batch, t_cap=200, b_cap=min(32, args.batch))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if tr.dp:
         dist.barrier()                       # every rank leaves together
         dist.destroy_process_group()
 

@@ -104,6 +104,14 @@ def lib():
         fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = C.c_char_p if "char" in ret else (C.c_int64 if ret == "int64_t" else C.c_int)
         fn.argtypes = [C.c_void_p if p else _SCALARS[b] for b, p in alist]
+    # ABI check: the struct layouts this binding mirrors from the header must be the ones the library was compiled with - a
+    # stale build (or another library selected through T2_LIB_PATH) would otherwise read garbage operand blocks
+    L.t2_sizeof.argtypes = [C.c_char_p]
+    for name, st in S.items():
+        got = L.t2_sizeof(name.encode())
+        if got != C.sizeof(st):
+            raise T2Error(f"{LIB_PATH}: struct {name} is {got} bytes in the library, {C.sizeof(st)} in include/tacotron2_amd.h - "
+                          "rebuild it (python -m tacotron2_amd.build [--stamps])")
     _lib = L
     return L
 

@@ -15,11 +15,13 @@ SOURCES = ["t2_error.cpp", "t2_gemm.hip", "t2_lstm.hip", "t2_attention.hip", "t2
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
+def _stale(lib: str = LIB) -> bool:
+    """True when `lib` is older than any kernel source, the ABI header or this recipe (its flags)."""
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "tacotron2_amd.h")]
+    t = os.path.getmtime(lib)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "tacotron2_amd.h"),
+                                                               os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -33,7 +35,7 @@ def build_stamps(verbose: bool = True) -> str:
     T2_LIB_PATH (tacotron2_amd/_lib.py)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    if os.path.exists(STAMPS_LIB) and all(os.path.getmtime(os.path.join(CSRC, f)) < os.path.getmtime(STAMPS_LIB) for f in os.listdir(CSRC)):
+    if not _stale(STAMPS_LIB):           # same dependency list as the product library: sources, ABI header, this recipe
         return STAMPS_LIB
     objdir = os.path.join(HERE, "..", "build", "obj_stamps")
     os.makedirs(objdir, exist_ok=True)
@@ -67,7 +69,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         objs.append(o)
         hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".hpp")]
         if not force and os.path.exists(o) and os.path.getmtime(o) > max(
-                [os.path.getmtime(s), os.path.getmtime(os.path.join(HERE, "..", "include", "tacotron2_amd.h"))] +
+                [os.path.getmtime(s), os.path.getmtime(os.path.join(HERE, "..", "include", "tacotron2_amd.h")),
+                 os.path.getmtime(os.path.abspath(__file__))] +
                 [os.path.getmtime(h) for h in hdrs]):
             continue
         cmd = [hipcc] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", s, "-o", o]

@@ -146,9 +146,12 @@ def restore_trainer(ck: dict, trainer) -> bool:
         trainer.milestones = sorted(int(m) for m, c in dict(sch["milestones"]).items() for _ in range(int(c)))
         trainer.base_lr = float(sch["base_lrs"][0])
     elif opt and opt.get("param_groups"):
-        # no scheduler in the checkpoint (scheduler_milestones = []): Lightning's optimizer.load_state_dict still restores
-        # param_groups[0]["lr"], which replaces the freshly configured lr (and the fine-tune's lr / 10) in the reference
+        # no scheduler in the checkpoint (it was written with scheduler_milestones = []): Lightning's optimizer.load_state_dict
+        # still restores param_groups[0]["lr"], which replaces the freshly configured lr (and the fine-tune's lr / 10) in the
+        # reference - and nothing else: restore_lr_schedulers has no state to load, so a MultiStepLR built from the CURRENT config
+        # (model/tts_model.py:84-89) stays alive with its own milestones, counted from last_epoch = 0 at the resume point.  The
+        # configured milestones are therefore kept, shifted by the restored global_step.
         pg = opt["param_groups"][0]
         trainer.base_lr = float(pg.get("initial_lr", pg["lr"]))
-        trainer.milestones = []
+        trainer.milestones = sorted(int(m) + trainer.global_step for m in trainer.milestones)
     return found

@@ -661,8 +661,13 @@ extern "C" int t2_lstm_persist_resident_n(int H, int K, int B, int n) {
     (void)hipGetLastError();
     T2_REQUIRE(H >= 4 && H % 4 == 0 && K >= 16 && K % 16 == 0 && B >= 1 && n >= 1, "t2_lstm_persist_resident: bad arguments");
     const size_t lds = persist_lds_bytes(K);
-    T2_REQUIRE(t2_allow_lds(lstm_seq_persist_fwd_kernel<1>, lds) && t2_allow_lds(lstm_seq_persist_fwd_kernel<2>, lds),
-               "t2_lstm_persist_resident: weight slice does not fit the LDS");
+    // "cannot run as ONE co-resident launch" is an answer, not an error: the caller falls back to step launches (T2_ERR_RESIDENCY)
+    if (n * (H / 4) > 256 || n > 2 ||
+        !(t2_allow_lds(lstm_seq_persist_fwd_kernel<1>, lds) && t2_allow_lds(lstm_seq_persist_fwd_kernel<2>, lds))) {
+        t2_set_error("t2_lstm_persist_resident: more than 256 workgroups, more than two cells, or a weight slice that does not fit "
+                     "the LDS; use t2_lstm_seq_fwd", __FILE__, __LINE__);
+        return T2_ERR_RESIDENCY;
+    }
     return persist_resident(n * (H / 4), B <= 16 ? 1 : 2, lds);
 }
 extern "C" int t2_lstm_persist_resident(int H, int K, int B) { return t2_lstm_persist_resident_n(H, K, B, 1); }

@@ -202,28 +202,59 @@ class DevicePrefetcher:
     host->device copies of batch k+1 run while the training step of batch k occupies the main stream (the reference gets
     the same overlap from DataLoader worker processes + pin_memory, run/train.py:140-158).  ctypes calls and torch copies
     release the GIL.  The consumer's stream waits for the batch's event and the tensors are re-registered with it
-    (`record_stream`), so the caching allocator does not hand their memory back to the copy stream while they are in use."""
+    (`record_stream`), so the caching allocator does not hand their memory back to the copy stream while they are in use.
+
+    Data-parallel training: `negotiate(host_batch) -> host_batch` runs in the loader thread on every batch BEFORE it goes to the
+    device (Trainer.negotiate_collated: one tiny MAX all-reduce of the padded lengths over the trainer's host-side group, then the
+    padding) - the shape of step k+1 is agreed while step k runs and the training loop never waits for a collective result.
+    Every rank must then produce exactly the batches it consumes, in the same count: `limit` = the number of batches the consumer
+    will take (the thread stops there, so no rank is left inside a collective its peers never enter), `cycle` = start the loader
+    again when it is exhausted (a new epoch: shuffling samplers draw their next permutation) instead of ending the iteration -
+    ranks whose shards differ by an utterance have epochs of different length, the k-th batch of every rank still meets the k-th
+    batch of the others.  `device` may be the CPU (host-logic tests): no stream, no events."""
 
     _END = object()
 
-    def __init__(self, loader, to_device, device, depth: int = 2):
+    def __init__(self, loader, to_device, device, depth: int = 2, negotiate=None, limit: Optional[int] = None, cycle: bool = False):
         self.loader, self.to_device, self.device, self.depth = loader, to_device, torch.device(device), max(1, depth)
+        self.negotiate, self.limit, self.cycle = negotiate, limit, bool(cycle)
         self.stream = None
+        self.produced = 0          # batches handed to the queue so far (all iterations)
 
     def __len__(self):
         return len(self.loader)
 
+    def _batches(self, stop):
+        while True:
+            n = 0
+            for b in self.loader:
+                n += 1
+                yield b
+            if not self.cycle or n == 0 or stop.is_set():
+                return
+
     def _work(self, q, stop):
+        import contextlib
         try:
-            torch.cuda.set_device(self.device)
-            with torch.cuda.stream(self.stream):
-                for b in self.loader:
-                    if stop.is_set():
-                        return
-                    out = self.to_device(b, self.device)
-                    ev = torch.cuda.Event()
-                    ev.record(self.stream)
-                    q.put((out, ev))
+            cuda = self.device.type == "cuda"
+            if cuda:
+                torch.cuda.set_device(self.device)
+            with (torch.cuda.stream(self.stream) if cuda else contextlib.nullcontext()):
+                if self.limit is None or self.produced < self.limit:
+                    for b in self._batches(stop):
+                        if stop.is_set():
+                            return
+                        if self.negotiate is not None:
+                            b = self.negotiate(b)
+                        out = self.to_device(b, self.device)
+                        ev = None
+                        if cuda:
+                            ev = torch.cuda.Event()
+                            ev.record(self.stream)
+                        q.put((out, ev))
+                        self.produced += 1
+                        if self.limit is not None and self.produced >= self.limit:
+                            break
             q.put((self._END, None))
         except BaseException as e:      # surfaces in the consumer
             q.put((e, None))
@@ -231,7 +262,8 @@ class DevicePrefetcher:
     def __iter__(self):
         import queue
         import threading
-        if self.stream is None:
+        cuda = self.device.type == "cuda"
+        if self.stream is None and cuda:
             self.stream = torch.cuda.Stream(device=self.device)
         q, stop = queue.Queue(maxsize=self.depth), threading.Event()
         th = threading.Thread(target=self._work, args=(q, stop), daemon=True)
@@ -243,11 +275,12 @@ class DevicePrefetcher:
                     return
                 if isinstance(out, BaseException):
                     raise out
-                cur = torch.cuda.current_stream(self.device)
-                cur.wait_event(ev)
-                for v in (out.values() if isinstance(out, dict) else out):
-                    if torch.is_tensor(v) and v.is_cuda:
-                        v.record_stream(cur)
+                if cuda:
+                    cur = torch.cuda.current_stream(self.device)
+                    cur.wait_event(ev)
+                    for v in (out.values() if isinstance(out, dict) else out):
+                        if torch.is_tensor(v) and v.is_cuda:
+                            v.record_stream(cur)
                 yield out
         finally:
             stop.set()

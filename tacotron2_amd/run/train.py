@@ -37,10 +37,21 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
     import pandas as pd
     from ..datasets.tts_dataset import DevicePrefetcher, TTSDataLoader, TTSDataset
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
-    if world > 1 and not dist.is_initialized():
-        device = int(os.environ.get("LOCAL_RANK", device))
+    force_dp = bool(training_config.get("force_collectives", False)) or os.environ.get("T2_FORCE_DP") == "1"
+    own_group = (world > 1 or force_dp) and not dist.is_initialized()
+    if own_group:
+        # T2_DIST_BACKEND=gloo + T2_SHARE_GPU=1: rehearsal of N ranks on ONE card (RCCL needs a GPU per rank); T2_FORCE_DP=1 /
+        # training.force_collectives: the collectives of the step also at world size 1 (RCCL on a single-GPU box)
+        backend = os.environ.get("T2_DIST_BACKEND", "nccl")
+        if os.environ.get("T2_SHARE_GPU") != "1":
+            device = int(os.environ.get("LOCAL_RANK", device))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        if backend == "nccl":      # (before any GPU call of this process: the communicator binds to the device eagerly)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
         torch.cuda.set_device(device)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", device))
     dev = torch.device("cuda", device)
     torch.cuda.set_device(dev)
     if results_dir is None:
@@ -65,7 +76,8 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
     tr = Trainer(model.tacotron2.store, lr=kw["lr"], weight_decay=kw["weight_decay"],
                  scheduler_milestones=kw["scheduler_milestones"], max_norm=1.0,
                  sync_bn=bool(training_config.get("sync_batchnorm", False)),
-                 overlap_allreduce=bool(training_config.get("overlap_allreduce", True)))
+                 overlap_allreduce=bool(training_config.get("overlap_allreduce", True)),
+                 force_collectives=force_dp)
     if resume_ckpt:
         # trainer.fit(ckpt_path=...) (run/train.py:245): weights, global_step, Adam moments and the scheduler state all come
         # back, for plain resumes and for --finetune alike (the fine-tune then runs exactly `finetune_steps` more steps)
@@ -77,6 +89,9 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
     if finetune:   # run/train.py:229-233: encoder and speaker embedding are frozen
         tr.frozen = {n for n in tr.ps.P if n.startswith("encoder.") or n.startswith("speaker_embedding.")}
 
+    # Every batch reaches Trainer.train_step already padded to the step's GLOBAL (L, T): the shape is agreed on the host, over the
+    # trainer's host-side group, before the batch goes to the device (real data: in the loader thread, a step ahead) - the training
+    # loop itself issues no collective whose result the host reads, and reads no device value between two loss printouts.
     if synthetic:
         from ..synthetic import ljspeech_batch
         def batches():
@@ -85,6 +100,7 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
                 b = ljspeech_batch(training_config["batch_size"], seed=1234 + i * world + rank,
                                    num_speakers=kw["num_speakers"] if kw["speaker_tokens"] else 0)
                 i += 1
+                b = tr.pad_to(b, *tr.negotiate_shape(b["chars_idx"].shape[1], b["mel_spectrogram"].shape[1]))
                 yield {k: v.to(dev) for k, v in b.items()}
     else:
         df = pd.read_csv(dataset_config["train"], delimiter="|", quoting=csv.QUOTE_NONE, engine="c")
@@ -105,11 +121,11 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
         loader = TTSDataLoader(ds, batch_size=training_config["batch_size"], shuffle=True, drop_last=True,
                                bucket_window=bucket_window, seed=0 if bucket_window else rank, rank=rank, world=world)
         # items and host->device copies of the next batches are prepared by a background thread on its own stream
-        prefetch = DevicePrefetcher(loader, _to_dev, dev, depth=int(training_config.get("prefetch_batches", 2)))
+        prefetch = DevicePrefetcher(loader, _to_dev, dev, depth=int(training_config.get("prefetch_batches", 2)),
+                                    negotiate=tr.negotiate_collated if tr.dp else None, limit=max(0, max_steps - start_step),
+                                    cycle=True)
         def batches():
-            while True:
-                for b in prefetch:
-                    yield b
+            yield from prefetch
 
     val_loader = None
     if not synthetic and dataset_config.get("val") and os.path.exists(dataset_config["val"]):
@@ -164,9 +180,14 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
     it = batches()
     steps_done = 0
     log_every = int(training_config["args"].get("log_every_n_steps", 50))
+    sync_debug = os.environ.get("T2_SYNC_DEBUG") == "1"      # tests: prove that a training step never blocks the host
     for step in range(start_step, max_steps):
         batch = next(it)
-        loss3, _ = tr.train_step(batch)
+        if sync_debug:
+            torch.cuda.set_sync_debug_mode("error")     # (diagnostic: any host synchronisation inside the step raises)
+        loss3, _ = tr.train_step(batch, padded=True)
+        if sync_debug:
+            torch.cuda.set_sync_debug_mode("default")
         steps_done += 1
         frames += batch["mel_spectrogram_len"].sum()
         if step % log_every == 0 or step == max_steps - 1:
@@ -192,7 +213,9 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
         path = os.path.join(results_dir, "finetuned.ckpt" if finetune else "final.ckpt")
         save(path, max_steps)
         print(f"saved {path} ({steps_done} optimiser steps this run, global_step {tr.global_step})")
-    if world > 1:
+    if tr.dp:
         dist.barrier()
+        if own_group:
+            dist.destroy_process_group()
     model.steps_done = steps_done
     return model

@@ -23,7 +23,8 @@ from .params import ParamStore
 
 class Trainer:
     def __init__(self, ps: ParamStore, lr: float, weight_decay: float, scheduler_milestones: Sequence[int] = (),
-                 max_norm: float = 1.0, seed: int = 1234, sync_bn: bool = False, overlap_allreduce: bool = True):
+                 max_norm: float = 1.0, seed: int = 1234, sync_bn: bool = False, overlap_allreduce: bool = True,
+                 force_collectives: bool = False):
         self.ps = ps
         self.engine = Engine(ps)
         self.base_lr, self.weight_decay, self.max_norm = lr, weight_decay, max_norm
@@ -32,11 +33,15 @@ class Trainer:
         self.seed = seed
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
+        # dp: the step issues its collectives.  force_collectives runs them at world size 1 too (an initialised process group of ONE
+        # rank): every RCCL call of the step - both gradient buckets, Work.wait(), the BatchNorm statistics - on the hardware a
+        # builder with one GPU has (tests/test_gpu_rccl.py, bench.py --force-dp); the sums are identities there.
+        self.dp = self.world > 1 or (bool(force_collectives) and dist.is_available() and dist.is_initialized())
         self.frozen: set = set()   # parameter names excluded from updates (fine-tuning, run/train.py:229-233)
         # sync_bn: BatchNorm batch statistics (8 layers, forward and backward) over ALL ranks' shards - 16 all-reduces of
         # 2C + 2 doubles per step - so that N x b utterances give the single-device result on the N*b batch (the reference's
         # BN layers see the whole batch, model/encoder.py:41, model/postnet.py:16,30,44).  Off: per-shard statistics.
-        self.sync_bn = bool(sync_bn) and self.world > 1
+        self.sync_bn = bool(sync_bn) and self.dp
         if self.sync_bn:
             self.engine.sync_bn_group = dist.group.WORLD
         # overlap_allreduce: the gradient buffer is reduced as two buckets.  The tail [prenet.0.weight, end) - 80 % of the bytes:
@@ -44,11 +49,26 @@ class Trainer:
         # GEMMs are; its all-reduce is started there (behind the engine's side stream) and runs next to the encoder backward
         # (BiLSTM recurrence + convolutions, ~2.6 ms of latency-bound launches).  The head (encoder, speaker table, description
         # linear: 22 MB) follows when the backward ends.  Same sums, same result as one all-reduce.
-        self.overlap_allreduce = bool(overlap_allreduce) and self.world > 1
+        # Not with sync_bn: RCCL runs the collectives of one communicator in issue order on its own stream, so the eight small
+        # BatchNorm reduces of the encoder backward would queue behind the 90 MB tail and stall the main stream - the overlap
+        # would turn into a wait.  (The overlapped path has run over gloo at 2 and 4 ranks and over RCCL at world size 1, where the
+        # stream ordering is what is exercised; no multi-GPU RCCL run exists - DESIGN.md section 7.)
+        self.overlap_allreduce = bool(overlap_allreduce) and self.dp and not self.sync_bn
         self._tail_start = ps.offsets["prenet.0.weight"]
         self._tail_work = None
         if self.overlap_allreduce:
             self.engine.grad_tail_hook = self._start_tail_allreduce
+        # Shape negotiation travels over its OWN host-side (gloo) group: the padded lengths of a batch are host integers, so no
+        # device tensor is read and the data-path communicator sees nothing but gradient / statistics reduces - which also lets a
+        # loader thread negotiate batch k+1 while step k runs (DevicePrefetcher(negotiate=...)); collectives of one communicator
+        # must be issued in one order on every rank, two threads on the same group could not promise that.
+        self._shape_group = None
+        if self.dp:
+            try:
+                self._shape_group = dist.new_group(backend="gloo")
+            except Exception as e:      # (no host transport: fall back to the default group, device tensors on an accelerator backend)
+                import warnings
+                warnings.warn(f"Trainer: no gloo group for the shape negotiation ({e}); using the default process group")
 
     def _start_tail_allreduce(self):
         # (called by Engine.backward_tf with its side stream current: the collective is ordered behind that stream's work)
@@ -77,14 +97,24 @@ class Trainer:
         """MultiStepLR(gamma=0.1), stepped once per optimiser step (model/tts_model.py:83-88)."""
         return self.base_lr * (0.1 ** sum(1 for m in self.milestones if step >= m))
 
-    def global_pad(self, batch: dict) -> dict:
-        """Pad this rank's shard to the global (L, T) maxima (no-op on one rank)."""
-        if self.world == 1:
-            return batch
-        dev = batch["chars_idx"].device
-        lt = torch.tensor([batch["chars_idx"].shape[1], batch["mel_spectrogram"].shape[1]], device=dev)
-        dist.all_reduce(lt, op=dist.ReduceOp.MAX)
-        Lg, Tg = int(lt[0]), int(lt[1])
+    def negotiate_shape(self, L: int, T: int):
+        """Global (max over ranks) padded text and frame lengths of this step's shards: ONE tiny MAX all-reduce of two host integers
+        on the host-side group.  Every rank must call it once per step, in step order (from one thread)."""
+        if not self.dp:
+            return int(L), int(T)
+        if self._shape_group is not None:
+            lt = torch.tensor([int(L), int(T)], dtype=torch.int64)
+            dist.all_reduce(lt, op=dist.ReduceOp.MAX, group=self._shape_group)
+        else:
+            lt = torch.tensor([int(L), int(T)], dtype=torch.int64, device=self.ps.device)
+            dist.all_reduce(lt, op=dist.ReduceOp.MAX)
+            lt = lt.cpu()
+        return int(lt[0]), int(lt[1])
+
+    @staticmethod
+    def pad_to(batch: dict, Lg: int, Tg: int) -> dict:
+        """Zero-pad `chars_idx` (B, L) and `mel_spectrogram` / `gate` (B, T, .) of a batch dict to (Lg, Tg); host or device
+        tensors (the padding the collate function applies, datasets/tts_dataloader.py:25-33, extended to the global shape)."""
         out = dict(batch)
         L = batch["chars_idx"].shape[1]
         T = batch["mel_spectrogram"].shape[1]
@@ -94,6 +124,23 @@ class Trainer:
             out["mel_spectrogram"] = torch.nn.functional.pad(batch["mel_spectrogram"], (0, 0, 0, Tg - T))
             out["gate"] = torch.nn.functional.pad(batch["gate"], (0, 0, 0, Tg - T))
         return out
+
+    def global_pad(self, batch: dict) -> dict:
+        """Pad this rank's shard to the global (L, T) maxima (no-op on one rank).  Host integers over the host-side group: no
+        device tensor is read."""
+        if not self.dp:
+            return batch
+        Lg, Tg = self.negotiate_shape(batch["chars_idx"].shape[1], batch["mel_spectrogram"].shape[1])
+        return self.pad_to(batch, Lg, Tg)
+
+    def negotiate_collated(self, collated):
+        """`negotiate` hook of DevicePrefetcher: a collated HOST batch (data, metadata, extra) of the loader, padded to the step's
+        global shape in the loader thread - one step ahead of the training loop, which then calls train_step(padded=True)."""
+        data, meta, extra = collated
+        if not self.dp:
+            return collated
+        Lg, Tg = self.negotiate_shape(data["chars_idx"].shape[1], data["mel_spectrogram"].shape[1])
+        return self.pad_to(data, Lg, Tg), meta, extra
 
     def train_step(self, batch: dict, masks: Optional[dict] = None, padded: bool = False):
         """One optimisation step on this rank's shard.  Returns the device tensor loss3 = (gate, mel, post) means.
@@ -115,7 +162,7 @@ class Trainer:
                                    controls=batch.get("controls"))
         ps.grad.zero_()
         loss3 = eng.loss_and_grads(outs, ctx, mel, batch["gate"])
-        if self.world > 1:
+        if self.dp:
             if self._tail_work is not None:       # two buckets: the tail has been in flight since the frame loop ended
                 dist.all_reduce(ps.grad[:self._tail_start])
                 self._tail_work.wait()            # (the current stream waits for the collective; no host block on RCCL)

@@ -134,7 +134,9 @@ def test_written_checkpoint_loads_into_torch_optimizer_and_round_trips(tmp_path)
 def test_checkpoint_without_scheduler_restores_the_optimizer_lr(tmp_path):
     """scheduler_milestones = []: no lr_schedulers entry is written (model/tts_model.py:83-90), and on resume Lightning's
     optimizer.load_state_dict brings back param_groups[0]["lr"] - it replaces the freshly configured lr, including the
-    fine-tune's lr / 10 (run/train.py:110,245).  Same here."""
+    fine-tune's lr / 10 (run/train.py:110,245).  Same here.  Nothing else of the scheduler is restored (there is no state to load),
+    so the MultiStepLR the CURRENT config builds stays alive and counts its milestones from the resume point
+    (model/tts_model.py:84-89, last_epoch = 0): milestone 5 configured, resumed at global_step 3 -> decay from step 8 on."""
     from tacotron2_amd.checkpoint import lightning_checkpoint, restore_trainer, save_atomic
     from tacotron2_amd.model.tts_model import TTSModel
     from tacotron2_amd.trainer import Trainer
@@ -148,7 +150,10 @@ def test_checkpoint_without_scheduler_restores_the_optimizer_lr(tmp_path):
     assert ck["lr_schedulers"] == [] and ck["optimizer_states"][0]["param_groups"][0]["lr"] == pytest.approx(2e-3)
     tr2 = Trainer(model.tacotron2.store, lr=2e-4, weight_decay=1e-6, scheduler_milestones=[5])     # fine-tune style: lr / 10
     assert restore_trainer(ck, tr2)
-    assert tr2.base_lr == pytest.approx(2e-3) and tr2.milestones == [] and tr2.lr_at(100) == pytest.approx(2e-3)
+    assert tr2.global_step == 3 and tr2.base_lr == pytest.approx(2e-3) and tr2.milestones == [8]
+    assert tr2.lr_at(7) == pytest.approx(2e-3) and tr2.lr_at(8) == pytest.approx(2e-4) and tr2.lr_at(100) == pytest.approx(2e-4)
+    tr3 = Trainer(model.tacotron2.store, lr=2e-4, weight_decay=1e-6, scheduler_milestones=[])      # no scheduler configured either
+    assert restore_trainer(ck, tr3) and tr3.milestones == [] and tr3.lr_at(100) == pytest.approx(2e-3)
 
 
 def test_trainable_ranges_exclude_frozen_tensors():

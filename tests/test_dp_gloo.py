@@ -96,3 +96,74 @@ def test_dp2_flat_allreduce_equals_single_process():
         got = out["grad"][o:o + gr.numel()].view(out["shapes"][k])
         scale = max(float(gr.abs().max()), 1e-4)
         assert float((got - gr).abs().max()) / scale < 2e-4, k
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Shape negotiation in the loader thread (Trainer.negotiate_collated as DevicePrefetcher's `negotiate` hook)
+# ---------------------------------------------------------------------------------------------------------------------------
+class _FakeLoader:
+    """`n` collated host batches per epoch with per-rank, per-batch lengths (data, metadata, extra) - the loader's layout."""
+
+    def __init__(self, rank, n):
+        self.rank, self.n, self.epoch = rank, n, 0
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        e = self.epoch
+        self.epoch += 1
+        for i in range(self.n):
+            g = torch.Generator().manual_seed(1000 * self.rank + 10 * e + i)
+            L = int(torch.randint(5, 20, (1,), generator=g)); T = int(torch.randint(8, 40, (1,), generator=g))
+            data = dict(chars_idx=torch.ones(2, L, dtype=torch.int64), mel_spectrogram=torch.full((2, T, 4), -1.0),
+                        gate=torch.ones(2, T, 1))
+            meta = dict(chars_idx_len=torch.tensor([L, L - 1]), mel_spectrogram_len=torch.tensor([T, T - 2], dtype=torch.int32))
+            yield data, meta, dict(own=(L, T))
+
+
+def _prefetch_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from tacotron2_amd.datasets.tts_dataset import DevicePrefetcher
+    from tacotron2_amd.params import ParamStore
+    from tacotron2_amd.trainer import Trainer
+    d = R.default_dims(**SMALL, dropout=0.0)
+    ps = ParamStore(d, "cpu")
+    tr = Trainer(ps, lr=1e-3, weight_decay=1e-6)
+    assert tr.dp and tr._shape_group is not None
+    steps = 9                                                   # rank 0: epochs of 3 batches, rank 1: of 4 - nine steps cross both
+    pf = DevicePrefetcher(_FakeLoader(rank, 3 + rank), lambda b, dev: b, "cpu", depth=2, negotiate=tr.negotiate_collated,
+                          limit=steps, cycle=True)
+    seen = []
+    for data, meta, extra in pf:
+        L, T = data["chars_idx"].shape[1], data["mel_spectrogram"].shape[1]
+        assert data["gate"].shape[1] == T
+        own = torch.tensor(extra["own"])
+        both = [torch.zeros_like(own) for _ in range(world)]
+        dist.all_gather(both, own)                              # (main thread, default group: the data-path side)
+        want = torch.stack(both).max(0).values
+        assert (L, T) == (int(want[0]), int(want[1])), ((L, T), want)
+        # the padding is zeros behind the rank's own data
+        assert float(data["mel_spectrogram"][:, int(own[1]):].abs().sum()) == 0.0 and int(data["chars_idx"][:, int(own[0]):].sum()) == 0
+        seen.append((L, T))
+    assert len(seen) == steps and pf.produced == steps
+    assert list(pf) == []                                       # the limit is spent: no further collective is entered
+    out[rank] = seen
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp2_loader_thread_negotiates_the_global_shape_one_step_ahead():
+    """Real data-parallel training takes its batches through DevicePrefetcher(negotiate=Trainer.negotiate_collated, limit, cycle):
+    the global (L, T) of step k+1 is agreed by the loader threads over the trainer's host-side gloo group while step k runs, and
+    train_step(padded=True) never sees a collective result.  Two ranks with epochs of different length (3 and 4 batches), nine
+    steps: the k-th batches of both ranks always carry the same, maximal shape, zero padding behind the rank's own data, both
+    threads end after exactly `limit` negotiations."""
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_prefetch_worker, args=(world, port, out), nprocs=world, join=True)
+        out = dict(out)
+    assert out[0] == out[1] and len(out[0]) == 9

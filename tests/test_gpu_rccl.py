@@ -1,0 +1,40 @@
+"""The RCCL (torch.distributed backend "nccl") code path of the data-parallel step, on the one GPU a builder has: a process
+group of ONE rank (tests/rccl_world1_check.py).  Every other DP test of this tree runs over gloo; here the
+async tail-bucket all-reduce under the side stream, the head all-reduce, Work.wait(), the synchronised BatchNorm reduces, the
+barrier and destroy_process_group run on RCCL itself, and at world size 1 every reduce must be a bitwise identity."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, port):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    return subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_world1_check.py")] + extra, cwd=ROOT,
+                          capture_output=True, text=True, timeout=900, env=env)
+
+
+@pytest.mark.parametrize("extra", [[], ["--one-allreduce"], ["--sync-bn"]], ids=["two_buckets", "one_call", "sync_bn"])
+def test_dp_step_over_rccl_world1_is_the_single_process_step(extra):
+    r = _run(extra, 29641 + len(extra) + (7 if "--sync-bn" in extra else 0))
+    assert r.returncode == 0 and "RCCL_CHECK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    print(r.stdout.strip().splitlines()[-1])
+
+
+def test_bench_force_dp_runs_the_rccl_path_at_one_gpu():
+    """`bench.py --gpus 1 --force-dp`: the driver's multi-GPU command line minus the launcher - process group over RCCL, both
+    gradient buckets, the `allreduce` segment in the breakdown - so that the 8-GPU run is not the first time RCCL sees this code."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29655")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dp", "--steps", "2", "--warmup", "1",
+                        "--batch", "4", "--no-cpu-baseline", "--no-decode", "--no-high"], cwd=ROOT, capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["allreduce"].startswith("2 buckets") and "allreduce" in d["segments_ms"]
+    assert d["value"] > 0 and all(np.isfinite(d["loss"])) and d["config"]["expected_scaling"]["speedup"]["n8"] > 7
