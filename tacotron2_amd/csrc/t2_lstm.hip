@@ -664,8 +664,8 @@ extern "C" int t2_lstm_persist_resident_n(int H, int K, int B, int n) {
     // "cannot run as ONE co-resident launch" is an answer, not an error: the caller falls back to step launches (T2_ERR_RESIDENCY)
     if (n * (H / 4) > 256 || n > 2 ||
         !(t2_allow_lds(lstm_seq_persist_fwd_kernel<1>, lds) && t2_allow_lds(lstm_seq_persist_fwd_kernel<2>, lds))) {
-        t2_set_error("t2_lstm_persist_resident: more than 256 workgroups, more than two cells, or a weight slice that does not fit "
-                     "the LDS; use t2_lstm_seq_fwd", __FILE__, __LINE__);
+        t2_set_error("t2_lstm_persist_resident: cannot be ONE co-resident launch (more than 256 workgroups, more than two cells, or a "
+                     "weight slice that does not fit the LDS); use t2_lstm_seq_fwd", __FILE__, __LINE__);
         return T2_ERR_RESIDENCY;
     }
     return persist_resident(n * (H / 4), B <= 16 ? 1 : 2, lds);

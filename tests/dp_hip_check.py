@@ -37,7 +37,17 @@ def main():
     ps = ParamStore(d, dev); ps.load_state_dict(P)
     overlap = "--one-allreduce" not in sys.argv
     tr = Trainer(ps, lr=1e-3, weight_decay=1e-6, max_norm=1.0, sync_bn=sync_bn, overlap_allreduce=overlap)
-    assert tr.world == world and tr.sync_bn == sync_bn and tr.overlap_allreduce == overlap
+    # (with synchronised BatchNorm the gradient goes as one call: the small statistics reduces of the encoder backward would queue
+    #  behind an overlapped tail bucket on the communicator's stream - Trainer.__init__)
+    assert tr.world == world and tr.sync_bn == sync_bn and tr.overlap_allreduce == (overlap and not sync_bn)
+    tail0 = ps.offsets["prenet.0.weight"]
+    hook_tail = []
+    if tr.overlap_allreduce:       # what the tail bucket held when its all-reduce was started (side stream, inside the hook)
+        inner = tr.engine.grad_tail_hook
+        def hook():
+            hook_tail.append(ps.grad[tail0:].clone())
+            inner()
+        tr.engine.grad_tail_hook = hook
     per = Bt // world
     sl = slice(rank * per, (rank + 1) * per)
     Lr, Tr = int(lens[sl].max()), int(tl[sl].max())                 # the shard arrives padded to ITS OWN maxima
@@ -52,6 +62,14 @@ def main():
     torch.cuda.synchronize()
     lsum = loss3.sum().reshape(1).clone()
     dist.all_reduce(lsum)                                            # mean of the per-rank loss means
+    tail_ok = True
+    if tr.overlap_allreduce:
+        # the tail bucket is [prenet.0.weight, end) and nothing writes to it after the hook: its content after the step is exactly
+        # the sum over ranks of what it held when the hook ran
+        assert len(hook_tail) == 1 and hook_tail[0].numel() == ps.numel - tail0
+        want = hook_tail[0].clone()
+        dist.all_reduce(want)
+        tail_ok = bool(torch.equal(want, ps.grad[tail0:]))
     gdp = (ps.grad / world).clone()                                  # train_step leaves the all-reduced SUM in ps.grad
     flat_dp = ps.flat.clone()
     other = flat_dp.cpu().clone()
@@ -62,6 +80,8 @@ def main():
     if rank == 0:
         if not all(torch.equal(gathered[0], g) for g in gathered[1:]):
             ok = False; msg.append("replicas diverged after the update")
+        if not tail_ok:
+            ok = False; msg.append("the tail bucket was written after its all-reduce had been started")
         ps1 = ParamStore(d, dev); ps1.load_state_dict(P)
         eng = Engine(ps1)
         outs, ctx = eng.forward_tf(ci.to(dev), lens.to(dev), mel.to(dev), tl.to(dev), speaker_id=spk.to(dev), training=True, masks=mfull)

@@ -91,8 +91,12 @@ def test_judged_train_lengths_four_utterance_step_matches_oracle():
     P = R.init_params(d, seed=0)
     b = ljspeech_batch(32, seed=1234, num_speakers=4)
     cl, tl = b["chars_idx_len"], b["mel_spectrogram_len"]
-    order = torch.argsort(tl)
-    pick = sorted({int(cl.argmax()), int(tl.argmax()), int(order[0]), int(order[1])})
+    pick = [int(cl.argmax()), int(tl.argmax())]
+    for i in torch.argsort(tl).tolist():              # ... and the shortest ones, until there are four different utterances
+        if len(set(pick)) == 4:
+            break
+        pick.append(i)
+    pick = sorted(set(pick))
     assert len(pick) == 4
     ci, mel, gate, spk = b["chars_idx"][pick], b["mel_spectrogram"][pick], b["gate"][pick], b["speaker_id"][pick]
     cl, tl = cl[pick], tl[pick]
@@ -189,8 +193,12 @@ def test_judged_decode_shape_192_frames_default_check_every_matches_oracle():
 
 def test_bench_decode_call_properties():
     """The call bench.py times for `decode`: 64 utterances, 860 frames, device Philox prenet masks, check_every = 64, random-init
-    weights (no stop).  No oracle at this length (the masks are the device generator's): every output finite, attention rows are
-    distributions supported on each utterance's text, lengths = 860, no persistent-launch timeout, bit-identical repeat."""
+    weights.  Under random weights the stop logit of an utterance is nearly constant in time (a per-speaker value): some utterances
+    never produce a negative one, so `done.all()` never holds and the loop runs to the cap - 860 frames for every utterance, which
+    is what the bench counts - while `lengths` (frames with a non-negative logit, model/tacotron2.py:320) is 860 for those and
+    smaller, down to 0, for the others.  No oracle at this length (the masks are the device generator's): 860 frames emitted,
+    every output finite, attention rows are distributions supported on each utterance's text, masked tails exact, no
+    persistent-launch timeout, bit-identical repeat."""
     from tacotron2_amd.init import init_parameters
     from tacotron2_amd.engine import Engine
     from tacotron2_amd.params import ParamStore
@@ -205,13 +213,18 @@ def test_bench_decode_call_properties():
     torch.cuda.synchronize()
     eng.check_persistent_kernels()
     assert mels.shape == (64, n_dec, 80) and al.shape == (64, n_dec, ci.shape[1])
-    assert bool((lengths == n_dec).all())
+    assert bool(((lengths >= 0) & (lengths <= n_dec)).all()) and int(lengths.max()) == n_dec      # someone never stops: ran to the cap
     for t in (mels, post, gates, al):
         assert bool(torch.isfinite(t).all())
     assert float((al.sum(-1) - 1).abs().max()) < 1e-4
     pos = torch.arange(ci.shape[1], device=dev)[None, None, :] >= cl[:, None, None]
     assert float((al * pos).abs().max()) == 0.0
-    assert float(gates.min()) >= 0.0                              # nobody stopped: the loop ran to the cap, as the bench assumes
+    for b in range(64):                                           # output masking by the counted lengths (model/tacotron2.py:335-345)
+        n = int(lengths[b])
+        if n < n_dec:
+            assert float(mels[b, n:].abs().max()) == 0.0 and float(post[b, n:].abs().max()) == 0.0 and bool((gates[b, n:] == -1000.0).all())
+        if n > 0:
+            assert float(mels[b, :n].abs().max()) > 0.0
     mels2, _, _, al2, _ = eng.infer(ci, cl, n_dec, speaker_id=spk, training=False, seed=2, check_every=64)
     torch.cuda.synchronize()
     assert torch.equal(mels, mels2) and torch.equal(al, al2)

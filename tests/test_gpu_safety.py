@@ -40,6 +40,9 @@ def test_persistent_launch_residency_is_checked():
     assert _lib.call_value("t2_lstm_persist_resident", 1024, 1024, 8) == 0
     assert _lib.call_value("t2_lstm_persist_resident", 4 * 4096, 1024, 32) == 3        # 4096 workgroups of 72 KB LDS
     assert b"co-resident" in _lib.lib().t2_last_error()
+    # two cells of H = 1024 (an encoder with encoded_dim = 2048) would be 512 workgroups: an answer (use step launches), not an error
+    assert _lib.call_value("t2_lstm_persist_resident_n", 1024, 1024, 32, 2) == 3
+    assert _lib.call_value("t2_lstm_persist_resident_n", 256, 256, 32, 2) == 0          # the vanilla encoder: 2 x 64 workgroups
 
 
 def test_engine_falls_back_to_step_launches_without_residency():
