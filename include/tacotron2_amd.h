@@ -283,8 +283,10 @@ typedef struct {
     int t_hi, t_lo;                  /* frames t_hi-1 .. t_lo of this call (descending); 0,0 = T-1 .. 0 */
     float* dgates_t;                 /* optional x16-tiled copy of the dgates part of Z: [T+1][4A/16][Bp][16], slot T
                                         zero-filled by the caller; read by the per-frame products of dgates[t+1] */
-    uint64_t* clk;                   /* diagnostic, normally NULL: 32 device words, s_memtime stamps of workgroup (0,0) at phase
-                                        boundaries of the dw kernel [16..19] and the ds kernel [24..30] */
+    uint64_t* clk;                   /* diagnostic, normally NULL: 128 zeroed device words, read by the -DT2_STAMPS build only: s_memtime
+                                        stamps of workgroup (0,0) at phase boundaries of the dw kernel [16..19] and the ds kernel
+                                        [24..30]; [32] event counter and [40..127] a ring of the last 11 launches of the frame chain
+                                        (products, dw, ds, cell backward) with wall-clock entry / exit and phase stamps (t2_common.hpp) */
     float* ws_bd;                    /* optional workspace of (Ad/16) * 16896 floats: with it (and L <= 252 while the kernel's LDS image
                                         stays under 60 KB) the per-slice kernel runs its two correlations (dU, d_in) on the bf16 matrix
                                         pipe with exactly split operands; the workspace receives the filter operands in fragment

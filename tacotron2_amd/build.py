@@ -28,31 +28,38 @@ def _stale(lib: str = LIB) -> bool:
 STAMPS_LIB = os.path.join(HERE, "libtacotron2_amd_stamps.so")
 
 
-def build_stamps(verbose: bool = True) -> str:
-    """The DIAGNOSTIC library: the same sources with -DT2_STAMPS, i.e. with the in-kernel phase stamps (s_memtime words of one
-    workgroup, read by tools/ubench_attn.py and tools/stamps_bwd.py) compiled in.  The product library has none: each stamp is a
-    branch that ends a basic block, and the kernels of the frame chains run 0.3-0.5 us longer per launch with them.  Select it with
-    T2_LIB_PATH (tacotron2_amd/_lib.py)."""
+def build_variant(tag: str, defines, verbose: bool = True) -> str:
+    """A DIAGNOSTIC library next to the product one: the same sources with extra -D defines, as libtacotron2_amd_<tag>.so (its
+    own object directory; same dependency list as the product library: sources, ABI header, this recipe).  Select it with
+    T2_LIB_PATH (tacotron2_amd/_lib.py, which checks the struct layouts of whatever it loads)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    lib = os.path.join(HERE, f"libtacotron2_amd_{tag}.so")
+    if not _stale(lib):
+        return lib
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    if not _stale(STAMPS_LIB):           # same dependency list as the product library: sources, ABI header, this recipe
-        return STAMPS_LIB
-    objdir = os.path.join(HERE, "..", "build", "obj_stamps")
+    objdir = os.path.join(HERE, "..", "build", f"obj_{tag}")
     os.makedirs(objdir, exist_ok=True)
     procs, objs = [], []
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s) + ".o")
         objs.append(o)
-        cmd = [hipcc] + FLAGS + ["-DT2_STAMPS"] + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + [f"-D{d}" for d in defines] + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", s, "-o", o]
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for s, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {s}:\n{out}")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", STAMPS_LIB] + objs)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
     if verbose:
-        print(f"built {STAMPS_LIB} (diagnostic, -DT2_STAMPS)")
-    return STAMPS_LIB
+        print(f"built {lib} (diagnostic: {' '.join('-D' + d for d in defines)})")
+    return lib
+
+
+def build_stamps(verbose: bool = True) -> str:
+    """The diagnostic library with -DT2_STAMPS, i.e. with the in-kernel phase stamps (s_memtime words of one workgroup, read by
+    tools/ubench_attn.py and tools/stamps_bwd.py) compiled in.  The product library has none: each stamp is a branch that ends a
+    basic block, and the kernels of the frame chains run 0.3-0.5 us longer per launch with them."""
+    return build_variant("stamps", ["T2_STAMPS"], verbose)
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -93,6 +100,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
 if __name__ == "__main__":
     if "--stamps" in sys.argv:
         print(build_stamps())
+    elif "--variant" in sys.argv:          # python -m tacotron2_amd.build --variant TAG DEFINE[=VALUE] ...
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
     else:
         build(force="--force" in sys.argv)
         print(LIB)

@@ -19,7 +19,7 @@
 #include "t2_lstm_step.hpp"
 
 int t2_lstm_step_fwd_launch(const T2LstmStep* steps, int n, hipStream_t st);
-int t2_lstm_step_bwd_launch(const T2LstmBwdStep* steps, int n, hipStream_t st);
+int t2_lstm_step_bwd_launch(const T2LstmBwdStep* steps, int n, hipStream_t st, unsigned long long* clk = nullptr);
 void t2_lstm_fwd_advance(T2LstmStep& c, const T2LstmStride& inc);
 void t2_lstm_bwd_advance(T2LstmBwdStep& c, const T2LstmBwdStride& inc);
 
@@ -764,6 +764,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dw_kernel(AttnBwdK p) {
     float* red = dwx_s + ((L + 3) & ~3);   // [8]
     [[maybe_unused]] const bool stamp = b == 0 && blockIdx.y == 0 && tid == 0;
     T2_STAMP(p, stamp, 16);
+    T2_RING_BEGIN(p.clk, stamp, 3);
     const int l = l0 + (tid >> 3), sub = tid & 7;
     // ---- issue FIRST the small loads that depend on the previous launches (upstream context gradient, location-path
     //      partials of frame t+1, weights): loads return in order, so the 80 KB of memory rows must not sit in front ----
@@ -871,6 +872,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dw_kernel(AttnBwdK p) {
     acc = t2_oct_sum(acc);
     if (sub == 0 && l < L) p.de[(long)b * L + l] = wme * (acc + dwx_s[l] - sigma);
     T2_STAMP(p, stamp, 19);
+    T2_RING_END();
 }
 
 __device__ __forceinline__ void attn_bwd_ds_body(const AttnBwdK& p, const int b, const int j, float* sm) {
@@ -1142,6 +1144,7 @@ __global__ __launch_bounds__(ENT, 4) void attn_bwd_ds_mfma_kernel(AttnBwdK p) {
     const int tid = threadIdx.x, lane = tid & 63;
     [[maybe_unused]] const bool stamp = b == 0 && j == 0 && tid == 0;
     T2_STAMP(p, stamp, 24);
+    T2_RING_BEGIN(p.clk, stamp, 4);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int al = tid >> 5, sub = tid & 31, a = j * 16 + al;
     const int n = lane & 15, q = lane >> 4;
@@ -1384,6 +1387,7 @@ __global__ __launch_bounds__(ENT, 4) void attn_bwd_ds_mfma_kernel(AttnBwdK p) {
         if (m < M8 && l < L) p.din_part_out[(((long)b * (p.Ad >> 4) + j) * 2 + (nn >> 3)) * L + l] = s2;
     }
     T2_STAMP(p, stamp, 30);
+    T2_RING_END();
 }
 
 // dynamic LDS of the matrix-pipe ds kernel (floats: ds planes | input planes | de | phase-C exchange [| query | tanh terms])
@@ -1454,7 +1458,7 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         r.ext1 = a->dh_ext + (long)t * B * a->ld_dh; r.ldx1 = a->ld_dh;
         r.dx_out = a->dh_rec; r.lddx = A;
         if (a->dgates_t) r.dgt_next = a->dgates_t + (long)(t + 1) * zts;
-        T2_TRY(t2_lstm_step_bwd_launch(s2, 2, st));
+        T2_TRY(t2_lstm_step_bwd_launch(s2, 2, st, (unsigned long long*)a->clk));
         // (2),(3) attention backward
         AttnBwdK k;
         memset(&k, 0, sizeof(k));
@@ -1494,7 +1498,7 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         c.dc = a->dc; c.lddc = A;
         c.dg_out = Z + (long)t * B * ldz; c.ldgo = ldz;
         if (a->dgates_t) c.dgt_out = a->dgates_t + (long)t * zts;
-        T2_TRY(t2_lstm_step_bwd_launch(&c, 1, st));
+        T2_TRY(t2_lstm_step_bwd_launch(&c, 1, st, (unsigned long long*)a->clk));
     }
     T2_CHECK_LAUNCH();
     return T2_OK;

@@ -48,6 +48,28 @@ void t2_set_error(const char* msg, const char* file, int line);
 // 70.35 -> 69.47 ms per training step in one session (profiles/r02_ab_wave_priority.txt); no effect without a second stream.
 #define T2_CHAIN_PRIO() __builtin_amdgcn_s_setprio(3)
 
+// Event ring of the DIAGNOSTIC build (-DT2_STAMPS): the first thread of workgroup (0,0,0) of a stamped launch takes the next of 11
+// entries of 8 words behind word 40 of the caller's 128-word stamp buffer (sequence counter: word 32) and records
+//   [0] kind  [1] 100 MHz wall clock at entry  [2] ... at exit  [3] shader clock at entry  [4..6] phase stamps  [7] shader clock at exit
+// so that consecutive launches of a dependent chain can be laid on one time axis (exit -> next entry gaps).  Nothing in the
+// product build: every stamp is a branch that ends a basic block.
+#ifdef T2_STAMPS
+#define T2_RING_BEGIN(clk, cond, kind)                                                                              \
+    unsigned long long* ring__ = nullptr;                                                                           \
+    if ((clk) && (cond)) {                                                                                          \
+        const unsigned long long seq__ = atomicAdd(&(clk)[32], 1ull);                                               \
+        ring__ = (clk) + 40 + 8 * (seq__ % 11);                                                                     \
+        ring__[0] = (kind); ring__[4] = 0; ring__[5] = 0; ring__[6] = 0;                                            \
+        ring__[1] = __builtin_amdgcn_s_memrealtime(); ring__[3] = __builtin_amdgcn_s_memtime();                     \
+    }
+#define T2_RING(i) do { if (ring__) ring__[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define T2_RING_END() do { if (ring__) { ring__[7] = __builtin_amdgcn_s_memtime(); ring__[2] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define T2_RING_BEGIN(clk, cond, kind) do { } while (0)
+#define T2_RING(i) do { } while (0)
+#define T2_RING_END() do { } while (0)
+#endif
+
 static inline int t2_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool t2_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 

@@ -488,10 +488,10 @@ __global__ __launch_bounds__(512, 1) void lstm_step_bwd_fast8_kernel(BwdK2 pp) {
 }
 static int g_bwd8_max_wgs = getenv("T2_BWD8_MAX_WGS") ? atoi(getenv("T2_BWD8_MAX_WGS")) : 64;
 
-int launch_bwd(const T2LstmBwdStep* steps, int n, hipStream_t st) {
+int launch_bwd(const T2LstmBwdStep* steps, int n, hipStream_t st, unsigned long long* clk = nullptr) {
     T2_REQUIRE(n == 1 || n == 2, "lstm bwd step: n must be 1 or 2");
     BwdK2 kk;
-    for (int i = 0; i < n; ++i) { T2_TRY(t2_lstm_check_bwd(steps[i])); t2_lstm_to_bk(steps[i], kk.s[i]); }
+    for (int i = 0; i < n; ++i) { T2_TRY(t2_lstm_check_bwd(steps[i])); t2_lstm_to_bk(steps[i], kk.s[i]); kk.s[i].clk = clk; }
     bool fast = true;
     for (int i = 0; i < n; ++i) fast = fast && steps[i].wtpacked && steps[i].dg_next && !steps[i].dg2;
     for (int i = 1; i < n; ++i)
@@ -580,7 +580,7 @@ void t2_lstm_bwd_advance(T2LstmBwdStep& c, const T2LstmBwdStride& inc) {
 }
 // internal entries used by the attention sequence (t2_attention.hip)
 int t2_lstm_step_fwd_launch(const T2LstmStep* steps, int n, hipStream_t st) { return launch_fwd(steps, n, st); }
-int t2_lstm_step_bwd_launch(const T2LstmBwdStep* steps, int n, hipStream_t st) { return launch_bwd(steps, n, st); }
+int t2_lstm_step_bwd_launch(const T2LstmBwdStep* steps, int n, hipStream_t st, unsigned long long* clk) { return launch_bwd(steps, n, st, clk); }
 extern "C" int t2_lstm_step_fwd(const T2LstmStep* steps, int n, void* stream) {
     (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(steps != nullptr, "t2_lstm_step_fwd: null");

@@ -3,6 +3,13 @@
 #pragma once
 #include "t2_common.hpp"
 
+// Diagnostic builds only (tacotron2_amd/build.py --variant): T2_CELL_MFMA_KEEP < 4 issues only that many of the four fp32 MFMA
+// k-substeps of every 16-deep chunk in the packed step kernels - WRONG RESULTS, same loads and epilogue - to bound what a faster
+// matrix path could buy these kernels (tools/ablate_cell_mfma.py).  The product build keeps all four.
+#ifndef T2_CELL_MFMA_KEEP
+#define T2_CELL_MFMA_KEEP 4
+#endif
+
 struct Seg { const float* x; long ldx; const float* w; long ldw; int K; };
 struct LstmK {
     int B, H, nseg;
@@ -122,7 +129,7 @@ __device__ __forceinline__ void t2_lstm_fwd_fast_body(const LstmK& p, const int 
     };
     auto mma_chunk = [&](const f32x4& bw, const f32x4 (&ax)[MT]) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < T2_CELL_MFMA_KEEP; ++s)
 #pragma unroll
             for (int m = 0; m < MT; ++m)
                 acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[m][s], bw[s], acc[m], 0, 0, 0);
@@ -221,6 +228,7 @@ struct BwdK {
     const int32_t* len; int t;
     const float* dgt; long dgt_cs; float* dgt_out;   // x16-tiled dg_next / dg_out (chunk stride Bp*16 floats)
     int off_chain;                      // T2LstmBwdStep.off_chain
+    unsigned long long* clk;            // diagnostic build: the caller's stamp buffer (event ring, t2_common.hpp) or null
 };
 struct BwdK2 { BwdK s[2]; };
 
@@ -235,6 +243,7 @@ inline void t2_lstm_to_bk(const T2LstmBwdStep& s, BwdK& k) {
     k.dc = s.dc; k.lddc = s.lddc; k.dg_out = s.dg_out; k.ldgo = s.ldgo; k.len = s.len; k.t = s.t;
     k.dgt = s.dgt_next; k.dgt_out = s.dgt_out; k.dgt_cs = (long)((s.B + 15) / 16 * 16) * 16;
     k.off_chain = s.off_chain;
+    k.clk = nullptr;
 }
 
 inline int t2_lstm_check_bwd(const T2LstmBwdStep& s) {
@@ -323,6 +332,8 @@ __device__ __forceinline__ void t2_lstm_bwd_fast_body(const BwdK& p, const int b
     const int r = lane & 15, q = lane >> 4;
     const int u0 = bx * 16, b0 = by * 16;
     if (u0 >= p.ncols) return;   // descriptors of one launch may have different widths (whole workgroup exits)
+    // kinds: 0 = products (plain store), 1 = cell backward behind a short product (K < 4H), 2 = BPTT step (K = 4H + cell backward)
+    T2_RING_BEGIN(p.clk, bx == 0 && by == 0 && blockIdx.z == 0 && tid == 0, p.epi == 0 ? 0 : (p.N4 < 4 * p.H ? 1 : 2));
     const int NCH = (p.N4 + p.N2) >> 4, NCHpad = (NCH + 31) & ~31, G = NCHpad / (NW * U);
     const float* wb = p.wtpacked + (long)bx * NCHpad * 256 + lane * 4;
     // x16-tiled gradients: one contiguous 1 KB block per (chunk, row tile) instead of 16 rows x 64 B
@@ -339,9 +350,9 @@ __device__ __forceinline__ void t2_lstm_bwd_fast_body(const BwdK& p, const int b
     };
     auto mma_chunk = [&](const f32x4& a, const f32x4& b) {
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc1, 0, 0, 0);
+        if (T2_CELL_MFMA_KEEP > 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
+        if (T2_CELL_MFMA_KEEP > 2) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc0, 0, 0, 0);
+        if (T2_CELL_MFMA_KEEP > 3) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc1, 0, 0, 0);
     };
     // chunk-granular software pipeline (see the forward kernel)
     auto pipe_group = [&](int gl, f32x4 (&aL)[U], f32x4 (&bL)[U], const f32x4 (&aM)[U], const f32x4 (&bM)[U]) {
@@ -360,6 +371,9 @@ __device__ __forceinline__ void t2_lstm_bwd_fast_body(const BwdK& p, const int b
         int g = 0;
         for (; g + 2 < G; g += 2) {
             pipe_group(g + 1, aB, bB, aA, bA);
+#ifdef T2_STAMPS
+            if (g == 0) T2_RING(4);          // group 0 consumed: the first operands of this launch have arrived
+#endif
             pipe_group(g + 2, aA, bA, aB, bB);
         }
         if (g + 1 < G) {
@@ -371,8 +385,11 @@ __device__ __forceinline__ void t2_lstm_bwd_fast_body(const BwdK& p, const int b
             for (int j = 0; j < U; ++j) mma_chunk(aA[j], bA[j]);
         }
     }
+    T2_RING(5);                              // main loop done
 #pragma unroll
     for (int g = 0; g < 4; ++g) red[(w * 16 + (q * 4 + g)) * 16 + r] = acc0[g] + acc1[g];
     __syncthreads();
+    T2_RING(6);                              // K shares of the waves in LDS
     if (tid < 256) bwd_epi_apply<NW>(p, epi, red, tid, u0, b0);
+    T2_RING_END();
 }
