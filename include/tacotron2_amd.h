@@ -202,6 +202,8 @@ int t2_lstm_seq_bwd(const T2LstmBwdStep* base, const T2LstmBwdStride* inc, int n
  *   len [B] int32    : positions l >= len[b] are masked to -inf before the softmax (model/attention.py:63)
  *   e_part           : workspace [B][Ad/16][L];  th_out: optional stash [B][Ad][L4] of tanh(.) for backward, rows padded
  *                      to L4 = round_up(L,4) floats (16-byte aligned; must be 16-byte aligned itself)
+ * Any text length whose per-sample images fit the 160 KB of LDS (energies kernel: 24 bytes per position - about 6,000 characters);
+ * the kernels walk texts above 256 positions in rounds.
  * Writes w_out (new attention weights = the alignments row), cum_out = cum_prev + w, ctx_out (context). */
 typedef struct {
     int B, L, A, Ad, Ef, Kl;
@@ -211,7 +213,6 @@ typedef struct {
     const float* cum_prev; int64_t ldcum;    /* NULL = zeros */
     const float* pmT; const float* memory; const int32_t* len;
     float* e_part; float* th_out;
-    float* q_out;                            /* optional [B][Ad]: the query projection Wq.att_h of this frame (stash for backward) */
     float* w_out; int64_t ldwo; float* cum_out; int64_t ldco;
     float* ctx_out; int64_t ldctx; float* ctx_out2; int64_t ldctx2;
     float* ctxt_out; int ctxt_col0;          /* optional x16-tiled copy of the context (see T2LstmStep) */
@@ -238,20 +239,11 @@ typedef struct {
     const float* pre; const float* pmT; const float* memory; const int32_t* len;
     const float* att_drop;
     float* xdec; float* att_c; float* gates; float* align; float* cum; float* th;
-    float* qproj;                    /* optional [T][B][Ad]: query projections of all frames (the backward recomputes the tanh terms
-                                        from them when th is not kept, see t2_attn_bwd_recomputes_th) */
     float* xproj_ctx; int64_t ld_xproj;
     float* e_part;
     int t_begin, t_end;              /* frame range [t_begin, t_end) of this call; 0,0 = all T frames */
     float* xdec_t;                   /* optional (with wpacked): x16-tiled copy of xdec, [T+1][(A+Ef)/16][Bp][16], slot 0
                                         zero-filled by the caller; the attention-LSTM step then reads its input from it */
-    /* Optional co-scheduled recurrence: step i of an independent LSTM sequence (the decoder LSTM of an EARLIER chunk of
-     * frames, whose hoisted input projection is already computed) runs INSIDE the attention-energies launch of frame
-     * t_begin+i (heterogeneous launch: extra workgroups next to the energies workgroups).  Dependent launches cost ~1.7 us +
-     * a memory round trip each and kernels of two streams do not overlap at this size; a cell step (MFMA + weight
-     * stream) next to the latency-bound energies kernel uses otherwise idle pipes.  Needs the packed single-segment path and
-     * co_step->B <= 32 (else, and for steps beyond the frame range, the steps run as plain launches). */
-    const T2LstmStep* co_step; const T2LstmStride* co_inc; int co_steps;
     uint64_t* clk;                   /* diagnostic (T2AttnStep.clk), normally NULL */
 } T2AttnSeq;
 int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream);
@@ -264,7 +256,10 @@ int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream);
  * with Z[s][b] = [dgates_s (4A) | dq_{s-1} (Ad)] (the caller zero-fills slot T's first 4A columns; `dq` is unused),
  * dctx_tot [T][B][Ef] (inputs of the post-loop weight-gradient GEMMs) and the per-sample
  * accumulators dpmT [B][Ad][L], dv_part [B][Ad], dU_part [B][Ad][2][Kl] (caller zero-fills; summed over b after).
- * Workspaces: dc [B][A] (zero-filled), G [2][B][L], de [B][L], din_part [B][Ad/16][2][L]. */
+ * Workspaces: dc [B][A] (zero-filled), G [2][B][L], de [B][L], din_part [B][Ad/16][2][L].
+ * Texts of up to 252 positions take the per-slice kernel in one pass; longer ones are walked in position tiles of 216 (+ 16 on
+ * either side: a tile's gradient reaches 15 positions beyond it through the location filter) inside the same launch - no length
+ * limit but the LDS (8 bytes per position for the location-input gradient of the whole text, 42 KB for a tile). */
 typedef struct {
     int B, L, T, A, Ad, Ef, Kl;
     const float* W_ih_ctx; int64_t ld_wih;
@@ -287,19 +282,11 @@ typedef struct {
                                         stamps of workgroup (0,0) at phase boundaries of the dw kernel [16..19] and the ds kernel
                                         [24..30]; [32] event counter and [40..127] a ring of the last 11 launches of the frame chain
                                         (products, dw, ds, cell backward) with wall-clock entry / exit and phase stamps (t2_common.hpp) */
-    float* ws_bd;                    /* optional workspace of (Ad/16) * 16896 floats: with it (and L <= 252 while the kernel's LDS image
-                                        stays under 60 KB) the per-slice kernel runs its two correlations (dU, d_in) on the bf16 matrix
-                                        pipe with exactly split operands; the workspace receives the filter operands in fragment
-                                        layout, rewritten by every call (same results to fp32 rounding; NULL = the packed-FMA kernel) */
-    const float* pmT;                /* processed memory [B][Ad][L] of the forward: needed when th == NULL */
-    const float* qproj;              /* query projections [T][B][Ad] of the forward (T2AttnSeq.qproj): needed when th == NULL */
+    float* ws_bd;                    /* workspace of (Ad/16) * 16896 floats: the per-slice kernel runs its two correlations (dU, d_in)
+                                        on the bf16 matrix pipe with exactly split operands (six products, fp32 accuracy); the
+                                        workspace receives the d_in filter operand in fragment layout, rewritten by every call */
 } T2AttnSeqBwd;
 int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream);
-/* 1 when t2_attn_seq_bwd (with ws_bd) can run WITHOUT the tanh stash for texts of padded length L: its matrix-pipe kernel then
- * recomputes tanh(query + location + processed memory) from qproj, U, align, cum and pmT - the location convolution on the
- * matrix pipe, as in the forward - and the forward (T2AttnSeq.th = NULL, qproj given) neither writes nor keeps [T][B][Ad][L4]
- * floats.  0: pass the stash. */
-int t2_attn_bwd_recomputes_th(int L, int Ad, int A);
 
 /* ------------------------------------------------------------------------------------------------
  * Conv stacks (encoder model/encoder.py:31-46,57; postnet model/postnet.py:8-49).

@@ -33,7 +33,7 @@ struct AttnK {
     const float* Wq; const float* U; const float* v;
     const float* w_prev; long ldw; const float* cum_prev; long ldcum;
     const float* pmT; const float* memory; const int32_t* len;
-    float* e_part; float* th_out; float* q_out;
+    float* e_part; float* th_out;
     float* w_out; long ldwo; float* cum_out; long ldco;
     float* ctx_out; long ldctx; float* ctx_out2; long ldctx2;
     float* ctxt_out; int ctxt_col0; long ctxt_cs;
@@ -63,7 +63,8 @@ struct StageRegs { float uv[1024 / NTH]; float iv[1024 / NTH]; };
 // DO_INP / DO_U: which of the two images a kernel needs (the matrix-pipe ds kernel takes its filter operand from global memory)
 template <int NTH, bool DO_INP = true, bool DO_U = true>
 __device__ __forceinline__ void stage_issue(StageRegs<NTH>& r, const float* w_prev, long ldw, const float* cum_prev, long ldcum,
-                                            const float* U, const float* dummy, int b, int j, int L, int Lp, int tid, int kpad = KPAD) {
+                                            const float* U, const float* dummy, int b, int j, int L, int Lp, int tid, int kpad = KPAD,
+                                            int loff = 0 /* text position of image index kpad (position tiles of long texts) */) {
     constexpr int PER = 1024 / NTH;
     const float* wsrc = w_prev ? w_prev + (long)b * ldw : dummy;
     const float* csrc = cum_prev ? cum_prev + (long)b * ldcum : dummy;
@@ -78,77 +79,15 @@ __device__ __forceinline__ void stage_issue(StageRegs<NTH>& r, const float* w_pr
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int idx = tid + NTH * i;
-            const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - kpad;
+            const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - kpad + loff;
             const int lc = imin(imax(l, 0), L - 1);
             r.iv[i] = (c ? csrc : wsrc)[lc];
         }
     }
 }
 
-template <int NTH>
-__device__ __forceinline__ void stage_commit(const StageRegs<NTH>& r, float* inp, float* Us, const float* w_prev, long ldw,
-                                             const float* cum_prev, long ldcum, const float* dummy, int b, int L, int Lp, int tid) {
-    constexpr int PER = 1024 / NTH;
-    const float* wsrc = w_prev ? w_prev + (long)b * ldw : dummy;
-    const float* csrc = cum_prev ? cum_prev + (long)b * ldcum : dummy;
-    const bool wz = w_prev == nullptr, cz = cum_prev == nullptr;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int idx = tid + NTH * i;
-        const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
-        const bool ok = l >= 0 && l < L && !(c ? cz : wz);
-        if (idx < 2 * Lp) inp[idx] = ok ? r.iv[i] : 0.f;
-    }
-    for (int base = 1024; base < 2 * Lp; base += 1024) {   // long texts (2*Lp > 1024): further rounds, load then store
-        float iv[PER];
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int idx = base + tid + NTH * i;
-            const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
-            const int lc = imin(imax(l, 0), L - 1);
-            iv[i] = (c ? csrc : wsrc)[lc];
-        }
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int idx = base + tid + NTH * i;
-            const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - KPAD;
-            const bool ok = l >= 0 && l < L && !(c ? cz : wz);
-            if (idx < 2 * Lp) inp[idx] = ok ? iv[i] : 0.f;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int idx = tid + NTH * i;
-        Us[idx] = (idx & 31) < KL ? r.uv[i] : 0.f;
-    }
-}
-
-template <int NTH>
-__device__ __forceinline__ void stage_inp_U(float* inp, float* Us, const float* w_prev, long ldw, const float* cum_prev,
-                                            long ldcum, const float* U, const float* dummy, int b, int j, int L, int Lp,
-                                            int tid) {
-    StageRegs<NTH> r;
-    stage_issue<NTH>(r, w_prev, ldw, cum_prev, ldcum, U, dummy, b, j, L, Lp, tid);
-    stage_commit<NTH>(r, inp, Us, w_prev, ldw, cum_prev, ldcum, dummy, b, L, Lp, tid);
-}
-
 constexpr int ENT = 512;   // threads of the energy / ds kernels: two waves per SIMD double the VALU issue rate
-constexpr int EMAXI = 2;   // 4-position work items per thread per round (32 threads per attention dim): one round covers L <= 256
-
-// Thread mapping of both kernels: attention dim al = tid >> 5 (16 dims x 32 threads), position groups lg = sub + 32*it.
-// All items of a thread share its dim, so the 62 filter taps are read from LDS ONCE into registers (16 aligned 16-byte
-// reads) instead of 62 scalar reads per item; the kernels are LDS-instruction bound otherwise.
-__device__ __forceinline__ void load_taps(const float* Us, int al, float (&uk)[2][32]) {
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const f32x4* up = reinterpret_cast<const f32x4*>(Us + al * 64 + c * 32);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const f32x4 t = up[i];
-            uk[c][4 * i] = t[0]; uk[c][4 * i + 1] = t[1]; uk[c][4 * i + 2] = t[2]; uk[c][4 * i + 3] = t[3];
-        }
-    }
-}
+constexpr int EMAXI = 2;   // 4-position work items per thread (32 threads per attention dim): 256 positions per pass of the ds kernel
 
 // ---- exact fp32 products on the bf16 matrix pipe (the scheme of csrc/t2_gemm.hip): a = h + m + l with three bf16 terms, six of
 //      the nine cross products issued, the small ones into their own accumulator ----
@@ -225,7 +164,7 @@ __device__ __forceinline__ Bf3 t2_split1(float v) {
 template <int NTH, bool DO_U = true>
 __device__ __forceinline__ void stage_commit_split(const StageRegs<NTH>& r, unsigned* PX, unsigned* UX, const float* w_prev, long ldw,
                                                    const float* cum_prev, long ldcum, const float* dummy, int b, int L, int Lp, int tid,
-                                                   int kpad = KPAD) {
+                                                   int kpad = KPAD, int loff = 0) {
     constexpr int PER = 1024 / NTH;
     const float* wsrc = w_prev ? w_prev + (long)b * ldw : dummy;
     const float* csrc = cum_prev ? cum_prev + (long)b * ldcum : dummy;
@@ -240,7 +179,7 @@ __device__ __forceinline__ void stage_commit_split(const StageRegs<NTH>& r, unsi
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int idx = tid + NTH * i;
-        const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - kpad;
+        const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - kpad + loff;
         const bool ok = l >= 0 && l < L && !(c ? cz : wz);
         if (idx < 2 * Lp) put(idx, ok ? r.iv[i] : 0.f);
     }
@@ -249,14 +188,14 @@ __device__ __forceinline__ void stage_commit_split(const StageRegs<NTH>& r, unsi
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int idx = base + tid + NTH * i;
-            const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - kpad;
+            const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - kpad + loff;
             const int lc = imin(imax(l, 0), L - 1);
             iv[i] = (c ? csrc : wsrc)[lc];
         }
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int idx = base + tid + NTH * i;
-            const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - kpad;
+            const int c = idx >= Lp ? 1 : 0, l = idx - c * Lp - kpad + loff;
             const bool ok = l >= 0 && l < L && !(c ? cz : wz);
             if (idx < 2 * Lp) put(idx, ok ? iv[i] : 0.f);
         }
@@ -378,10 +317,7 @@ __device__ __forceinline__ void attn_energy_body(const AttnK& p, const int b, co
             }
         }
         const float sq0 = t2_wave_sum(qacc[0]), sq1 = t2_wave_sum(qacc[1]);
-        if (lane == 0) {
-            qs[2 * w] = sq0; qs[2 * w + 1] = sq1;
-            if (p.q_out) *reinterpret_cast<f32x2*>(p.q_out + (long)b * p.Ad + j * 16 + 2 * w) = (f32x2){sq0, sq1};
-        }
+        if (lane == 0) { qs[2 * w] = sq0; qs[2 * w + 1] = sq1; }
         T2_STAMP(p, stamp, 5);
     }
     __syncthreads();   // qs visible
@@ -560,7 +496,7 @@ __global__ void fold_location_kernel(const float* Wd, const float* Wc, float* U,
 }
 
 int check_attn(const T2AttnStep& s) {
-    T2_REQUIRE(s.B >= 1 && s.L >= 1 && s.L <= 768, "attention: need 1 <= L <= 768");
+    T2_REQUIRE(s.B >= 1 && s.L >= 1, "attention: need B >= 1 and L >= 1");
     T2_REQUIRE(s.Kl == KL, "attention: location kernel size must be 31 (model/decoder.py:36)");
     T2_REQUIRE(s.Ad % 16 == 0 && s.Ef % 32 == 0 && s.A % 4 == 0, "attention: need Ad%16==0, Ef%32==0, A%4==0");
     T2_REQUIRE(s.ldh % 4 == 0 && t2_aligned16(s.att_h) && t2_aligned16(s.Wq), "attention: att_h/Wq alignment");
@@ -573,51 +509,24 @@ void to_ak(const T2AttnStep& s, AttnK& k) {
     k.B = s.B; k.L = s.L; k.A = s.A; k.Ad = s.Ad; k.Ef = s.Ef;
     k.att_h = s.att_h; k.ldh = s.ldh; k.Wq = s.Wq; k.U = s.U; k.v = s.v;
     k.w_prev = s.w_prev; k.ldw = s.ldw; k.cum_prev = s.cum_prev; k.ldcum = s.ldcum;
-    k.pmT = s.pmT; k.memory = s.memory; k.len = s.len; k.e_part = s.e_part; k.th_out = s.th_out; k.q_out = s.q_out;
+    k.pmT = s.pmT; k.memory = s.memory; k.len = s.len; k.e_part = s.e_part; k.th_out = s.th_out;
     k.w_out = s.w_out; k.ldwo = s.ldwo; k.cum_out = s.cum_out; k.ldco = s.ldco;
     k.ctx_out = s.ctx_out; k.ldctx = s.ldctx; k.ctx_out2 = s.ctx_out2; k.ldctx2 = s.ldctx2;
     k.ctxt_out = s.ctxt_out; k.ctxt_col0 = s.ctxt_col0; k.ctxt_cs = (long)((s.B + 15) / 16 * 16) * 16;
     k.clk = (unsigned long long*)s.clk;
 }
 
-// Heterogeneous launch: workgroups [0, nE) are the energies workgroups (b = id % B, attention-dim slice id / B), workgroups
-// [nE, nE + H/4) run one step of a co-scheduled LSTM cell (t2_lstm_step.hpp).  512-thread workgroups; the cell body uses 256
-// threads, the upper four waves of a cell workgroup end at once (finished waves do not count at s_barrier and release their
-// registers), so an energies workgroup (2 waves per SIMD) and a cell workgroup (1 wave per SIMD) share a CU at <= 168 VGPRs.
-template <int MT>
-__global__ __launch_bounds__(ENT, 3) void attn_energy_co_kernel(AttnK p, LstmK c, int nE) {
-    T2_CHAIN_PRIO();
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int bid = blockIdx.x;
-    if (bid < nE) { attn_energy_body(p, bid % p.B, bid / p.B, sm); return; }
-    if (threadIdx.x >= 256) return;
-    t2_lstm_fwd_fast_body<MT, 4>(c, bid - nE, sm);
-}
-
-// A cell step can ride in the energies launch if it takes the packed single-segment path with <= 32 batch rows.
-bool co_eligible(const T2LstmStep& c) { return c.wpacked && c.nseg == 1 && c.B <= 32 && c.H % 4 == 0; }
-
-int launch_attn(const T2AttnStep& s, hipStream_t st, const T2LstmStep* co = nullptr) {
+int launch_attn(const T2AttnStep& s, hipStream_t st) {
     AttnK k;
     to_ak(s, k);
     const int NG = (s.L + 3) >> 2, Lp = 4 * NG + 48;
     const size_t sm_e = (size_t)(16 + 6 * Lp + 3 * 640) * sizeof(float);
     const int wsn = ((s.L + 3) & ~3) > 192 ? ((s.L + 3) & ~3) : 192;
     const size_t sm_c = (size_t)(wsn + 8 + 256) * sizeof(float);
-    T2_REQUIRE(t2_allow_lds(attn_energy_kernel, sm_e), "attention: LDS budget exceeded (energies kernel)");
-    if (co) {
-        T2_TRY(t2_lstm_check_step(*co));
-        LstmK ck;
-        t2_lstm_to_k(*co, ck, 0, co->B);
-        const int MT = co->B <= 16 ? 1 : 2;
-        const int nE = s.B * (s.Ad / 16);
-        const size_t sm_co = (size_t)4 * MT * 256 * sizeof(float), sme = sm_e > sm_co ? sm_e : sm_co;
-        T2_REQUIRE(t2_allow_lds(attn_energy_co_kernel<1>, sme) && t2_allow_lds(attn_energy_co_kernel<2>, sme), "attention: LDS budget exceeded");
-        if (MT == 1) hipLaunchKernelGGL(attn_energy_co_kernel<1>, dim3(nE + co->H / 4), dim3(ENT), sme, st, k, ck, nE);
-        else hipLaunchKernelGGL(attn_energy_co_kernel<2>, dim3(nE + co->H / 4), dim3(ENT), sme, st, k, ck, nE);
-    } else {
-        hipLaunchKernelGGL(attn_energy_kernel, dim3(s.B, s.Ad / 16), dim3(ENT), sm_e, st, k);
-    }
+    // (no fixed length limit: what bounds a text is the 160 KB of LDS - 24 bytes per position in the energies kernel)
+    T2_REQUIRE(t2_allow_lds(attn_energy_kernel, sm_e) && t2_allow_lds(attn_context_kernel, sm_c),
+               "attention: the text is too long for the LDS images of the attention kernels");
+    hipLaunchKernelGGL(attn_energy_kernel, dim3(s.B, s.Ad / 16), dim3(ENT), sm_e, st, k);
     hipLaunchKernelGGL(attn_context_kernel, dim3(s.B, s.Ef / 32), dim3(256), sm_c, st, k);
     T2_CHECK_LAUNCH();
     return T2_OK;
@@ -646,8 +555,7 @@ extern "C" int t2_attn_step_fwd(const T2AttnStep* s, void* stream) {
     return t2_attn_step_launch(s, (hipStream_t)stream);
 }
 
-// Teacher-forced attention chain over frames [t_begin, t_end): per frame  attention-LSTMCell -> energies -> softmax/context
-// (co step i rides the energies launch of frame t_begin + i).
+// Teacher-forced attention chain over frames [t_begin, t_end): per frame  attention-LSTMCell -> energies -> softmax/context.
 extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
     (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(a != nullptr, "t2_attn_seq_fwd: null");
@@ -657,13 +565,6 @@ extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
     const int tb = (a->t_begin == 0 && a->t_end == 0) ? 0 : a->t_begin, te = (a->t_begin == 0 && a->t_end == 0) ? T : a->t_end;
     T2_REQUIRE(tb >= 0 && te <= T && tb <= te, "t2_attn_seq_fwd: bad frame range");
     T2_REQUIRE(!a->xdec_t || (a->wpacked && (A + Ef) % 16 == 0 && A % 16 == 0), "t2_attn_seq_fwd: xdec_t needs wpacked and A, Ef multiples of 16");
-    T2LstmStep co;
-    int co_left = 0;
-    bool co_ride = false;
-    if (a->co_step && a->co_steps > 0) {
-        T2_REQUIRE(a->co_inc != nullptr, "t2_attn_seq_fwd: co_inc required with co_step");
-        co = *a->co_step; co_left = a->co_steps; co_ride = co_eligible(co);
-    }
     for (int t = tb; t < te; ++t) {
         T2LstmStep s;
         memset(&s, 0, sizeof(s));
@@ -697,7 +598,6 @@ extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
         q.cum_prev = a->cum + (long)t * B * L; q.ldcum = L;
         q.pmT = a->pmT; q.memory = a->memory; q.len = a->len; q.e_part = a->e_part;
         if (a->th) q.th_out = a->th + (long)t * B * Ad * ((L + 3) & ~3);
-        if (a->qproj) q.q_out = a->qproj + (long)t * B * Ad;
         q.w_out = a->align + (long)t * L; q.ldwo = (long)T * L;
         q.cum_out = a->cum + (long)(t + 1) * B * L; q.ldco = L;
         q.ctx_out = slot1 + A; q.ldctx = ldx;
@@ -705,16 +605,7 @@ extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
         if (a->xdec_t) { q.ctxt_out = a->xdec_t + (long)(t + 1) * xts; q.ctxt_col0 = A; }
         q.clk = a->clk;
         if (t == tb) T2_TRY(check_attn(q));
-        if (co_left > 0 && co_ride) {
-            T2_TRY(launch_attn(q, st, &co));
-            t2_lstm_fwd_advance(co, *a->co_inc); --co_left;
-        } else {
-            T2_TRY(launch_attn(q, st));
-        }
-    }
-    for (; co_left > 0; --co_left) {   // co-scheduled steps that did not ride in an energies launch
-        T2_TRY(t2_lstm_step_fwd_launch(&co, 1, st));
-        t2_lstm_fwd_advance(co, *a->co_inc);
+        T2_TRY(launch_attn(q, st));
     }
     return T2_OK;
 }
@@ -729,7 +620,7 @@ extern "C" int t2_attn_seq_fwd(const T2AttnSeq* a, void* stream) {
 //     softmax backward needs sigma = sum_l w[l]*(dw[l]+dwx[l]) = dctx.context_t + sum_l w[l]*dwx[l],
 //     which every workgroup recomputes locally - no cross-workgroup reduction.
 //     de[l] = w[l] * (dw[l] + dwx[l] - sigma)        (masked positions have w = 0 -> de = 0)
-//  attn_bwd_ds_kernel   grid (B, Ad/16): workgroup (b, j) owns 16 attention dims for all l.
+//  attn_bwd_ds_mfma_kernel / attn_bwd_ds_tiled_kernel   grid (B, Ad/16): workgroup (b, j) owns 16 attention dims for all l.
 //     ds[l][a] = de[l] * v[a] * (1 - th^2);  dpmT += ds;  dq[a] = sum_l ds;  dv[a] += sum_l de[l]*th[l][a]
 //     dU[a][c][k] += sum_l ds[l][a] * in[c][l+k-15]                   (per-sample partial, summed after the loop)
 //     d_in partial [c][l'] = sum_{a in slice,k} ds[l'+15-k][a] * U[a][c][k]  (summed over slices by the next frame)
@@ -745,9 +636,7 @@ struct AttnBwdK {
     const float* w_prev; long ldwp; const float* cum_prev; long ldcp;
     float* dpmT; float* dq; long lddq; float* dv_part; float* dU_part; float* din_part_out;
     unsigned long long* clk;   // diagnostic stamps (T2AttnSeqBwd.clk) or null
-    const unsigned* bd;        // matrix-pipe ds kernel: fragment-ready bf16 planes of the d_in filter operand (attn_bwd_prep_kernel)
-    // recomputation of the tanh terms in the matrix-pipe ds kernel (th == nullptr): operands of the forward energies kernel
-    const unsigned* ub; const float* pmT; const float* qproj;
+    const unsigned* bd;        // fragment-ready bf16 planes of the d_in filter operand (attn_bwd_prep_kernel)
 };
 
 namespace {
@@ -875,209 +764,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dw_kernel(AttnBwdK p) {
     T2_RING_END();
 }
 
-__device__ __forceinline__ void attn_bwd_ds_body(const AttnBwdK& p, const int b, const int j, float* sm) {
-    const int tid = threadIdx.x;
-    [[maybe_unused]] const bool stamp = b == 0 && j == 0 && tid == 0;
-    T2_STAMP(p, stamp, 24);
-    const int al = tid >> 5, sub = tid & 31, a = j * 16 + al;
-    const int L = p.L, NG = (L + 3) >> 2, Lp = 4 * NG + 36, L4 = 4 * NG;
-    constexpr int DH = 16;         // halo of the ds rows (16, not 15: keeps every 4-position read 16-byte aligned)
-    float* inp = sm;               // [2][Lp]  haloed (w_{t-1}, cum_{t-1}), index l + 15
-    float* dsp = inp + 2 * Lp;     // [16][Lp] haloed ds, index l + 16
-    float* Us = dsp + 16 * Lp;     // [16][2][32]
-    float* tvs = Us + 16 * 64;     // [16][L4] de*th      } after phase C these three (32*L4 floats) hold the
-    float* des = tvs + 16 * L4;    // [L4]                } per-dim d_in partials dinq[16][2][L4]
-                                   // [15*L4] extension   }
-    const long rowoff = ((long)b * p.Ad + a) * L;
-    // ---- issue: tanh stash + old dpmT of the first round, de, location inputs, filter rows, old accumulator values ----
-    float thv[EMAXI][4], dpv[EMAXI][4];
-    const float va = p.v[a];
-    const float* th_row = p.th + ((long)b * p.Ad + a) * L4;   // stash rows are padded to L4 floats (16-byte aligned items)
-#pragma unroll
-    for (int it = 0; it < EMAXI; ++it) {
-        const int lg = imin(sub + 32 * it, NG - 1);
-        const f32x4 t4 = *reinterpret_cast<const f32x4*>(th_row + 4 * lg);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int l = imin(4 * lg + i, L - 1);
-            thv[it][i] = t4[i];
-            dpv[it][i] = p.dpmT[rowoff + l];
-        }
-    }
-    // phase C ownership: (dim al, channel c_c, tap group c_kg of 8 taps, position quarter c_lq)
-    const int c_c = sub >> 4, c_kg = (sub >> 2) & 3, c_lq = sub & 3, c_k0 = 8 * c_kg;
-    float* dU_dst = p.dU_part + (((long)b * p.Ad + a) * 2 + c_c) * KL + c_k0;
-    float dU_old[8];
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) dU_old[kk] = dU_dst[imin(kk, KL - 1 - c_k0)];
-    const float dv_old = p.dv_part[(long)b * p.Ad + a];
-    float dev[2];   // de for up to 1024 positions
-#pragma unroll
-    for (int i = 0; i < 2; ++i) dev[i] = p.de[(long)b * L + imin(tid + ENT * i, L - 1)];
-    stage_inp_U<ENT>(inp, Us, p.w_prev, p.ldwp, p.cum_prev, p.ldcp, p.U, p.th, b, j, L, Lp, tid);
-    for (int idx = tid; idx < 16 * Lp; idx += ENT) dsp[idx] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int l = tid + ENT * i;
-        if (l < L4) des[l] = l < L ? dev[i] : 0.f;
-    }
-    for (int l = tid + 1024; l < L4; l += ENT) des[l] = l < L ? p.de[(long)b * L + l] : 0.f;
-    __syncthreads();
-    T2_STAMP(p, stamp, 25);
-
-    // phase A: ds, dpmT accumulation (32 threads per dim)
-    for (int base = 0; base < NG; base += 32 * EMAXI) {
-#pragma unroll
-        for (int it = 0; it < EMAXI; ++it) {
-            const int lg = base + sub + 32 * it;
-            if (lg >= NG) continue;
-            if (base > 0) {
-                const f32x4 t4 = *reinterpret_cast<const f32x4*>(th_row + 4 * lg);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int l = imin(4 * lg + i, L - 1);
-                    thv[it][i] = t4[i];
-                    dpv[it][i] = p.dpmT[rowoff + l];
-                }
-            }
-            f32x4 d4 = {0.f, 0.f, 0.f, 0.f}, t4 = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 de4 = *reinterpret_cast<const f32x4*>(des + 4 * lg);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int l = 4 * lg + i;
-                if (l < L) {
-                    const float th = thv[it][i];
-                    d4[i] = de4[i] * va * (1.f - th * th);
-                    t4[i] = de4[i] * th;
-                    p.dpmT[rowoff + l] = dpv[it][i] + d4[i];
-                }
-            }
-            *reinterpret_cast<f32x4*>(dsp + al * Lp + DH + 4 * lg) = d4;
-            *reinterpret_cast<f32x4*>(tvs + al * L4 + 4 * lg) = t4;
-        }
-    }
-    __syncthreads();
-    T2_STAMP(p, stamp, 26);
-
-    {   // phase B: dq[a], dv[a]: 32 lanes per attention dim, 16-byte reads
-        float sq = 0.f, sv = 0.f;
-        for (int lg = sub; lg < NG; lg += 32) {
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dsp + al * Lp + DH + 4 * lg);
-            const f32x4 t4 = *reinterpret_cast<const f32x4*>(tvs + al * L4 + 4 * lg);
-            sq += (d4[0] + d4[1]) + (d4[2] + d4[3]);
-            sv += (t4[0] + t4[1]) + (t4[2] + t4[3]);
-        }
-        sq = t2_half_sum_hi(sq); sv = t2_half_sum_hi(sv);   // totals of the dim's 32 lanes land in its upper 16 lanes
-        if (sub == 31) {
-            p.dq[(long)b * p.lddq + a] = sq;
-            p.dv_part[(long)b * p.Ad + a] = dv_old + sv;
-        }
-    }
-
-    T2_STAMP(p, stamp, 27);
-    {   // phase C: dU[a][c][k0..k0+7] += sum_l ds[l] * in[c][l + k - 15]; 8 taps x 4 positions per register tile,
-        // a quarter of the position groups per thread, quarters combined by two shuffles
-        float out[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const float* dsr = dsp + al * Lp + DH;
-        const float* inr = inp + c_c * Lp + c_k0;          // padded index of in[c][l + k - 15] is l + k
-        for (int lg = c_lq; lg < NG; lg += 4) {
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dsr + 4 * lg);
-            float wv[12];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(inr + 4 * lg + 4 * i);
-                wv[4 * i] = t[0]; wv[4 * i + 1] = t[1]; wv[4 * i + 2] = t[2]; wv[4 * i + 3] = t[3];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk) out[kk] = fmaf(d4[i], wv[i + kk], out[kk]);
-        }
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            out[kk] = t2_quad_sum(out[kk]);
-        }
-        if (c_lq == 0) {
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
-                if (c_k0 + kk < KL) dU_dst[kk] = dU_old[kk] + out[kk];
-        }
-    }
-    T2_STAMP(p, stamp, 28);
-    __syncthreads();   // tvs (and the tail of dsp's region is NOT touched) is reused below
-
-    // phase D: d_in partial of THIS dim: dinq[al][c][l'] = sum_k ds[l' + 15 - k] * U[al][c][k].  Work items are (channel,
-    // 12 adjacent positions): for L <= 192 that is exactly one item per lane of the dim's 32 lanes.  The 12 positions are
-    // six v_pk_fma_f32 accumulators; ds[l' + 15 - k] = win[i + 31 - k], and the window pair at offset o = 31 - k is a register
-    // pair of the aligned 44-float LDS read for even o and a pair built with one v_pk_mov_b32 for odd o; the taps of the
-    // lane's channel are read from LDS per lane (186 packed FMAs + 11 LDS reads per item, against 3 x 175 instructions for
-    // three 4-position items before).
-    float* dinq = tvs;   // [16][2][L4] over tvs + des + extension
-    {
-        const int NI = (L + 11) / 12;
-        for (int item = sub; item < 2 * NI; item += 32) {
-            const int c = item >= NI ? 1 : 0, ig = item - c * NI;
-            float ukc[32];
-            {
-                const f32x4* up = reinterpret_cast<const f32x4*>(Us + al * 64 + c * 32);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const f32x4 t = up[i];
-                    ukc[4 * i] = t[0]; ukc[4 * i + 1] = t[1]; ukc[4 * i + 2] = t[2]; ukc[4 * i + 3] = t[3];
-                }
-            }
-            f32x2 we[22], wo[21];
-            const f32x4* wp = reinterpret_cast<const f32x4*>(dsp + al * Lp + 12 * ig);   // padded index of ds[m] is m + 16
-#pragma unroll
-            for (int i = 0; i < 11; ++i) {
-                const f32x4 t = wp[i];
-                we[2 * i] = (f32x2){t[0], t[1]}; we[2 * i + 1] = (f32x2){t[2], t[3]};
-            }
-#pragma unroll
-            for (int m = 0; m < 21; ++m) wo[m] = (f32x2){we[m][1], we[m + 1][0]};
-            f32x2 a[6];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) a[q] = (f32x2){0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < KL; ++k) {
-                const f32x2 u = {ukc[k], ukc[k]};
-                const int o = 31 - k;
-                if ((o & 1) == 0) {
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) a[q] = __builtin_elementwise_fma(u, we[o / 2 + q], a[q]);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) a[q] = __builtin_elementwise_fma(u, wo[o / 2 + q], a[q]);
-                }
-            }
-            float* dst = dinq + (al * 2 + c) * L4 + 12 * ig;
-#pragma unroll
-            for (int q4 = 0; q4 < 3; ++q4)
-                if (12 * ig + 4 * q4 < L4)
-                    *reinterpret_cast<f32x4*>(dst + 4 * q4) = (f32x4){a[2 * q4][0], a[2 * q4][1], a[2 * q4 + 1][0], a[2 * q4 + 1][1]};
-        }
-    }
-    __syncthreads();
-    T2_STAMP(p, stamp, 29);
-    for (int idx = tid; idx < 2 * L; idx += ENT) {
-        const int c = idx >= L ? 1 : 0, l = idx - c * L;
-        float s2 = 0.f;
-#pragma unroll
-        for (int al2 = 0; al2 < 16; ++al2) s2 += dinq[(al2 * 2 + c) * L4 + l];
-        p.din_part_out[(((long)b * (p.Ad >> 4) + j) * 2 + c) * L + l] = s2;
-    }
-    T2_STAMP(p, stamp, 30);
-}
-
-__global__ __launch_bounds__(ENT, 2) void attn_bwd_ds_kernel(AttnBwdK p) {
-    T2_CHAIN_PRIO();
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    attn_bwd_ds_body(p, blockIdx.x, blockIdx.y, sm);
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------------
-// The ds kernel with both correlations on the bf16 matrix pipe (L <= 256; exactly split operands, six products - the scheme of the
-// energies kernel).  Phases A / B as attn_bwd_ds_body (ds, dpmT, dq, dv), then
+// The per-slice kernel: both correlations on the bf16 matrix pipe (exactly split operands, six products - the scheme of the energies
+// kernel).  Phases A / B: ds, dpmT, dq, dv (32 threads per attention dim), then
 //   dU   (phase C)  dU[a][(c,k)] += sum_l ds[a][l] * IN[l][(c,k)],  IN[l][(c,k)] = in[c][l + k - 15]: M = the slice's 16 dims,
 //                   N = 4 tiles of 16 (c,k) columns, K = positions; 24 (tile, k-step) pairs over 8 waves, the two K halves of a tile
 //                   meet in LDS;
@@ -1091,8 +780,17 @@ __global__ __launch_bounds__(ENT, 2) void attn_bwd_ds_kernel(AttnBwdK p) {
 // fragments - 8 consecutive elements from x = 8 (m + rb + 1) - and the dU fragments - from x = 32 ks + 8 q - are then aligned
 // 16-byte items, one ds_read_b128 per plane, rows an odd number of items apart), written by the threads that compute it; the haloed
 // inputs as neighbour pairs with their own halo of 40 (stage_commit_split), so that in[c][l + k - 15] sits at index x + k.
-// 1.4 + 1.8 us of packed-FMA loops before.
+// (1.4 + 1.8 us of packed-FMA loops in rounds 1-2; that kernel was the only path above 252 positions until round 4.)
+//
+// One pass covers 252 positions.  Longer texts (TILED) are walked in position tiles INSIDE the launch: tile i owns the positions
+// [216 i, 216 (i + 1)) - its ds, dpmT, dq, dv, dU terms - and runs the same code on the window that reaches 16 positions further on
+// either side, with the energy gradients outside the owned range set to zero: the d_in of a window is then exactly the contribution
+// of the tile's ds to the positions it can reach through the 31-tap filter, and the windows' d_in are added up in an LDS image of the
+// whole text (8 bytes per position).  dq, dv and the dU accumulators simply run on across the tiles.
 constexpr int DSH = 25;      // halo of the ds planes
+constexpr int DS_ONE = 252;  // positions of one pass
+constexpr int DS_TI = 216;   // positions a tile owns (a multiple of 8: window origins stay aligned for the 16-byte stash reads)
+constexpr int DS_MARGIN = 16;
 
 __global__ void attn_bwd_prep_kernel(const float* U, unsigned* bd, int Ad) {
     // bd[((j*20 + ks)*3 + plane)*64 + lane] (16 bytes each): lane (n = (c, s), q) holds B[(a, r = 8 rb + jj)][(c, s)] = U[a][c][32 - r + s]
@@ -1108,15 +806,6 @@ __global__ void attn_bwd_prep_kernel(const float* U, unsigned* bd, int Ad) {
     const Split8 sp = t2_split8(v);
     u32x4v* o = reinterpret_cast<u32x4v*>(bd) + ((long)(j * 20 + ks) * 3) * 64 + lane;
     o[0] = __builtin_bit_cast(u32x4v, sp.h); o[64] = __builtin_bit_cast(u32x4v, sp.m); o[128] = __builtin_bit_cast(u32x4v, sp.l);
-    if (ks < 2) {      // filter rows of the forward convolution as its B operand (recomputation of the tanh terms): channel c = ks,
-        const int c2 = ks;   // lane (n = dim, q) holds U[a = n][c][8 q + jj], tap 31 = 0; stored behind the d_in planes
-        float u[8];
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) u[jj] = (8 * q + jj) < KL ? U[((long)(j * 16 + n) * 2 + c2) * KL + 8 * q + jj] : 0.f;
-        const Split8 su = t2_split8(u);
-        u32x4v* ou = reinterpret_cast<u32x4v*>(bd) + (long)(Ad >> 4) * 20 * 3 * 64 + ((long)(j * 2 + c2) * 3) * 64 + lane;
-        ou[0] = __builtin_bit_cast(u32x4v, su.h); ou[64] = __builtin_bit_cast(u32x4v, su.m); ou[128] = __builtin_bit_cast(u32x4v, su.l);
-    }
 }
 
 struct DsDims { int NG, L4, M8, MT, KS, S16, LpI; };
@@ -1131,15 +820,8 @@ __host__ __device__ inline DsDims ds_dims(int L) {
     return d;
 }
 
-// RECOMP: the tanh terms are not read from a stash of the forward but recomputed here - stashed query projection (128 values per
-// frame and sample) + location convolution on the matrix pipe (as attn_energy_body, from the input planes this kernel stages anyway,
-// filter fragments from attn_bwd_prep_kernel) + processed memory, tanh.  The forward then neither writes nor keeps the stash
-// (2.7 GB per training step at the bench shape).  It is an OPTION (Engine.attn_bwd_recompute): this kernel reaches its first barrier
-// 1.1 us later, and the forward chain gains only 0.2 us per frame from the missing write-back.
-template <bool RECOMP>
-__global__ __launch_bounds__(ENT, 4) void attn_bwd_ds_mfma_kernel(AttnBwdK p) {
-    T2_CHAIN_PRIO();
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+template <bool TILED>
+__device__ __forceinline__ void attn_bwd_ds_mfma_body(const AttnBwdK& p, float* sm) {
     const int b = blockIdx.x, j = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
     [[maybe_unused]] const bool stamp = b == 0 && j == 0 && tid == 0;
@@ -1148,170 +830,124 @@ __global__ __launch_bounds__(ENT, 4) void attn_bwd_ds_mfma_kernel(AttnBwdK p) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int al = tid >> 5, sub = tid & 31, a = j * 16 + al;
     const int n = lane & 15, q = lane >> 4;
-    const int L = p.L;
-    const DsDims dd = ds_dims(L);
-    const int L4 = dd.L4, M8 = dd.M8, MT = dd.MT, KS = dd.KS, S16 = dd.S16, LpI = dd.LpI;
-    // position groups of phase A: group g = positions 4g - 1 .. 4g + 2, i.e. elements x = 24 + 4g .. 27 + 4g of a ds row: one aligned
-    // 8-byte store per plane (the tanh stash rows are read from 4 g - 1: dword-aligned 16-byte global loads)
-    const int NGA = (L + 4) >> 2;                            // groups 0 .. NGA - 1 cover positions -1 .. L - 1 (<= 64 for L <= 252)
+    const int Lg = p.L, Lg4 = (Lg + 3) & ~3;                 // the whole text
+    // LDS layout: sized for the longest window of the launch (one pass: the text itself)
+    const DsDims dm = ds_dims(TILED ? imin(Lg, DS_TI + 2 * DS_MARGIN) : Lg);
+    const int S16 = dm.S16, LpI = dm.LpI;
     u32x4v* DX = reinterpret_cast<u32x4v*>(sm);              // [3][16][S16] items of 8 bf16
     unsigned* PX = reinterpret_cast<unsigned*>(DX + 48 * S16);   // [3][2*LpI] neighbour pairs, in[c][l'] at index l' + 40
-    float* des = reinterpret_cast<float*>(PX + 6 * LpI);     // [4 + L4 + 4]: de[l] at index l + 1 (zero at 0 and past L)
-    float* redC = des + L4 + 8;                              // [4][256]   phase C: second K half of each (c,k) tile
+    float* des = reinterpret_cast<float*>(PX + 6 * LpI);     // [4 + L4 + 4]: de[l] at index l + 1 (zero at 0, past L and outside the owned range)
+    float* redC = des + dm.L4 + 8;                           // [4][256]   phase C: second K half of each (c,k) tile
+    float* dinacc = redC + 4 * 256;                          // TILED: [2][Lg4] d_in of this slice over the whole text
     float* red = reinterpret_cast<float*>(DX);               // [8][MT][256] phase D: the waves' K shares (aliases DX after the MFMAs)
-    const int TS = 4 * (((L4 >> 2) + 3) | 1);                // RECOMP: row stride of the recomputed tanh terms (an odd number of 16-byte items)
-    float* th_s = redC + 4 * 256;                            // RECOMP: [16][TS]
-    const long rowoff = ((long)b * p.Ad + a) * L;
-    // ---- issue: the energy gradients first (the only operand that depends on the previous launch), tanh stash / old dpmT,
-    //      location inputs, old accumulator values, the d_in filter fragments ----
-    float dev[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) dev[i] = p.de[(long)b * L + imin(tid + ENT * i, L - 1)];
-    float thv[EMAXI][4], dpv[EMAXI][4];
+    const long rowoff = ((long)b * p.Ad + a) * Lg;
     const float va = p.v[a];
+    const float* th_base = p.th + ((long)b * p.Ad + a) * Lg4;
+    // phase C result ownership of waves 0..3: tile nt = w, lane holds dims 4q + r, column n -> (c, k)
+    const int c_nt = w & 3, c_c = c_nt >> 1, c_k = 16 * (c_nt & 1) + n;
+    float sq = 0.f, sv = 0.f;                                // dq, dv of this thread's positions (all tiles)
+    f32x4 ch0 = {0.f, 0.f, 0.f, 0.f}, cl0 = ch0, cl1 = ch0, cl2 = ch0;     // dU accumulators (all tiles)
+    u32x4v bdv[3][3];
+    float dv_old = 0.f, dU_old[4] = {0.f, 0.f, 0.f, 0.f};
+    const int ntile = TILED ? (Lg + DS_TI - 1) / DS_TI : 1;
+    if (TILED) {
+        for (int i = tid; i < 2 * Lg4; i += ENT) dinacc[i] = 0.f;
+    }
+    for (int tile = 0; tile < ntile; ++tile) {
+        // owned positions [a0, b0), window [v0, v1) in text coordinates; everything below runs in window coordinates l = 0 .. L-1
+        const int a0 = TILED ? tile * DS_TI : 0, b0 = TILED ? imin(a0 + DS_TI, Lg) : Lg;
+        const int v0 = TILED ? imax(a0 - DS_MARGIN, 0) : 0, v1 = TILED ? imin(b0 + DS_MARGIN, Lg) : Lg;
+        const int L = v1 - v0, ia = a0 - v0, ib = b0 - v0;
+        const DsDims dd = TILED ? ds_dims(L) : dm;
+        const int L4 = dd.L4, M8 = dd.M8, MT = dd.MT, KS = dd.KS;
+        // position groups of phase A: group g = positions 4g - 1 .. 4g + 2, i.e. elements x = 24 + 4g .. 27 + 4g of a ds row: one aligned
+        // 8-byte store per plane (the tanh stash rows are read from 4 g - 1: dword-aligned 16-byte global loads)
+        const int NGA = (L + 4) >> 2;                        // groups 0 .. NGA - 1 cover positions -1 .. L - 1 (<= 64 for L <= 252)
+        // ---- issue: the energy gradients first (the only operand that depends on the previous launch), tanh stash / old dpmT,
+        //      location inputs, old accumulator values, the d_in filter fragments ----
+        float dev[TILED ? 1 : 2];
 #pragma unroll
-    for (int it = 0; it < EMAXI; ++it) {
-        const int g = imin(sub + 32 * it, NGA - 1);
-        if (!RECOMP) {
+        for (int i = 0; i < (TILED ? 1 : 2); ++i) dev[i] = p.de[(long)b * Lg + v0 + imin(tid + ENT * i, L - 1)];
+        float thv[EMAXI][4], dpv[EMAXI][4];
+        const float* th_row = th_base + v0;                  // (v0 is a multiple of 8: 16-byte items stay aligned)
+#pragma unroll
+        for (int it = 0; it < EMAXI; ++it) {
+            const int g = imin(sub + 32 * it, NGA - 1);
             // positions 4g - 1 .. 4g + 2: one scalar + the aligned quad of positions 4g .. 4g + 3 (clamped; unused elements are guarded)
-            const float* th_row = p.th + ((long)b * p.Ad + a) * L4;
             const f32x4 t4 = *reinterpret_cast<const f32x4*>(th_row + imin(4 * g, L4 - 4));
             thv[it][0] = th_row[imax(4 * g - 1, 0)];
             thv[it][1] = t4[0]; thv[it][2] = t4[1]; thv[it][3] = t4[2];
         }
-    }
-    auto load_dp = [&]() {      // old dpmT values of this thread's positions (written by the previous frame's launch: L2)
 #pragma unroll
-        for (int it = 0; it < EMAXI; ++it) {
+        for (int it = 0; it < EMAXI; ++it) {                 // old dpmT values of this thread's positions (previous frame's launch: L2)
             const int g = imin(sub + 32 * it, NGA - 1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dpv[it][i] = p.dpmT[rowoff + imin(imax(4 * g - 1 + i, 0), L - 1)];
+            for (int i = 0; i < 4; ++i) dpv[it][i] = p.dpmT[rowoff + v0 + imin(imax(4 * g - 1 + i, 0), L - 1)];
         }
-    };
-    load_dp();
-    // phase C result ownership of waves 0..3: tile nt = w, lane holds dims 4q + r, column n -> (c, k)
-    const int c_nt = w & 3, c_c = c_nt >> 1, c_k = 16 * (c_nt & 1) + n;
-    const float dv_old = p.dv_part[(long)b * p.Ad + a];
-    StageRegs<ENT> sr;
-    stage_issue<ENT, true, false>(sr, p.w_prev, p.ldwp, p.cum_prev, p.ldcp, p.U, p.dpmT, b, j, L, LpI, tid, 40);
-    u32x4v bdv[3][3];
-    const u32x4v* bdp = reinterpret_cast<const u32x4v*>(p.bd) + (long)j * 20 * 3 * 64 + lane;
-    auto load_bd = [&]() {     // this wave's d_in filter fragments (k-steps w, w + 8, w + 16 < 20): from L2, independent of the chain
+        if (tile == 0) dv_old = p.dv_part[(long)b * p.Ad + a];
+        StageRegs<ENT> sr;
+        stage_issue<ENT, true, false>(sr, p.w_prev, p.ldwp, p.cum_prev, p.ldcp, p.U, p.dpmT, b, j, Lg, LpI, tid, 40, v0);
+        if (tile == 0) {       // this wave's d_in filter fragments (k-steps w, w + 8, w + 16 < 20): from L2, independent of the chain
+            const u32x4v* bdp = reinterpret_cast<const u32x4v*>(p.bd) + (long)j * 20 * 3 * 64 + lane;
 #pragma unroll
-        for (int ki = 0; ki < 3; ++ki) {
-            const int ks = imin(w + 8 * ki, 19);
+            for (int ki = 0; ki < 3; ++ki) {
+                const int ks = imin(w + 8 * ki, 19);
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) bdv[ki][pl] = bdp[(ks * 3 + pl) * 64];
-        }
-    };
-    if (!RECOMP) load_bd();
-    // RECOMP operands: filter fragments of the convolution, processed memory of this wave's two position tiles, query operands
-    const int an = j * 16 + n;                                  // the dim this lane holds in the MFMA layouts
-    u32x4v ubv[2][3];
-    float pmv[2][4];
-    float qa = 0.f;
-    if (RECOMP) {
-        const u32x4v* ubp = reinterpret_cast<const u32x4v*>(p.ub) + (long)j * 2 * 3 * 64 + lane;
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) ubv[c][pl] = ubp[(c * 3 + pl) * 64];
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int lg = imin(4 * (w + 8 * it) + q, dd.NG - 1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) pmv[it][i] = p.pmT[((long)b * p.Ad + an) * L + imin(4 * lg + i, L - 1)];
-        }
-        qa = p.qproj[(long)b * p.Ad + an];
-    }
-    for (int i = tid; i < 48 * S16; i += ENT) DX[i] = (u32x4v){0u, 0u, 0u, 0u};     // halo and tail of the ds planes
-    stage_commit_split<ENT, false>(sr, PX, nullptr, p.w_prev, p.ldwp, p.cum_prev, p.ldcp, p.dpmT, b, L, LpI, tid, 40);
-    if (RECOMP) {
-        __syncthreads();     // input planes visible (none of this depends on the previous launch)
-        // location convolution of this wave's position tiles mt = w, w + 8: IN[l = 16 mt + n][(c, 8 q + jj)] = in[c][l + 8q + jj - 15]
-        // = input index c*LpI + l + 8q + jj + 25
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int mt = w + 8 * it;
-            if (16 * mt < L) {
-                f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, l0 = h0, l1 = h0, l2 = h0;
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const unsigned* ap = PX + c * LpI + 16 * mt + n + 8 * q + 25;
-                    Split8 fa, fb;
-                    fa.h = __builtin_bit_cast(bf16x8, (u32x4v){ap[0], ap[2], ap[4], ap[6]});
-                    fa.m = __builtin_bit_cast(bf16x8, (u32x4v){ap[2 * LpI], ap[2 * LpI + 2], ap[2 * LpI + 4], ap[2 * LpI + 6]});
-                    fa.l = __builtin_bit_cast(bf16x8, (u32x4v){ap[4 * LpI], ap[4 * LpI + 2], ap[4 * LpI + 4], ap[4 * LpI + 6]});
-                    fb.h = __builtin_bit_cast(bf16x8, ubv[c][0]); fb.m = __builtin_bit_cast(bf16x8, ubv[c][1]); fb.l = __builtin_bit_cast(bf16x8, ubv[c][2]);
-                    l0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.l, fb.h, l0, 0, 0, 0);
-                    l1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.l, l1, 0, 0, 0);
-                    l2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.m, fb.m, l2, 0, 0, 0);
-                    l0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.m, fb.h, l0, 0, 0, 0);
-                    l1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.m, l1, 0, 0, 0);
-                    h0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.h, h0, 0, 0, 0);
-                }
-                const f32x4 loc = h0 + ((l0 + l1) + l2);
-                f32x4 t4;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) t4[i] = t2_tanh(qa + loc[i] + pmv[it][i]);
-                *reinterpret_cast<f32x4*>(th_s + n * TS + 16 * mt + 4 * q) = t4;      // positions 16 mt + 4 q + i of dim n
+                for (int pl = 0; pl < 3; ++pl) bdv[ki][pl] = bdp[(ks * 3 + pl) * 64];
             }
         }
-        load_bd();
-    }
+        for (int i = tid; i < 48 * S16; i += ENT) DX[i] = (u32x4v){0u, 0u, 0u, 0u};     // halo and tail of the ds planes
+        stage_commit_split<ENT, false>(sr, PX, nullptr, p.w_prev, p.ldwp, p.cum_prev, p.ldcp, p.dpmT, b, Lg, LpI, tid, 40, v0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int l = tid + ENT * i;
-        if (l < L4 + 7) des[l + 1] = l < L ? dev[i] : 0.f;
-    }
-    if (tid == 0) des[0] = 0.f;
-    __syncthreads();
-    T2_STAMP(p, stamp, 25);
-
-    // ---- phase A: ds -> its bf16 planes, dpmT accumulation; phase B sums in registers ----
-    float sq = 0.f, sv = 0.f;
-    {
-        uint2* dx64 = reinterpret_cast<uint2*>(DX);
-#pragma unroll
-        for (int it = 0; it < EMAXI; ++it) {
-            const int g = sub + 32 * it;
-            if (g >= NGA) continue;
-            f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 de4 = *reinterpret_cast<const f32x4*>(des + 4 * g);      // de[4g - 1 .. 4g + 2]
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int l = 4 * g - 1 + i;
-                if (l >= 0 && l < L) {
-                    const float th = RECOMP ? th_s[al * TS + l] : thv[it][i];
-                    d4[i] = de4[i] * va * (1.f - th * th);
-                    sv += de4[i] * th;
-                    p.dpmT[rowoff + l] = dpv[it][i] + d4[i];
-                }
-            }
-            sq += (d4[0] + d4[1]) + (d4[2] + d4[3]);
-            const Split3 s3 = split3_attn(d4);     // packed (d0,d1), (d2,d3) of every plane: elements x = 24 + 4g .. 27 + 4g
-            const int o = al * S16 * 2 + 6 + g;    // 8-byte items: row base + (24 + 4 g) / 4
-            dx64[o] = s3.h; dx64[16 * S16 * 2 + o] = s3.m; dx64[32 * S16 * 2 + o] = s3.l;
+        for (int i = 0; i < (TILED ? 1 : 2); ++i) {
+            const int l = tid + ENT * i;
+            if (l < dm.L4 + 7) des[l + 1] = (l >= ia && l < ib) ? dev[i] : 0.f;
         }
-    }
-    sq = t2_half_sum_hi(sq); sv = t2_half_sum_hi(sv);   // totals of the dim's 32 lanes land in its upper 16 lanes
-    if (sub == 31) {
-        p.dq[(long)b * p.lddq + a] = sq;
-        p.dv_part[(long)b * p.Ad + a] = dv_old + sv;
-    }
-    __syncthreads();
-    T2_STAMP(p, stamp, 26);
-    float dU_old[4] = {0.f, 0.f, 0.f, 0.f};      // old accumulator values: consumed after both MFMA phases
-    if (w < 4 && c_k < KL) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dU_old[r] = p.dU_part[(((long)b * p.Ad + j * 16 + 4 * q + r) * 2 + c_c) * KL + c_k];
-    }
+        if (tid == 0) des[0] = 0.f;
+        __syncthreads();
+        T2_STAMP(p, stamp, 25);
 
-    // ---- phase C: dU tile c_nt, k-steps (w >> 2), +2, +4, ...: A[a = n][x = 32 ks + 8 q + jj] (ds[l = x - 25]),
-    //      B[x][(c,k)] = in[c][l + k - 15] = input index x + k ----
-    f32x4 cC;
-    {
-        f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, l0 = h0, l1 = h0, l2 = h0;
+        // ---- phase A: ds -> its bf16 planes, dpmT accumulation; phase B sums in registers ----
+        {
+            uint2* dx64 = reinterpret_cast<uint2*>(DX);
+#pragma unroll
+            for (int it = 0; it < EMAXI; ++it) {
+                const int g = sub + 32 * it;
+                if (g >= NGA) continue;
+                f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 de4 = *reinterpret_cast<const f32x4*>(des + 4 * g);      // de[4g - 1 .. 4g + 2]
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int l = 4 * g - 1 + i;
+                    if (l >= ia && l < ib) {
+                        const float th = thv[it][i];
+                        d4[i] = de4[i] * va * (1.f - th * th);
+                        sv += de4[i] * th;
+                        p.dpmT[rowoff + v0 + l] = dpv[it][i] + d4[i];
+                    }
+                }
+                sq += (d4[0] + d4[1]) + (d4[2] + d4[3]);
+                const Split3 s3 = split3_attn(d4);     // packed (d0,d1), (d2,d3) of every plane: elements x = 24 + 4g .. 27 + 4g
+                const int o = al * S16 * 2 + 6 + g;    // 8-byte items: row base + (24 + 4 g) / 4
+                dx64[o] = s3.h; dx64[16 * S16 * 2 + o] = s3.m; dx64[32 * S16 * 2 + o] = s3.l;
+            }
+        }
+        if (!TILED) {       // one pass: the sums are complete - out before the MFMA phases (the cell-backward launch waits for dq)
+            sq = t2_half_sum_hi(sq); sv = t2_half_sum_hi(sv);   // totals of the dim's 32 lanes land in its upper 16 lanes
+            if (sub == 31) {
+                p.dq[(long)b * p.lddq + a] = sq;
+                p.dv_part[(long)b * p.Ad + a] = dv_old + sv;
+            }
+        }
+        __syncthreads();
+        T2_STAMP(p, stamp, 26);
+        if (tile == 0 && w < 4 && c_k < KL) {      // old accumulator values: consumed after the last tile's MFMA phases
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dU_old[r] = p.dU_part[(((long)b * p.Ad + j * 16 + 4 * q + r) * 2 + c_c) * KL + c_k];
+        }
+
+        // ---- phase C: dU tile c_nt, k-steps (w >> 2), +2, +4, ...: A[a = n][x = 32 ks + 8 q + jj] (ds[l = x - 25]),
+        //      B[x][(c,k)] = in[c][l + k - 15] = input index x + k ----
         for (int ks = w >> 2; ks < KS + 1; ks += 2) {            // x runs to 25 + L - 1 < 32 (KS + 1)
             const int it = n * S16 + 4 * ks + q;
             Split8 fa, fb;
@@ -1320,114 +956,134 @@ __global__ __launch_bounds__(ENT, 4) void attn_bwd_ds_mfma_kernel(AttnBwdK p) {
             fb.h = __builtin_bit_cast(bf16x8, (u32x4v){bp[0], bp[2], bp[4], bp[6]});
             fb.m = __builtin_bit_cast(bf16x8, (u32x4v){bp[2 * LpI], bp[2 * LpI + 2], bp[2 * LpI + 4], bp[2 * LpI + 6]});
             fb.l = __builtin_bit_cast(bf16x8, (u32x4v){bp[4 * LpI], bp[4 * LpI + 2], bp[4 * LpI + 4], bp[4 * LpI + 6]});
-            l0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.l, fb.h, l0, 0, 0, 0);
-            l1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.l, l1, 0, 0, 0);
-            l2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.m, fb.m, l2, 0, 0, 0);
-            l0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.m, fb.h, l0, 0, 0, 0);
-            l1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.m, l1, 0, 0, 0);
-            h0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.h, h0, 0, 0, 0);
+            cl0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.l, fb.h, cl0, 0, 0, 0);
+            cl1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.l, cl1, 0, 0, 0);
+            cl2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.m, fb.m, cl2, 0, 0, 0);
+            cl0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.m, fb.h, cl0, 0, 0, 0);
+            cl1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.m, cl1, 0, 0, 0);
+            ch0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.h, ch0, 0, 0, 0);
         }
-        cC = h0 + ((l0 + l1) + l2);
+        T2_STAMP(p, stamp, 28);
+        // ---- phase D: d_in, this wave's K share (k-steps w, w + 8, w + 16) for the MT row tiles:
+        //      A[m][(a, r = 8 rb + jj)] = ds[a][8 m + r - 17] = element x = 8 (m + rb + 1) + jj of dim a ----
+        f32x4 cD[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, l0 = h0, l1 = h0, l2 = h0;
+            if (mt < MT) {
+                const int m = imin(16 * mt + n, M8 - 1);
+#pragma unroll
+                for (int ki = 0; ki < 3; ++ki) {
+                    const int ks = w + 8 * ki;
+                    if (ks < 20) {
+                        const int blk = 4 * ks + q, ad = blk / 5, rb = blk - 5 * ad;
+                        const int it = ad * S16 + m + rb + 1;
+                        Split8 fa, fb;
+                        fa.h = __builtin_bit_cast(bf16x8, DX[it]); fa.m = __builtin_bit_cast(bf16x8, DX[16 * S16 + it]); fa.l = __builtin_bit_cast(bf16x8, DX[32 * S16 + it]);
+                        fb.h = __builtin_bit_cast(bf16x8, bdv[ki][0]); fb.m = __builtin_bit_cast(bf16x8, bdv[ki][1]); fb.l = __builtin_bit_cast(bf16x8, bdv[ki][2]);
+                        l0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.l, fb.h, l0, 0, 0, 0);
+                        l1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.l, l1, 0, 0, 0);
+                        l2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.m, fb.m, l2, 0, 0, 0);
+                        l0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.m, fb.h, l0, 0, 0, 0);
+                        l1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.m, l1, 0, 0, 0);
+                        h0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.h, h0, 0, 0, 0);
+                    }
+                }
+            }
+            cD[mt] = h0 + ((l0 + l1) + l2);
+        }
+        __syncthreads();      // every wave has read its last ds fragment: the planes' memory becomes the reduction buffer
+        T2_STAMP(p, stamp, 27);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            if (mt < MT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[((w * MT + mt) * 16 + 4 * q + r) * 16 + n] = cD[mt][r];
+            }
+        }
+        __syncthreads();
+        T2_STAMP(p, stamp, 29);
+        for (int o = tid; o < MT * 256; o += ENT) {
+            const int mt = o >> 8, ml = (o >> 4) & 15, nn = o & 15;
+            float s2 = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) s2 += red[((ww * MT + mt) * 16 + ml) * 16 + nn];
+            const int m = 16 * mt + ml, l = 8 * m + (nn & 7);
+            if (m < M8 && l < L) {
+                if (TILED) dinacc[(nn >> 3) * Lg4 + v0 + l] += s2;      // (one thread per (channel, position) and tile; tiles are sequential)
+                else p.din_part_out[(((long)b * (p.Ad >> 4) + j) * 2 + (nn >> 3)) * Lg + l] = s2;
+            }
+        }
+        if (TILED) __syncthreads();     // `red` (the ds planes' memory) is rewritten by the next tile
     }
+    // ---- totals over all positions: dq, dv (32 lanes per dim), dU (two K halves of every (c,k) tile) ----
+    if (TILED) {
+        sq = t2_half_sum_hi(sq); sv = t2_half_sum_hi(sv);
+        if (sub == 31) {
+            p.dq[(long)b * p.lddq + a] = sq;
+            p.dv_part[(long)b * p.Ad + a] = dv_old + sv;
+        }
+    }
+    const f32x4 cC = ch0 + ((cl0 + cl1) + cl2);
     if (w >= 4) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) redC[c_nt * 256 + (4 * q + r) * 16 + n] = cC[r];
     }
-    T2_STAMP(p, stamp, 28);
-    // ---- phase D: d_in, this wave's K share (k-steps w, w + 8, w + 16) for the MT row tiles:
-    //      A[m][(a, r = 8 rb + jj)] = ds[a][8 m + r - 17] = element x = 8 (m + rb + 1) + jj of dim a ----
-    f32x4 cD[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, l0 = h0, l1 = h0, l2 = h0;
-        if (mt < MT) {
-            const int m = imin(16 * mt + n, M8 - 1);
-#pragma unroll
-            for (int ki = 0; ki < 3; ++ki) {
-                const int ks = w + 8 * ki;
-                if (ks < 20) {
-                    const int blk = 4 * ks + q, ad = blk / 5, rb = blk - 5 * ad;
-                    const int it = ad * S16 + m + rb + 1;
-                    Split8 fa, fb;
-                    fa.h = __builtin_bit_cast(bf16x8, DX[it]); fa.m = __builtin_bit_cast(bf16x8, DX[16 * S16 + it]); fa.l = __builtin_bit_cast(bf16x8, DX[32 * S16 + it]);
-                    fb.h = __builtin_bit_cast(bf16x8, bdv[ki][0]); fb.m = __builtin_bit_cast(bf16x8, bdv[ki][1]); fb.l = __builtin_bit_cast(bf16x8, bdv[ki][2]);
-                    l0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.l, fb.h, l0, 0, 0, 0);
-                    l1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.l, l1, 0, 0, 0);
-                    l2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.m, fb.m, l2, 0, 0, 0);
-                    l0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.m, fb.h, l0, 0, 0, 0);
-                    l1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.m, l1, 0, 0, 0);
-                    h0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.h, h0, 0, 0, 0);
-                }
-            }
-        }
-        cD[mt] = h0 + ((l0 + l1) + l2);
-    }
-    __syncthreads();      // every wave has read its last ds fragment: the planes' memory becomes the reduction buffer
-    T2_STAMP(p, stamp, 27);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        if (mt < MT) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[((w * MT + mt) * 16 + 4 * q + r) * 16 + n] = cD[mt][r];
-        }
-    }
-    if (w < 4 && c_k < KL) {      // dU: first K half (registers) + second (redC, visible since the barrier above)
+    __syncthreads();
+    if (w < 4 && c_k < KL) {      // first K half (registers) + second (redC)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             p.dU_part[(((long)b * p.Ad + j * 16 + 4 * q + r) * 2 + c_c) * KL + c_k] = dU_old[r] + cC[r] + redC[c_nt * 256 + (4 * q + r) * 16 + n];
     }
-    __syncthreads();
-    T2_STAMP(p, stamp, 29);
-    for (int o = tid; o < MT * 256; o += ENT) {
-        const int mt = o >> 8, ml = (o >> 4) & 15, nn = o & 15;
-        float s2 = 0.f;
-#pragma unroll
-        for (int ww = 0; ww < 8; ++ww) s2 += red[((ww * MT + mt) * 16 + ml) * 16 + nn];
-        const int m = 16 * mt + ml, l = 8 * m + (nn & 7);
-        if (m < M8 && l < L) p.din_part_out[(((long)b * (p.Ad >> 4) + j) * 2 + (nn >> 3)) * L + l] = s2;
+    if (TILED) {
+        for (int i = tid; i < 2 * Lg; i += ENT) {
+            const int c = i >= Lg ? 1 : 0, l = i - c * Lg;
+            p.din_part_out[(((long)b * (p.Ad >> 4) + j) * 2 + c) * Lg + l] = dinacc[c * Lg4 + l];
+        }
     }
     T2_STAMP(p, stamp, 30);
     T2_RING_END();
 }
 
-// dynamic LDS of the matrix-pipe ds kernel (floats: ds planes | input planes | de | phase-C exchange [| query | tanh terms])
-size_t ds_mfma_lds(const DsDims& dd, bool recomp) {
+// one pass (L <= 252): at most 128 VGPRs, so that two of its waves and a side-stream GEMM wave share a SIMD (section 4.5 of DESIGN.md)
+__global__ __launch_bounds__(ENT, 4) void attn_bwd_ds_mfma_kernel(AttnBwdK p) {
+    T2_CHAIN_PRIO();
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    attn_bwd_ds_mfma_body<false>(p, sm);
+}
+// position tiles (L > 252)
+__global__ __launch_bounds__(ENT, 2) void attn_bwd_ds_tiled_kernel(AttnBwdK p) {
+    T2_CHAIN_PRIO();
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    attn_bwd_ds_mfma_body<true>(p, sm);
+}
+
+// dynamic LDS of the per-slice kernel (floats: ds planes | input planes | de | phase-C exchange [| d_in image of the whole text])
+size_t ds_mfma_lds(int L) {
+    const bool tiled = L > DS_ONE;
+    const DsDims dd = ds_dims(tiled ? (L < DS_TI + 2 * DS_MARGIN ? L : DS_TI + 2 * DS_MARGIN) : L);
     size_t f = (size_t)48 * dd.S16 * 4 + 6 * dd.LpI + dd.L4 + 8 + 4 * 256;
-    if (recomp) f += (size_t)16 * 4 * (((dd.L4 >> 2) + 3) | 1);
+    if (tiled) f += (size_t)2 * ((L + 3) & ~3);
     return f * sizeof(float);
 }
 
 }  // namespace
 
-extern "C" int t2_attn_bwd_recomputes_th(int L, int Ad, int A) {
-    (void)A;
-    if (L < 1 || L > 252 || Ad % 16 != 0) return 0;
-    const DsDims dd = ds_dims(L);
-    return ds_mfma_lds(dd, true) <= 60 * 1024 && dd.MT <= 2 ? 1 : 0;
-}
-
 extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
     (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
     T2_REQUIRE(a != nullptr, "t2_attn_seq_bwd: null");
     T2_REQUIRE(a->Kl == KL && a->Ad % 16 == 0 && a->Ef % 32 == 0, "t2_attn_seq_bwd: unsupported dims");
-    T2_REQUIRE(a->L >= 1 && a->L <= 768, "t2_attn_seq_bwd: need 1 <= L <= 768 (LDS budget of the attention kernels)");
+    T2_REQUIRE(a->L >= 1, "t2_attn_seq_bwd: need L >= 1");
+    T2_REQUIRE(a->ws_bd && a->th, "t2_attn_seq_bwd: the filter workspace ws_bd and the forward's tanh stash th are required");
     hipStream_t st = (hipStream_t)stream;
     const int B = a->B, L = a->L, T = a->T, A = a->A, Ef = a->Ef, Ad = a->Ad, NA = Ad / 16;
     const long ldx = A + Ef;
-    const int NG = (L + 3) >> 2, Lp = 4 * NG + 36, L4 = 4 * NG;
     const size_t sm_dw = (size_t)((Ef > 640 ? Ef : 640) + ((L + 3) & ~3) + 8) * sizeof(float);
-    const size_t sm_ds = (size_t)(18 * Lp + 16 * 64 + 32 * L4) * sizeof(float);
-    T2_REQUIRE(t2_allow_lds(attn_bwd_ds_kernel, sm_ds), "t2_attn_seq_bwd: LDS budget exceeded");
-    // matrix-pipe build of the ds kernel: when the caller gives the workspace and its LDS image leaves room for a side-stream GEMM
-    // workgroup (96 KB) and a BPTT workgroup on the same CU (60 KB: L <= 208)
-    const DsDims dd = ds_dims(L);
-    const bool recomp = a->th == nullptr;      // no tanh stash: the matrix-pipe ds kernel recomputes the terms
-    const size_t sm_dsm = ds_mfma_lds(dd, recomp);
-    const bool ds_mfma = a->ws_bd != nullptr && L <= 252 && sm_dsm <= 60 * 1024 && dd.MT <= 2;
-    T2_REQUIRE(!recomp || (ds_mfma && a->pmT && a->qproj), "t2_attn_seq_bwd: without a tanh stash (th) the matrix-pipe kernel must "
-               "apply (t2_attn_bwd_recomputes_th) and pmT, qproj are required");
-    if (ds_mfma)
-        hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(NA, 20), dim3(64), 0, st, a->U, reinterpret_cast<unsigned*>(a->ws_bd), Ad);
+    const bool tiled = L > DS_ONE;
+    const size_t sm_dsm = ds_mfma_lds(L);
+    T2_REQUIRE(t2_allow_lds(attn_bwd_dw_kernel, sm_dw) && (tiled ? t2_allow_lds(attn_bwd_ds_tiled_kernel, sm_dsm) : t2_allow_lds(attn_bwd_ds_mfma_kernel, sm_dsm)),
+               "t2_attn_seq_bwd: the text is too long for the LDS images of the attention backward kernels");
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(NA, 20), dim3(64), 0, st, a->U, reinterpret_cast<unsigned*>(a->ws_bd), Ad);
     T2_REQUIRE(a->wtp_ctx && a->wtp_h, "t2_attn_seq_bwd: packed weight streams (t2_lstm_pack_bwd) are required");
     // Z[s][b] = [ dgates_s (4A) | dq_{s-1} (Ad) ], s = 0..T; slot T's dgates part is zero-filled by the caller, so the
     // backward step of frame t always reads ONE contiguous row Z[t+1] (no special case for the last frame).
@@ -1471,7 +1127,7 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         k.G_in = last ? nullptr : a->G + (long)((t + 1) & 1) * B * L;
         k.G_out = a->G + (long)(t & 1) * B * L;
         k.de = a->de;
-        k.th = a->th ? a->th + (long)t * B * Ad * ((L + 3) & ~3) : nullptr; k.v = a->v; k.U = a->U;
+        k.th = a->th + (long)t * B * Ad * ((L + 3) & ~3); k.v = a->v; k.U = a->U;
         if (t > 0) { k.w_prev = a->align + (long)(t - 1) * L; k.ldwp = (long)T * L; }
         k.cum_prev = a->cum + (long)t * B * L; k.ldcp = L;
         k.dpmT = a->dpmT; k.dq = Z + (long)(t + 1) * B * ldz + 4 * A; k.lddq = ldz;
@@ -1479,12 +1135,8 @@ extern "C" int t2_attn_seq_bwd(const T2AttnSeqBwd* a, void* stream) {
         k.clk = (unsigned long long*)a->clk;
         hipLaunchKernelGGL(attn_bwd_dw_kernel, dim3(B, t2_cdiv(L, 32)), dim3(256), sm_dw, st, k);
         k.bd = reinterpret_cast<const unsigned*>(a->ws_bd);
-        if (recomp) {
-            k.th = nullptr;
-            k.ub = k.bd + (long)NA * 20 * 3 * 64 * 4; k.pmT = a->pmT; k.qproj = a->qproj + (long)t * B * Ad;
-            hipLaunchKernelGGL(attn_bwd_ds_mfma_kernel<true>, dim3(B, NA), dim3(ENT), sm_dsm, st, k);
-        } else if (ds_mfma) hipLaunchKernelGGL(attn_bwd_ds_mfma_kernel<false>, dim3(B, NA), dim3(ENT), sm_dsm, st, k);
-        else hipLaunchKernelGGL(attn_bwd_ds_kernel, dim3(B, NA), dim3(ENT), sm_ds, st, k);
+        if (tiled) hipLaunchKernelGGL(attn_bwd_ds_tiled_kernel, dim3(B, NA), dim3(ENT), sm_dsm, st, k);
+        else hipLaunchKernelGGL(attn_bwd_ds_mfma_kernel, dim3(B, NA), dim3(ENT), sm_dsm, st, k);
         // (4) attention-LSTM cell backward: dh = (dh_ext + dgates_{t+1}.W_hh) + dq_t.Wq  (short K = Ad product + pointwise)
         T2LstmBwdStep c;
         memset(&c, 0, sizeof(c));

@@ -110,7 +110,8 @@ class Engine:
         self.chunk = 64               # frames per pipeline chunk of the forward frame loop
         self.chunk_bwd = 64           # frames per chunk of the backward pipeline (r03: 64 beats 80 by 0.2 ms with the BPTT launches at default wave priority)
         self.dec_chain = "persistent" # forward decoder-LSTM chain: "persistent" (one weight-stationary launch per chunk on the side
-                                      # stream) or "hosted" (its steps ride in the attention-energies launches)
+                                      # stream) or "steps" (one launch per frame there; also what runs when the persistent launch
+                                      # cannot be co-resident or the batch has more than 64 rows)
         self.persist_gemm_side = True    # the hoisted pre_dec GEMM of a chunk runs on the side stream too, in front of the chunk's
                                          # persistent launch (70.0 against 71.3 ms per step on the main stream, profiles/r02_ab_fwd_dec_chain.txt)
         self._persist_sync = None
@@ -124,11 +125,6 @@ class Engine:
         self.splitk_small_chunks = True  # forward pipeline: the hoisted decoder-LSTM input GEMM of short chunks runs split-K
         self.enc_chain = "persistent"    # encoder BiLSTM recurrence: "persistent" (one launch, both directions) | "steps" (S launches)
         self.enc_persist_max_rows = 32   # (the launch itself takes up to 64 rows, as two consecutive blocks)
-        self.attn_bwd_mfma = True     # attention backward: the per-slice kernel's correlations (dU, d_in) on the bf16 matrix pipe (T2AttnSeqBwd.ws_bd)
-        # ... which can also recompute the tanh terms (location convolution on the matrix pipe + stashed query projection + processed
-        # memory) instead of reading the forward's stash: 2.7 GB less memory per step at the bench shape, but +1.2 us per backward
-        # frame against -0.2 us per forward frame (64.0 vs 63.0 ms per step) - off by default, DESIGN.md section 4.4
-        self.attn_bwd_recompute = False
         self.bptt_off_chain = True    # the decoder-LSTM BPTT launches (side stream, a chunk ahead) keep the default wave priority
         self.sync_bn_group = None     # torch.distributed group: BatchNorm statistics over all ranks' shards (Trainer(sync_bn=True))
         self.grad_tail_hook = None    # called on the side stream once the gradients from prenet.0.weight onwards are enqueued
@@ -136,10 +132,6 @@ class Engine:
                                       # so only the LATEST forward can be back-propagated (checked in backward_tf)
         self.profile = False          # when True, mark() records HIP events at segment boundaries
         self.marks = []; self.spans = []               # [(name, event)] of the current step
-
-    def attn_bwd_recomputes_th(self, L: int, Ad: int, A: int) -> bool:
-        """True when the attention backward runs without the forward's tanh stash (t2_attn_bwd_recomputes_th)."""
-        return bool(self.attn_bwd_mfma and self.attn_bwd_recompute and _lib.call_value("t2_attn_bwd_recomputes_th", L, Ad, A) == 1)
 
     def persist_resident(self, D: int, B: int, n: int = 1) -> bool:
         """True when the persistent LSTM launch (n cells x H/4 workgroups that wait for each other) is fully co-resident on this
@@ -472,14 +464,10 @@ class Engine:
         dech_t = self.buf("dech_t", T + 1, D // 16, Bp, 16, zero=(B != Bp))
         dech_t[0].zero_()
         gates_att = self.buf("gates_att", T, B, 4 * A) if save_for_backward else None
-        # tanh terms of the energies: kept for the backward only when its per-slice kernel cannot recompute them (long texts, or
-        # the packed-FMA kernel) - the stash is [T][B][Ad][L4] floats, 2.7 GB per step at b=32, T=870, L=188
-        th = qproj = None
-        if save_for_backward:
-            if self.attn_bwd_recomputes_th(L, Ad, A):
-                qproj = self.buf("qproj", T, B, Ad)
-            else:
-                th = self.buf("th", T, B, Ad, (L + 3) // 4 * 4)
+        # tanh terms of the energies, kept for the backward: [T][B][Ad][L4] floats, 2.7 GB per step at b=32, T=870, L=188 - sized for
+        # 288 GB of HBM (a backward that recomputes them instead was built and measured in round 3: +1.0 ms per step,
+        # profiles/r03_ab_tanh_recompute.txt)
+        th = self.buf("th", T, B, Ad, (L + 3) // 4 * 4) if save_for_backward else None
         align = torch.empty(B, T, L, dtype=torch.float32, device=self.dev)
         e_part = self.buf("e_part", B, Ad // 16, L)
         # packed in the column order of the xdec row [att_h | ctx], so each step reads ONE contiguous activation segment
@@ -489,7 +477,7 @@ class Engine:
                    W_ih_ctx=_ptr(P["decoder.att_rnn.weight_ih"], Pd), ld_wih=Pd + Ef,
                    W_hh=P["decoder.att_rnn.weight_hh"], Wq=P["decoder.attention.query_layer.weight"], U=U,
                    v=P["decoder.attention.v.weight"], pre=pre_att, pmT=pmT, memory=memory, len=len32,
-                   att_drop=masks.get("att_drop"), xdec=xdec, att_c=att_c, gates=gates_att, align=align, cum=cum, th=th, qproj=qproj,
+                   att_drop=masks.get("att_drop"), xdec=xdec, att_c=att_c, gates=gates_att, align=align, cum=cum, th=th,
                    xproj_ctx=_ptr(xproj, B * (D + Ef) + D), ld_xproj=D + Ef, e_part=e_part, xdec_t=xdec_t)
         # decoder-LSTM chain operands (prepared before the pipeline below)
         pre_dec = self.buf("pre_dec", T, B, 4 * D)
@@ -500,12 +488,10 @@ class Engine:
         ldp = D + Ef
         wp_dec = self.pack_fwd("dec", [(P["decoder.lstm.weight_hh"], D, D)], D)
         # Software pipeline over chunks of CH frames.  In teacher-forced mode the attention chain never reads the decoder
-        # LSTM (model/decoder.py:70-101), so the decoder-LSTM chain of chunk i-1 is CO-SCHEDULED inside the attention chain of
-        # chunk i: its step rides in the attention-energies launch of a frame (extra workgroups in the same launch,
-        # T2AttnSeq.co_step), and the hoisted input-projection GEMM of a chunk runs on the main stream between chunks.
-        # Measured (tools/ubench_cell.hip, profiles/): step kernels of two streams do NOT overlap each other and two cells
-        # in one launch take the sum of their times, but a cell step next to the latency-bound energies workgroups does
-        # overlap.  Batches above 32 rows (no room for the hosted cell) fall back to a plain two-stream pipeline.
+        # LSTM (model/decoder.py:70-101): the attention chain of chunk i runs on the main stream while the decoder-LSTM chain of
+        # chunk i-1 - its hoisted input-projection GEMM, then the recurrence - runs on the side stream.  (Round 1 co-scheduled the
+        # decoder steps inside the attention-energies launches instead; that stretched every frame of the critical chain and was
+        # removed in round 4: profiles/r02_ab_fwd_dec_chain.txt.)
         CH = self.chunk
 
         def dec_chunk(c0, c1):
@@ -539,62 +525,36 @@ class Engine:
 
         main, side = torch.cuda.current_stream(), self.side_stream()
         side.wait_stream(main)
-        import ctypes as _C
         # Pipeline chunks; the LAST ones shrink (CH/2, CH/4, CH/8, CH/8): what follows the attention chain's end on the side stream
         # (the decoder-LSTM frames of the final chunk) is exposed time, proportional to that chunk's length.
         sizes = _chunk_sizes(T, CH, ramp_at_end=self.ramp_chunks)
         chunks, c0 = [], 0
         for n in sizes:
             chunks.append((c0, c0 + n)); c0 += n
-        co = B <= 32 and self.dec_chain == "hosted"     # the hosted cell needs <= 32 rows (register budget of the host kernel)
         persist = B <= 64 and self.dec_chain == "persistent" and D // 4 <= 256 and self.persist_resident(D, B)
         ctx["persist"] = persist
-        if persist:
-            # The decoder-LSTM chain of a chunk as ONE persistent, weight-stationary launch on the side stream
-            # (t2_lstm_seq_fwd_persist): W_hh stays in LDS, the workgroups exchange h through the tiled stash, and the
-            # attention chain on the main stream runs without hosted cells (energies launch 11 -> 7.5 us per frame).
-            sync = self.persist_sync()
-            for i, (c0, c1) in enumerate(chunks):
-                seq.t_begin, seq.t_end = c0, c1
-                seq.co_step, seq.co_inc, seq.co_steps = None, None, 0
-                call("t2_attn_seq_fwd", seq, st)
-                if not self.persist_gemm_side:
-                    pre_dec_gemm(c0, c1)
-                ev = main.record_event()
-                with torch.cuda.stream(side):
-                    side.wait_event(ev)
-                    if self.persist_gemm_side:
-                        SHARE_CU[0] = self.share_cu
-                        pre_dec_gemm(c0, c1)
-                        SHARE_CU[0] = 0
-                    stp, inc = dec_chunk(c0, c1)
-                    call("t2_lstm_seq_fwd_persist", stp, inc, c1 - c0, sync, side.cuda_stream)
-            chunks_done = True
-        else:
-            chunks_done = False
-        for i, (c0, c1) in enumerate([] if chunks_done else chunks):
+        sync = self.persist_sync() if persist else None
+        for i, (c0, c1) in enumerate(chunks):
             seq.t_begin, seq.t_end = c0, c1
-            if co and i >= 1:
-                stp, inc = dec_chunk(*chunks[i - 1])
-                seq.co_step, seq.co_inc = _C.pointer(stp), _C.pointer(inc)
-                seq.co_steps = chunks[i - 1][1] - chunks[i - 1][0]
-            else:
-                seq.co_step, seq.co_inc, seq.co_steps = None, None, 0
             call("t2_attn_seq_fwd", seq, st)
-            if co:
+            if persist and not self.persist_gemm_side:
                 pre_dec_gemm(c0, c1)
-            else:
-                ev = main.record_event()
-                with torch.cuda.stream(side):
-                    side.wait_event(ev)
+            ev = main.record_event()
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                if not persist or self.persist_gemm_side:
+                    SHARE_CU[0] = self.share_cu if persist else 0
                     pre_dec_gemm(c0, c1)
-                    stp, inc = dec_chunk(c0, c1)
+                    SHARE_CU[0] = 0
+                stp, inc = dec_chunk(c0, c1)
+                if persist:
+                    # The decoder-LSTM chain of a chunk as ONE persistent, weight-stationary launch (t2_lstm_seq_fwd_persist):
+                    # W_hh stays in LDS, the workgroups exchange h through the tiled stash
+                    call("t2_lstm_seq_fwd_persist", stp, inc, c1 - c0, sync, side.cuda_stream)
+                else:
                     call("t2_lstm_seq_fwd", stp, inc, 1, c1 - c0, side.cuda_stream)
         self.mark("fwd.dec.attn_chain")
         main.wait_stream(side)
-        if co:                                  # drain: the decoder-LSTM frames of the last chunk found no attention frame to ride in
-            stp, inc = dec_chunk(*chunks[-1])
-            call("t2_lstm_seq_fwd", stp, inc, 1, chunks[-1][1] - chunks[-1][0], st)
         self.mark("fwd.dec.lstm_chain_tail")
 
         # mel + stop projection over all frames: [mel_out.weight ; gate.weight] is one (M+1, D+Ef) matrix
@@ -633,7 +593,7 @@ class Engine:
                                  length=mlen32 if last else None, fill=0.0)
         self.mark("fwd.postnet")
         ctx.update(controls=ctl, pmT=pmT, mel_tm=mel_tm, p1=p1, p2=p2, pd=pd, pre_att=pre_att, U=U, xdec=xdec, att_c=att_c, cum=cum,
-                   xproj=xproj, gates_att=gates_att, th=th, qproj=qproj, align=align, pre_dec=pre_dec, dec_c=dec_c,
+                   xproj=xproj, gates_att=gates_att, th=th, align=align, pre_dec=pre_dec, dec_c=dec_c,
                    gates_dec=gates_dec, proj=proj, post_in=post_in, masks=masks, training=training)
         return (mels, post, gates, align), ctx
 
@@ -786,8 +746,7 @@ class Engine:
                   dh_ext=dxdec, ld_dh=ldx, dctx_ext1=_ptr(dxdec, A), ld_dc1=ldx, dctx_ext2=_ptr(dxproj, D), ld_dc2=ldp,
                   dgates=Z, dctx_tot=dctx_tot, dq=None, dpmT=dpmT, dv_part=dv_part, dU_part=dU_part,
                   dc=dc_att, G=Gc, de=de, din_part=din_part, dgates_t=Zt, clk=getattr(self, "clk_bwd", None),
-                  ws_bd=self.buf("attn.ws_bd", Ad // 16 * 16896) if self.attn_bwd_mfma else None, pmT=ctx["pmT"],
-                  qproj=ctx["qproj"])
+                  ws_bd=self.buf("attn.ws_bd", Ad // 16 * 16896))
         self.mark("bwd.dec.proj")
         main, side = torch.cuda.current_stream(), self.side_stream()
         side.wait_stream(main)

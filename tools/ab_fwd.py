@@ -1,5 +1,6 @@
 """A/B of the forward decoder-LSTM chain on the bench batch (GPU box): persistent weight-stationary launches on the side stream
-vs steps hosted in the attention-energies launches."""
+vs one launch per frame there (the round-1 variant with the steps hosted in the attention-energies launches was removed in
+round 4; its record: profiles/r02_ab_fwd_dec_chain.txt)."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import VANILLA
@@ -12,7 +13,7 @@ ps = ParamStore(VANILLA, dev); init_parameters(ps, 0)
 tr = Trainer(ps, lr=1e-3, weight_decay=1e-6)
 batch = {k: v.to(dev) for k, v in ljspeech_batch(32, seed=1234, num_speakers=4).items()}
 for rep in range(2):
-    for mode, chunk, gs in (("hosted", 64, False), ("persistent", 64, False), ("persistent", 64, True), ("persistent", 96, True)):
+    for mode, chunk, gs in (("steps", 64, True), ("persistent", 64, False), ("persistent", 64, True), ("persistent", 96, True)):
         tr.engine.dec_chain, tr.engine.chunk, tr.engine.persist_gemm_side = mode, chunk, gs
         for _ in range(3):
             tr.train_step(batch)
