@@ -193,20 +193,6 @@ typedef struct { int64_t dg, dg2, ext1, ext2, drop, gates, c_prev, c_cur; int dt
 /* S steps; every pointer advances by its stride each step.  The caller lays the dgates stash out with one extra
  * zero-filled slot so that base[i].dg_next (the slot 'after' the first processed step) is valid and zero. */
 int t2_lstm_seq_bwd(const T2LstmBwdStep* base, const T2LstmBwdStride* inc, int n, int S, void* stream);
-/* The same S steps of n = 1 or 2 independent cells (the two directions of the encoder BiLSTM, model/encoder.py:47-52,59-65) as ONE
- * persistent, weight-stationary launch - the mirror of t2_lstm_seq_fwd_persist_n: a workgroup owns 16 hidden units x 16 batch rows,
- * keeps its 16 columns of W_hh^T (K = 4H rows, 64 KB at H = 256) in LDS and the cell-state gradient in registers; what a step
- * needs from the other workgroups of its (cell, row tile) group is the gate gradient of the step before (16 rows x 4H floats),
- * exchanged through `xchg` (two x16-tiled slots per cell, ping-pong) with write-through stores, a sharded arrival counter and
- * sc1 loads.  Needs: epi = 1 descriptors on the packed path (wtpacked), N4 = 4H, H % 16 == 0, no dg2 / ext2 / drop, and a ZERO
- * gate gradient in front of the first step (base[i].dg_next is not read: the recurrence starts from zero, as the caller's
- * zero-filled slot says); dg_out / dg_out2 are written exactly as by the step launches, dgt_* are ignored.
- * n * (H/16) * ceil(min(B,32)/16) workgroups must be co-resident (T2_ERR_RESIDENCY otherwise; blocks of 32 rows run as
- * consecutive launches).  xchg: n * 2 * 4H * round_up(B,16) floats; sync: the scratch of t2_lstm_seq_fwd_persist (arrival
- * counters in words [0, 256), sticky timeout flag in word 256). */
-int t2_lstm_seq_bwd_persist(const T2LstmBwdStep* base, const T2LstmBwdStride* inc, int n, int S, float* xchg, uint32_t* sync,
-                            void* stream);
-int t2_lstm_persist_bwd_resident(int H, int B, int n);      /* residency check of the launch above (T2_OK / T2_ERR_RESIDENCY) */
 
 /* ------------------------------------------------------------------------------------------------
  * Location-sensitive attention, one frame (model/attention.py:52-69 + cumulative update model/decoder.py:78-90).

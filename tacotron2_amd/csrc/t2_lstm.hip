@@ -510,154 +510,6 @@ int launch_bwd(const T2LstmBwdStep* steps, int n, hipStream_t st, unsigned long 
     return T2_OK;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Persistent, weight-stationary BACKWARD recurrence: S steps of back-propagation through time of n independent cells in ONE
-// launch (the encoder BiLSTM: 188 launches of ~7 us before).  A workgroup owns a 16 (batch rows) x 16 (hidden units) tile of
-// dh = dgates_{s-1} . W_hh: its 16 columns of W_hh^T (K = 4H) stay in LDS, the cell-state gradient of its 256 (row, unit)
-// pairs in registers.  The product needs the gate gradients of ALL units of its 16 rows from the step before - produced by the
-// H/16 workgroups of its (cell, row tile) group - so each step is: wait for the group's arrival counter, read the exchanged
-// gate gradients with sc1 loads (two ping-pong x16-tiled slots: a slot is rewritten only after every workgroup of the group has
-// published the step in between, i.e. has finished reading it), MFMA against the LDS weights, the cell's pointwise backward,
-// write the new gate gradients (plain copies for the weight-gradient GEMMs + the exchanged copy with write-through stores),
-// drain, signal.  Same hand-off and the same bounded waits / sticky timeout flag as the forward kernel above.
-struct PersistBwdK {
-    BwdK s;                   // operand block of step 0
-    long i_dg, i_dg2, i_ext1, i_gates, i_cp, i_cc;    // element increments per step
-    int i_dt, steps;
-    float* xchg;              // this cell's exchange: [2][4H/16][Bp][16]
-    unsigned* sync;           // this cell's arrival counters: [row tile (2)][4 shards] x 16 words
-    unsigned* tmo;
-    int spin_limit;
-};
-struct PersistBwdK2 { PersistBwdK c[2]; };
-
-__global__ __launch_bounds__(256, 1) void lstm_seq_persist_bwd_kernel(PersistBwdK2 pq) {
-    T2_CHAIN_PRIO();
-    extern __shared__ __attribute__((aligned(16))) float plds[];
-    const PersistBwdK& pp = pq.c[blockIdx.z];
-    const BwdK& p = pp.s;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 15, q = lane >> 4;
-    const int bx = blockIdx.x, by = blockIdx.y, u0 = bx * 16, b0 = by * 16, H = p.H;
-    const int NCH = p.N4 >> 4, NCHpad = (NCH + 31) & ~31;
-    float* wl = plds;                          // [NCHpad][64 lanes][4]: this workgroup's tile of the packed transposed stream
-    float* red = plds + (long)NCHpad * 256;    // [4 waves][16][16] + 1 word for the wait's verdict
-    {
-        const f32x4* src = reinterpret_cast<const f32x4*>(p.wtpacked + (long)bx * NCHpad * 256);
-        f32x4* dst = reinterpret_cast<f32x4*>(wl);
-        for (int i = tid; i < NCHpad * 64; i += 256) dst[i] = src[i];
-    }
-    const int nwg = gridDim.x;                 // workgroups of this (cell, row tile) group
-    unsigned* grp = pp.sync + by * 64;
-    unsigned* my_shard = grp + (bx & 3) * 16;
-    unsigned* tmo = pp.tmo;
-    const unsigned want_per_step = lane < 4 ? (unsigned)((nwg + 3 - lane) >> 2) : 0u;     // workgroups that add to shard `lane`
-    // this thread's (row, unit) of the epilogue
-    const int bl = tid >> 4, ul = tid & 15;
-    const int b = b0 + bl, u = u0 + ul;
-    const bool live = b < p.B && u < p.ncols;
-    const long bc = b < p.B ? b : p.B - 1;
-    const int uc = u < p.ncols ? u : p.ncols - 1;
-    float dc_reg = live ? p.dc[bc * p.lddc + uc] : 0.f;
-    const int e_len = p.len ? p.len[bc] : 0x7fffffff;
-    const long cs = p.dgt_cs;                  // chunk stride of the tiled exchange: Bp * 16 floats
-    const long slot = (long)NCH * cs;
-    const int arow = (b0 + r) < p.B ? (b0 + r) : p.B - 1;      // (padding rows are never written: read a real one)
-    __syncthreads();
-    bool alive = true;
-    for (int s = 0; s < pp.steps && alive; ++s) {
-        // epilogue operands of this step: independent of the other workgroups, requested before the wait
-        float e_ext = 0.f, e_cp = 0.f, e_cc = 0.f;
-        f32x4 g4 = {0.f, 0.f, 0.f, 0.f};
-        if (p.ext1) e_ext = (p.ext1 + (long)s * pp.i_ext1)[bc * p.ldx1 + uc];
-        g4 = *reinterpret_cast<const f32x4*>(p.gates + (long)s * pp.i_gates + bc * p.ldgs + 4 * uc);
-        if (p.c_prev) e_cp = (p.c_prev + (long)s * pp.i_cp)[bc * p.ldcp + uc];
-        e_cc = (p.c_cur + (long)s * pp.i_cc)[bc * p.ldcc + uc];
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        if (s > 0) {       // dgates_{s-1}: every workgroup of the group has published it when shard i shows want_i * s arrivals
-            if (w == 0) {
-                int spins = 0;
-                bool ok = false;
-                while (true) {
-                    unsigned got = 0xffffffffu;
-                    if (lane < 4) got = __hip_atomic_load(grp + lane * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned bad = __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = __all(lane >= 4 || got >= want_per_step * (unsigned)s) && pp.spin_limit >= 0;
-                    if (ok || bad) { ok = ok && !bad; break; }
-                    if (++spins > pp.spin_limit || pp.spin_limit < 0) {   // (< 0: debug hook, every wait times out)
-                        if (lane == 0) __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (lane == 0) red[4 * 256] = ok ? 1.f : 0.f;
-            }
-            __syncthreads();
-            alive = red[4 * 256] != 0.f;
-            if (!alive) break;
-            // dh tile = dgates_{s-1}[16 rows][4H] . W^T[4H][16 units]: weights from LDS, gradients by sc1 buffer loads
-            const float* xt = pp.xchg + (long)((s - 1) & 1) * slot;
-            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xt, 0, (int)(slot * 4), 0x00020000);
-            for (int c0 = w; c0 < NCH; c0 += 4 * 8) {
-                f32x4 ax[8], bw[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int c = (c0 + 4 * j) < NCH ? (c0 + 4 * j) : NCH - 1;
-                    const unsigned off = (unsigned)((((long)c * cs) + arow * 16 + 4 * q) * 4);
-                    ax[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
-                    bw[j] = *reinterpret_cast<const f32x4*>(wl + ((long)c * 64 + lane) * 4);
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float okf = (c0 + 4 * j) < NCH ? 1.f : 0.f;
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[j][0], okf * bw[j][0], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[j][1], okf * bw[j][1], acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[j][2], okf * bw[j][2], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[j][3], okf * bw[j][3], acc1, 0, 0, 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) red[(w * 16 + (q * 4 + g)) * 16 + r] = acc0[g] + acc1[g];
-        __syncthreads();
-        if (live) {
-            float dx = e_ext;
-#pragma unroll
-            for (int ww = 0; ww < 4; ++ww) dx += red[(ww * 16 + bl) * 16 + ul];
-            const bool active = (p.t + s * pp.i_dt) < e_len;
-            const float gi = g4[0], gf = g4[1], gg = g4[2], go = g4[3];
-            const float tc = t2_tanh(e_cc);
-            const float dcv = dc_reg + dx * go * (1.f - tc * tc);
-            float d_o = dx * tc * go * (1.f - go);
-            float d_i = dcv * gg * gi * (1.f - gi);
-            float d_f = dcv * e_cp * gf * (1.f - gf);
-            float d_g = dcv * gi * (1.f - gg * gg);
-            float dcp = dcv * gf;
-            if (!active) { d_i = d_f = d_g = d_o = 0.f; dcp = 0.f; }
-            dc_reg = dcp;
-            float* dgo = p.dg_out + (long)s * pp.i_dg + (long)b * p.ldgo + u;
-            dgo[0] = d_i; dgo[H] = d_f; dgo[2 * H] = d_g; dgo[3 * H] = d_o;
-            if (p.dg_out2) {
-                float* dg2o = p.dg_out2 + (long)s * pp.i_dg2 + (long)b * p.ldgo2 + u;
-                dg2o[0] = d_i; dg2o[H] = d_f; dg2o[2 * H] = d_g; dg2o[3 * H] = d_o;
-            }
-            {   // the exchanged copy (x16-tiled, H % 16 == 0: the four gate columns share u & 15): write-through
-                float* xo = pp.xchg + (long)(s & 1) * slot + (long)(u >> 4) * cs + b * 16 + (u & 15);
-                const long gs = (long)(H >> 4) * cs;
-                __hip_atomic_store(xo, d_i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(xo + gs, d_f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(xo + 2 * gs, d_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(xo + 3 * gs, d_o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores ...
-        __syncthreads();                                        // ... before the workgroup signals (also frees `red`)
-        if (tid == 0) __hip_atomic_fetch_add(my_shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (live) p.dc[(long)b * p.lddc + u] = dc_reg;              // (the state the step launches leave behind)
-}
-
 struct PackSegs { int nseg; const float* w[3]; long ldw[3]; int K[3]; };
 
 // out[((j*NT + c)*64 + lane)*4 + e] = W_seg[(g*H + 4j + uu)*ldw + 16*lc + 4q + e],  lane = q*16 + (g*4 + uu)
@@ -865,97 +717,6 @@ extern "C" int t2_lstm_seq_fwd_persist_n(const T2LstmStep* base, const T2LstmStr
 
 extern "C" int t2_lstm_seq_fwd_persist(const T2LstmStep* base, const T2LstmStride* inc, int S, uint32_t* sync, void* stream) {
     return t2_lstm_seq_fwd_persist_n(base, inc, 1, S, sync, stream);
-}
-
-static size_t persist_bwd_lds_bytes(int N4) {
-    const int NCH = N4 >> 4, NCHpad = (NCH + 31) & ~31;
-    return ((size_t)NCHpad * 256 + 4 * 256 + 4) * sizeof(float);
-}
-
-// All workgroups of the persistent backward launch must be resident at once: compute units x the occupancy the runtime reports.
-static int persist_bwd_resident(int nwg, size_t lds) {
-    static std::mutex mu;
-    static std::unordered_map<long, int> cap;
-    std::lock_guard<std::mutex> lock(mu);
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { t2_set_error("hipGetDevice failed", __FILE__, __LINE__); return T2_ERR_LAUNCH; }
-    const long key = ((long)dev << 40) | (long)lds;
-    auto it = cap.find(key);
-    if (it == cap.end()) {
-        int cus = 0, per_cu = 0;
-        hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_persist_bwd_kernel, 256, lds);
-        if (e != hipSuccess) { t2_set_error(hipGetErrorString(e), __FILE__, __LINE__); (void)hipGetLastError(); return T2_ERR_LAUNCH; }
-        it = cap.emplace(key, cus * per_cu).first;
-    }
-    if (nwg > it->second) {
-        t2_set_error("t2_lstm_seq_bwd_persist: the launch would not be co-resident on this device; use t2_lstm_seq_bwd", __FILE__, __LINE__);
-        return T2_ERR_RESIDENCY;
-    }
-    return T2_OK;
-}
-
-extern "C" int t2_lstm_persist_bwd_resident(int H, int B, int n) {
-    (void)hipGetLastError();
-    T2_REQUIRE(H >= 16 && B >= 1 && n >= 1, "t2_lstm_persist_bwd_resident: bad arguments");
-    const size_t lds = persist_bwd_lds_bytes(4 * H);
-    const int rows = B < 32 ? B : 32;
-    if (H % 16 != 0 || n > 2 || H / 16 > 64 || !t2_allow_lds(lstm_seq_persist_bwd_kernel, lds)) {
-        t2_set_error("t2_lstm_persist_bwd_resident: cannot be ONE co-resident launch (H % 16, more than two cells, or a weight tile "
-                     "that does not fit the LDS); use t2_lstm_seq_bwd", __FILE__, __LINE__);
-        return T2_ERR_RESIDENCY;
-    }
-    return persist_bwd_resident(n * (H / 16) * t2_cdiv(rows, 16), lds);
-}
-
-extern "C" int t2_lstm_seq_bwd_persist(const T2LstmBwdStep* base, const T2LstmBwdStride* inc, int n, int S, float* xchg, uint32_t* sync,
-                                       void* stream) {
-    (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
-    T2_REQUIRE(base && inc && xchg && sync && S >= 0 && (n == 1 || n == 2), "t2_lstm_seq_bwd_persist: bad arguments");
-    if (S == 0) return T2_OK;
-    for (int i = 0; i < n; ++i) {
-        T2_TRY(t2_lstm_check_bwd(base[i]));
-        const T2LstmBwdStep& b = base[i];
-        T2_REQUIRE(b.epi == 1 && b.wtpacked && b.N4 == 4 * b.H && b.H % 16 == 0 && b.ncols == b.H && !b.dg2 && !b.ext2 && !b.drop,
-                   "t2_lstm_seq_bwd_persist: needs epi = 1 on the packed path with N4 = 4H, H % 16 == 0 and no dg2 / ext2 / drop");
-        T2_REQUIRE(b.B == base[0].B && b.H == base[0].H, "t2_lstm_seq_bwd_persist: the cells of one launch share B and H");
-    }
-    const int H = base[0].H, B = base[0].B;
-    const size_t lds = persist_bwd_lds_bytes(4 * H);
-    T2_TRY(t2_lstm_persist_bwd_resident(H, B, n));
-    hipStream_t st = (hipStream_t)stream;
-    const int Bp = (B + 15) / 16 * 16;
-    // Rows are independent: blocks of up to 32 rows (two 16-row tiles, two arrival-counter groups per cell) run as consecutive launches
-    for (int r0 = 0; r0 < B; r0 += 32) {
-        const int bn = (B - r0) < 32 ? (B - r0) : 32;
-        PersistBwdK2 kk;
-        for (int i = 0; i < n; ++i) {
-            PersistBwdK& k = kk.c[i];
-            T2LstmBwdStep sb = base[i];
-            // row block: advance every per-row pointer by r0 rows
-            sb.B = bn;
-            if (sb.ext1) sb.ext1 += (long)r0 * sb.ldx1;
-            sb.gates += (long)r0 * sb.ldgs;
-            if (sb.c_prev) sb.c_prev += (long)r0 * sb.ldcp;
-            sb.c_cur += (long)r0 * sb.ldcc;
-            sb.dc += (long)r0 * sb.lddc;
-            sb.dg_out += (long)r0 * sb.ldgo;
-            if (sb.dg_out2) sb.dg_out2 += (long)r0 * sb.ldgo2;
-            if (sb.len) sb.len += r0;
-            t2_lstm_to_bk(sb, k.s);
-            k.s.dgt_cs = (long)Bp * 16;          // the exchange is laid out for all rows of the call
-            k.i_dg = inc[i].dg; k.i_dg2 = inc[i].dg2; k.i_ext1 = inc[i].ext1; k.i_gates = inc[i].gates;
-            k.i_cp = inc[i].c_prev; k.i_cc = inc[i].c_cur; k.i_dt = inc[i].dt; k.steps = S;
-            k.xchg = xchg + (long)i * 2 * 4 * H * Bp + (long)r0 * 16;
-            k.sync = sync + i * 128; k.tmo = sync + 256; k.spin_limit = g_persist_spin_limit;
-        }
-        if (n == 1) kk.c[1] = kk.c[0];
-        (void)hipMemsetAsync(sync, 0, 16 * 16 * sizeof(uint32_t), st);
-        dim3 grid(H / 16, t2_cdiv(bn, 16), n), block(256);
-        hipLaunchKernelGGL(lstm_seq_persist_bwd_kernel, grid, block, lds, st, kk);
-    }
-    T2_CHECK_LAUNCH();
-    return T2_OK;
 }
 
 extern "C" int t2_lstm_pack_fwd(const T2Seg* segs, int nseg, int H, float* out, void* stream) {

@@ -125,7 +125,6 @@ class Engine:
         self.splitk_small_chunks = True  # forward pipeline: the hoisted decoder-LSTM input GEMM of short chunks runs split-K
         self.enc_chain = "persistent"    # encoder BiLSTM recurrence: "persistent" (one launch, both directions) | "steps" (S launches)
         self.enc_persist_max_rows = 32   # (the launch itself takes up to 64 rows, as two consecutive blocks)
-        self.enc_chain_bwd = "persistent"  # its backward recurrence: "persistent" (t2_lstm_seq_bwd_persist) | "steps" (S launches)
         self.bptt_off_chain = True    # the decoder-LSTM BPTT launches (side stream, a chunk ahead) keep the default wave priority
         self.sync_bn_group = None     # torch.distributed group: BatchNorm statistics over all ranks' shards (Trainer(sync_bn=True))
         self.grad_tail_hook = None    # called on the side stream once the gradients from prenet.0.weight onwards are enqueued
@@ -142,16 +141,6 @@ class Engine:
             rc = _lib.call_value("t2_lstm_persist_resident_n", D, D, min(B, 32), n)
             if rc not in (0, 3):
                 raise _lib.T2Error(f"t2_lstm_persist_resident failed (rc={rc}): {_lib.lib().t2_last_error().decode()}")
-            self._persist_ok[key] = rc == 0
-        return self._persist_ok[key]
-
-    def persist_bwd_resident(self, H: int, B: int, n: int = 2) -> bool:
-        """The same question for the persistent backward recurrence (t2_lstm_seq_bwd_persist: n cells x H/16 x row tiles)."""
-        key = ("bwd", H, min(B, 32) <= 16, n)
-        if key not in self._persist_ok:
-            rc = _lib.call_value("t2_lstm_persist_bwd_resident", H, B, n)
-            if rc not in (0, 3):
-                raise _lib.T2Error(f"t2_lstm_persist_bwd_resident failed (rc={rc}): {_lib.lib().t2_last_error().decode()}")
             self._persist_ok[key] = rc == 0
         return self._persist_ok[key]
 
@@ -965,19 +954,10 @@ class Engine:
             ic = incs[dr]
             ic.dg = sg * B * 4 * H; ic.dg2 = sg * 8 * H; ic.ext1 = sg * E; ic.gates = sg * B * 4 * H
             ic.c_prev = sg * B * H; ic.c_cur = sg * B * H; ic.dt = sg
-        # The recurrence as ONE persistent launch for both directions (t2_lstm_seq_bwd_persist: W_hh^T tiles in LDS, gate gradients
-        # exchanged through two x16-tiled slots) instead of S launches of ~7 us
-        persist_b = self.enc_chain_bwd == "persistent" and H % 16 == 0 and self.persist_bwd_resident(H, B, 2)
-        ctx["enc_persist_bwd"] = persist_b
-        if persist_b:
-            Bp = (B + 15) // 16 * 16
-            xchg = self.buf("enc.dg_xchg", 2, 2, 4 * H // 16, Bp, 16)
-            call("t2_lstm_seq_bwd_persist", steps, incs, 2, S, xchg, self.persist_sync(), st)
-            # (a wait that timed out - sticky device flag - turns the input-projection gradient into NaN: the gradient norm is then
-            #  not finite, t2_adam_step skips the step, and the host raises at its next check_persistent_kernels)
-            call("t2_guard_poison", self._persist_sync.data_ptr() + 4 * 256, dpre, B * Lp * 8 * H, st)
-        else:
-            call("t2_lstm_seq_bwd", steps, incs, 2, S, st)
+        # (S launches: a persistent, weight-stationary launch of this recurrence - the mirror of the forward's - was built in round 4
+        #  and removed: 1.4 instead of 1.8 ms for the chain, but the step's tail is bound by the side stream's weight-gradient GEMMs,
+        #  which then collide with the encoder convolutions' backward instead: 63.0 against 63.1 ms, profiles/r04_ab_bilstm_bwd_persistent.txt)
+        call("t2_lstm_seq_bwd", steps, incs, 2, S, st)
         Rr = B * Lp - 4
         x3 = e["x3"]
 

@@ -704,38 +704,3 @@ def test_encoder_bilstm_persistent_launch_equals_step_launches(B, L):
         for a, b in zip(got[0], other):
             assert float((a - b).abs().max()) <= 2e-6 * max(float(a.abs().max()), 1.0)
     assert float(got[0][0].abs().max()) > 0.01
-
-
-@pytest.mark.parametrize("B,L", [(5, 37), (16, 9), (33, 21), (64, 12)])
-def test_encoder_bilstm_backward_persistent_launch_equals_step_launches(B, L):
-    """The encoder BiLSTM's backward recurrence as ONE persistent launch for both directions (Engine.enc_chain_bwd = "persistent",
-    t2_lstm_seq_bwd_persist: W_hh^T tiles in LDS, gate gradients exchanged between the workgroups of a (direction, 16-row tile)
-    group) or as L launches of the step kernel ("steps").  The whole training step through both - ragged lengths (the forward
-    direction's BPTT starts inside the padding), 1 to 4 row tiles, a second block of 32 rows - gives the same gradients: the encoder
-    tensors to fp32 re-association level (the two kernels sum K in different orders), everything downstream identical inputs."""
-    dev = _dev()
-    d = R.default_dims(num_chars=39, encoded_dim=64, prenet_dim=32, att_rnn_dim=64, att_dim=32, rnn_hidden_dim=64,
-                       postnet_dim=64, num_mels=16, dropout=0.5)
-    P = R.init_params(d, seed=6)
-    ci, lens, mel, tl, gate, masks = random_case(d, B, L, 5, 600 + B, dev)
-    grads = []
-    for mode in ("steps", "persistent"):
-        eng, ps = build_engine(d, P, dev)
-        eng.enc_chain_bwd = mode
-        outs, ctx = eng.forward_tf(ci.to(dev), lens.to(dev), mel.to(dev), tl.to(dev), training=True, masks=masks_to_device(masks, dev))
-        ps.grad.zero_()
-        eng.loss_and_grads(outs, ctx, mel.to(dev), gate.to(dev))
-        torch.cuda.synchronize()
-        eng.check_persistent_kernels()
-        assert ctx["enc_persist_bwd"] == (mode == "persistent")
-        grads.append(ps.grad.clone())
-    gmax = float(grads[0].abs().max())
-    assert gmax > 0
-    for name in ps.P:
-        if name in ZERO_GRADIENT_BY_CONSTRUCTION:
-            continue
-        o, k = ps.offsets[name], ps.P[name].numel()
-        a, b = grads[0][o:o + k].double(), grads[1][o:o + k].double()
-        scale = max(float(a.abs().max()), 1e-3 * gmax)
-        assert float((a - b).abs().max()) < 2e-5 * scale, (name, float((a - b).abs().max()), scale)
-    assert float(ps.G["encoder.lstm.weight_hh_l0_reverse"].abs().max()) > 0 and float(ps.G["encoder.embedding.weight"].abs().max()) > 0

@@ -53,7 +53,7 @@ def test_engine_falls_back_to_step_launches_without_residency():
     torch.cuda.synchronize()
     assert tr.engine._persist_sync is not None                     # the persistent path ran
     tr2, ps2, _ = _small_trainer(dev)
-    tr2.engine._persist_ok = {(64, True, 1): False, (32, True, 2): False, ("bwd", 32, True, 2): False}     # as if t2_lstm_persist_resident had said no (decoder
+    tr2.engine._persist_ok = {(64, True, 1): False, (32, True, 2): False}     # as if t2_lstm_persist_resident had said no (decoder
                                                                                 # LSTM H = 64; encoder BiLSTM 2 x H = 32)
     loss_s, _ = tr2.train_step(batch)
     torch.cuda.synchronize()
