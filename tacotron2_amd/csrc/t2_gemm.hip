@@ -312,8 +312,12 @@ __device__ __forceinline__ void split_store_unit(const f32x4 v, char* op, int ti
     const int off = KMAJ ? (idx >> 2) * KM_ROW + (idx & 3) * 8 : (idx >> 5) * MM_ROW + (idx & 31) * 8;
     constexpr int PL = KMAJ ? KM_PLANE : MM_PLANE;
     *reinterpret_cast<uint2*>(op + off) = s.h;
+#if defined(T2_GEMM_ABL_STORE)          // diagnostic build (wrong results): one plane stored instead of three, the split itself kept
+    if (NP >= 2 && (s.m.x ^ s.l.x) == 0x12345u) *reinterpret_cast<uint2*>(op + PL + off) = s.m;
+#else
     if (NP >= 2) *reinterpret_cast<uint2*>(op + PL + off) = s.m;
     if (NP >= 3) *reinterpret_cast<uint2*>(op + 2 * PL + off) = s.l;
+#endif
 }
 
 // fragment of plane `pl` for the 32-row MFMA tile starting at tile row r0: element j = k offset 8*(lane>>5) + j
@@ -415,6 +419,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(GemmK p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) {
+#if defined(T2_GEMM_ABL_FRAG)       // diagnostic build (wrong results): half of the fragment reads - what is the LDS read traffic worth?
+                if (i == 1) { fa[1][pl] = fa[0][pl]; fb[1][pl] = fb[0][pl]; continue; }
+#endif
                 fa[i][pl] = split_frag<AK>(As, pl, wm * 64 + i * 32, lane);
                 fb[i][pl] = split_frag<BKM>(Bs, pl, wn * 64 + i * 32, lane);
             }

@@ -73,10 +73,11 @@ __device__ __forceinline__ void stop_logic(const float* proj, long ldp, int M, i
 // out[b][n] = act(sum_k x[b][k] w[n][k] + bias[n] + rowterm[b][n]) * mask[b][n]; batch rows on the MFMA M axis (MT tiles of
 // 16 rows per workgroup, blockIdx.y selects the row block), one 16-column tile per workgroup, K split over the 4 waves
 // (K % 16 == 0), all loads of a group issued before the first MFMA wait; partial tiles are summed in fixed wave order.
-template <int MT>
-__global__ __launch_bounds__(256, 1) void linear_rows_kernel(LinK p) {
+// NW waves split K (4, or 8 for the long reduction of the combined linear: all of a wave's loads are then ONE round in flight)
+template <int MT, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void linear_rows_kernel(LinK p) {
     T2_CHAIN_PRIO();
-    __shared__ float red[4 * MT * 256];
+    __shared__ float red[NW * MT * 256];
     __shared__ int notdone;
     if (p.stop_proj && blockIdx.x == gridDim.x - 1) {   // one extra workgroup: the stop logic runs next to the linear, not in front
         if (blockIdx.y == 0) stop_logic(p.stop_proj, p.stop_ldp, p.stop_M, p.B, p.stop_t, p.stop_done, p.stop_state, &notdone);
@@ -109,11 +110,11 @@ __global__ __launch_bounds__(256, 1) void linear_rows_kernel(LinK p) {
     // flight before the first MFMA waits (these launches are a handful of workgroups deep: latency, not bandwidth; with 4
     // chunks per round the K = 1536 launch took six dependent round trips, 8.7 us)
     constexpr int U = 12;
-    for (int c0 = w; c0 < NT; c0 += 4 * U) {
+    for (int c0 = w; c0 < NT; c0 += NW * U) {
         f32x4 bw[U], ax[U][MT];
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const int c = c0 + 4 * j < NT ? c0 + 4 * j : NT - 1;
+            const int c = c0 + NW * j < NT ? c0 + NW * j : NT - 1;
             bw[j] = *reinterpret_cast<const f32x4*>(wb + wcs * c);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256, 1) void linear_rows_kernel(LinK p) {
         }
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const float okf = (c0 + 4 * j) < NT ? 1.f : 0.f;
+            const float okf = (c0 + NW * j) < NT ? 1.f : 0.f;
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -134,12 +135,12 @@ __global__ __launch_bounds__(256, 1) void linear_rows_kernel(LinK p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) red[((w * MT + m) * 16 + (q * 4 + g)) * 16 + r] = acc[m][g];
     __syncthreads();
-    for (int o = tid; o < MT * 256; o += 256) {
+    for (int o = tid; o < MT * 256; o += 64 * NW) {
         const int bl = o >> 4, nl = o & 15, n = n0 + nl, b = b0 + bl;
         if (b < p.B && n < p.N) {
             float s = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < 4; ++ww) s += red[((ww * MT + (bl >> 4)) * 16 + (bl & 15)) * 16 + nl];
+            for (int ww = 0; ww < NW; ++ww) s += red[((ww * MT + (bl >> 4)) * 16 + (bl & 15)) * 16 + nl];
             if (p.bias) s += p.bias[n];
             if (p.rowterm) s += p.rowterm[(long)b * p.ldrt + n];
             if (n >= p.split_n) { p.out2[(long)b * p.ldo2 + (n - p.split_n)] = s; continue; }
@@ -163,8 +164,10 @@ int launch_linear(const LinK& k, hipStream_t st) {
     // are what spreads them over the chip; each workgroup streams its 16 weight rows (re-read from L2 by the other row
     // blocks) and 16 activation rows
     const int ny = t2_cdiv(k.B, 16);
-    dim3 grid(t2_cdiv(k.N, 16) + (k.stop_proj ? 1 : 0), ny), block(256);
-    hipLaunchKernelGGL((linear_rows_kernel<1>), grid, block, 0, st, k);
+    dim3 grid(t2_cdiv(k.N, 16) + (k.stop_proj ? 1 : 0), ny);
+    static const int nw8_min_k = getenv("T2_LINEAR_NW8_MIN_K") ? atoi(getenv("T2_LINEAR_NW8_MIN_K")) : 1024;
+    if (k.K >= nw8_min_k) hipLaunchKernelGGL((linear_rows_kernel<1, 8>), grid, dim3(512), 0, st, k);
+    else hipLaunchKernelGGL((linear_rows_kernel<1, 4>), grid, dim3(256), 0, st, k);
     T2_CHECK_LAUNCH();
     return T2_OK;
 }
