@@ -139,6 +139,60 @@ def test_cli_controls_extension_train_then_say(tmp_path):
     assert r.returncode != 0 and "comma-separated" in (r.stdout + r.stderr)      # wrong number of control values
 
 
+def _wav_manifest(tmp_path, n=6, sr=22050):
+    speech = tmp_path / "wavs"
+    speech.mkdir()
+    rows = ["text|wav|speaker_id"]
+    rng = np.random.default_rng(0)
+    for i in range(n):
+        k = sr // 2 + 997 * i
+        x = 0.3 * np.sin(2 * np.pi * (200 + 40 * i) * np.arange(k) / sr) + 0.01 * rng.normal(size=k)
+        with wave.open(str(speech / f"u{i}.wav"), "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(sr); w.writeframes((x * 32767).astype("<i2").tobytes())
+        rows.append(f"Utterance number {i}{', and a few more words' * (i % 3)}, Dr. Who says hi!|u{i}.wav|{i % 4}")
+    csvp = tmp_path / "train.csv"
+    csvp.write_text("\n".join(rows) + "\n")
+    return speech, csvp
+
+
+def test_cli_train_data_parallel_step_over_rccl_never_blocks_the_host(tmp_path):
+    """`main.py train` with the data-parallel step forced on at world size 1 (T2_FORCE_DP=1: process group over RCCL, shape agreed on
+    the host over the trainer's gloo group, both gradient buckets, Work.wait) and torch's sync-debug mode set to "error" around
+    every Trainer.train_step (T2_SYNC_DEBUG=1): the run only succeeds if no call of the step synchronises the host - no `.item()`,
+    no `int()` of a device value, no blocking copy - between two loss printouts (run/train.py's loop)."""
+    cfg = _cfg(tmp_path)
+    res = tmp_path / "res"
+    env = dict(os.environ, T2_FORCE_DP="1", T2_SYNC_DEBUG="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29661")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "--config", str(cfg), "--device", "0", "train", "--speech-dir",
+                        "unused", "--results-dir", str(res), "--synthetic", "--max-steps", "5"], cwd=ROOT, capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    losses = [float(l.split("training_loss ")[1].split()[0]) for l in r.stdout.splitlines() if "training_loss" in l]
+    assert len(losses) >= 2 and all(np.isfinite(losses))
+    ck = torch.load(res / "final.ckpt", map_location="cpu", weights_only=True)
+    assert ck["global_step"] == 5
+
+
+def test_cli_train_two_ranks_on_a_wav_manifest(tmp_path):
+    """`main.py train` as two ranks (torch.distributed.run; gloo, both on cuda:0 - RCCL needs a GPU per rank) on a real WAV
+    manifest: utterances sharded by rank (3 each, batch 1: an epoch is 3 steps, the 5 steps cross it), every batch padded to the
+    step's global (L, T) by the LOADER THREADS (DevicePrefetcher(negotiate=Trainer.negotiate_collated, limit, cycle)) while the
+    previous step runs, train_step(padded=True) on both ranks, the flat-gradient all-reduce, one checkpoint from rank 0."""
+    speech, csvp = _wav_manifest(tmp_path)
+    cfg = _cfg(tmp_path, csvp, batch=1)
+    res = tmp_path / "res"
+    env = dict(os.environ, T2_DIST_BACKEND="gloo", T2_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29663", os.path.join(ROOT, "main.py"), "--config", str(cfg), "--device", "0", "train", "--speech-dir",
+           str(speech), "--results-dir", str(res), "--max-steps", "5"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    losses = [float(l.split("training_loss ")[1].split()[0]) for l in r.stdout.splitlines() if "training_loss" in l]
+    assert len(losses) >= 2 and all(np.isfinite(losses))
+    ck = torch.load(res / "final.ckpt", map_location="cpu", weights_only=True)
+    assert ck["global_step"] == 5 and "saved" in r.stdout
+
+
 def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
     """The data-parallel code path end to end on the GPU (shard padding, flat-gradient all-reduce, 1/world scale) with two
     ranks sharing cuda:0 over gloo (RCCL needs one GPU per rank; the 8-GPU run is the driver's)."""
