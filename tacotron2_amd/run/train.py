@@ -76,7 +76,7 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
     tr = Trainer(model.tacotron2.store, lr=kw["lr"], weight_decay=kw["weight_decay"],
                  scheduler_milestones=kw["scheduler_milestones"], max_norm=1.0,
                  sync_bn=bool(training_config.get("sync_batchnorm", False)),
-                 overlap_allreduce=bool(training_config.get("overlap_allreduce", True)),
+                 overlap_allreduce=bool(training_config.get("overlap_allreduce", False)),
                  force_collectives=force_dp)
     if resume_ckpt:
         # trainer.fit(ckpt_path=...) (run/train.py:245): weights, global_step, Adam moments and the scheduler state all come

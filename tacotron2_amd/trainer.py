@@ -23,7 +23,7 @@ from .params import ParamStore
 
 class Trainer:
     def __init__(self, ps: ParamStore, lr: float, weight_decay: float, scheduler_milestones: Sequence[int] = (),
-                 max_norm: float = 1.0, seed: int = 1234, sync_bn: bool = False, overlap_allreduce: bool = True,
+                 max_norm: float = 1.0, seed: int = 1234, sync_bn: bool = False, overlap_allreduce: bool = False,
                  force_collectives: bool = False):
         self.ps = ps
         self.engine = Engine(ps)
@@ -49,6 +49,10 @@ class Trainer:
         # GEMMs are; its all-reduce is started there (behind the engine's side stream) and runs next to the encoder backward
         # (BiLSTM recurrence + convolutions, ~2.6 ms of latency-bound launches).  The head (encoder, speaker table, description
         # linear: 22 MB) follows when the backward ends.  Same sums, same result as one all-reduce.
+        # OFF by default (round 4): measured over RCCL at world size 1, where the collective is a device-local pass over the bucket,
+        # the overlapped tail costs the encoder backward and the chains' tail 0.9 ms (63.6 against 62.7 ms per step for ONE call
+        # after the backward, 62.5 without a process group) - it pays only if the exposed all-reduce of a real multi-GPU run is
+        # longer than that, which nobody has measured.
         # Not with sync_bn: RCCL runs the collectives of one communicator in issue order on its own stream, so the eight small
         # BatchNorm reduces of the encoder backward would queue behind the 90 MB tail and stall the main stream - the overlap
         # would turn into a wait.  (The overlapped path has run over gloo at 2 and 4 ranks and over RCCL at world size 1, where the

@@ -18,11 +18,12 @@ import sys
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29641")
 os.environ["RANK"] = "0"; os.environ["WORLD_SIZE"] = "1"
 
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import tacotron2_amd  # noqa: E402,F401  (as every product entry point: pins GPU_MAX_HW_QUEUES before the HIP runtime starts)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
 def main():

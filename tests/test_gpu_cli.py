@@ -204,16 +204,17 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["allreduce"] == "1 call after the backward"            # the default (the four-rank rehearsal runs the two buckets)
     assert all(np.isfinite(d["loss"]))
 
 
 def test_bench_four_ranks_rehearsal_on_one_gpu(tmp_path):
     """`bench.py --gpus 4` as the driver launches it, rehearsed with four ranks on cuda:0 over gloo (the GPU box admits six
     processes on its card; the 8-rank run needs the 8-GPU node and is the driver's): global batch = 4 x the per-rank batch,
-    every rank padded to the global shape, the two-bucket all-reduce, one JSON line from rank 0."""
+    every rank padded to the global shape, the two-bucket all-reduce (`--overlap-allreduce`), one JSON line from rank 0."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
            "--master-port", "29614", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
-           "--batch", "3", "--backend", "gloo", "--share-gpu"]
+           "--batch", "3", "--backend", "gloo", "--share-gpu", "--overlap-allreduce"]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

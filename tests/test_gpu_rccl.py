@@ -31,8 +31,8 @@ def test_bench_force_dp_runs_the_rccl_path_at_one_gpu():
     """`bench.py --gpus 1 --force-dp`: the driver's multi-GPU command line minus the launcher - process group over RCCL, both
     gradient buckets, the `allreduce` segment in the breakdown - so that the 8-GPU run is not the first time RCCL sees this code."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29655")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dp", "--steps", "2", "--warmup", "1",
-                        "--batch", "4", "--no-cpu-baseline", "--no-decode", "--no-high"], cwd=ROOT, capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dp", "--overlap-allreduce", "--steps", "2",
+                        "--warmup", "1", "--batch", "4", "--no-cpu-baseline", "--no-decode", "--no-high"], cwd=ROOT, capture_output=True, text=True,
                        timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
