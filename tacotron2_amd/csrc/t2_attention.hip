@@ -963,6 +963,11 @@ __device__ __forceinline__ void attn_bwd_ds_mfma_body(const AttnBwdK& p, float* 
             cl1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.m, cl1, 0, 0, 0);
             ch0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.h, fb.h, ch0, 0, 0, 0);
         }
+        if (!TILED && w >= 4) {      // one pass: the dU sums are complete - second K half of every (c,k) tile to its partner wave
+            const f32x4 cC1 = ch0 + ((cl0 + cl1) + cl2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) redC[c_nt * 256 + (4 * q + r) * 16 + n] = cC1[r];
+        }
         T2_STAMP(p, stamp, 28);
         // ---- phase D: d_in, this wave's K share (k-steps w, w + 8, w + 16) for the MT row tiles:
         //      A[m][(a, r = 8 rb + jj)] = ds[a][8 m + r - 17] = element x = 8 (m + rb + 1) + jj of dim a ----
@@ -1001,6 +1006,12 @@ __device__ __forceinline__ void attn_bwd_ds_mfma_body(const AttnBwdK& p, float* 
                 for (int r = 0; r < 4; ++r) red[((w * MT + mt) * 16 + 4 * q + r) * 16 + n] = cD[mt][r];
             }
         }
+        if (!TILED && w < 4 && c_k < KL) {      // dU: first K half (registers) + second (redC, visible since the barrier above)
+            const f32x4 cC0 = ch0 + ((cl0 + cl1) + cl2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                p.dU_part[(((long)b * p.Ad + j * 16 + 4 * q + r) * 2 + c_c) * KL + c_k] = dU_old[r] + cC0[r] + redC[c_nt * 256 + (4 * q + r) * 16 + n];
+        }
         __syncthreads();
         T2_STAMP(p, stamp, 29);
         for (int o = tid; o < MT * 256; o += ENT) {
@@ -1024,16 +1035,18 @@ __device__ __forceinline__ void attn_bwd_ds_mfma_body(const AttnBwdK& p, float* 
             p.dv_part[(long)b * p.Ad + a] = dv_old + sv;
         }
     }
-    const f32x4 cC = ch0 + ((cl0 + cl1) + cl2);
-    if (w >= 4) {
+    if (TILED) {
+        const f32x4 cC = ch0 + ((cl0 + cl1) + cl2);
+        if (w >= 4) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) redC[c_nt * 256 + (4 * q + r) * 16 + n] = cC[r];
-    }
-    __syncthreads();
-    if (w < 4 && c_k < KL) {      // first K half (registers) + second (redC)
+            for (int r = 0; r < 4; ++r) redC[c_nt * 256 + (4 * q + r) * 16 + n] = cC[r];
+        }
+        __syncthreads();
+        if (w < 4 && c_k < KL) {      // first K half (registers) + second (redC)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            p.dU_part[(((long)b * p.Ad + j * 16 + 4 * q + r) * 2 + c_c) * KL + c_k] = dU_old[r] + cC[r] + redC[c_nt * 256 + (4 * q + r) * 16 + n];
+            for (int r = 0; r < 4; ++r)
+                p.dU_part[(((long)b * p.Ad + j * 16 + 4 * q + r) * 2 + c_c) * KL + c_k] = dU_old[r] + cC[r] + redC[c_nt * 256 + (4 * q + r) * 16 + n];
+        }
     }
     if (TILED) {
         for (int i = tid; i < 2 * Lg; i += ENT) {
