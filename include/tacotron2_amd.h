@@ -404,8 +404,9 @@ typedef struct {
                                         every frame (controls . W_ih[:, A+Ef:]^T, model/decoder.py:94-99) */
 } T2Infer;
 int t2_decoder_infer(const T2Infer* a, int t0, int t1, void* stream);
-/* proj[g] [nframes][Bg[g]][ld_proj] for g < ngroups (<= 8) -> lengths [sum Bg] int64, out2 = {frames emitted n, 0} */
-typedef struct { const float* proj[8]; int Bg[8]; int ngroups; int64_t ld_proj; int M, nframes; } T2StopScan;
+/* proj[g] [nframes][Bg[g]][ld_proj] for g < ngroups (<= 64 groups of up to 64 utterances) -> lengths [sum Bg] int64,
+ * out2 = {frames emitted n, 0} */
+typedef struct { const float* proj[64]; int Bg[64]; int ngroups; int64_t ld_proj; int M, nframes; } T2StopScan;
 int t2_stop_scan(const T2StopScan* s, int64_t* lengths, int32_t* out2, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -180,7 +180,7 @@ __global__ void stop_kernel(const float* proj, long ldp, int M, int B, int t, in
 // Exact break frame and lengths from the stored stop logits of ALL utterances (several groups: proj_g [n][B_g][ldp]):
 // first[b] = first frame with logit < 0; the loop breaks after frame n* = max_b first[b] (or runs to `nframes` if some
 // utterance never stops); lengths[b] = #{t <= n* : logit[t][b] >= 0}; out2 = {frames emitted, 0}.  One workgroup.
-struct StopScan { const float* proj[8]; int Bg[8]; int ng; long ldp; int M; int nframes; int64_t* lengths; int32_t* out2; };
+struct StopScan { const float* proj[64]; int Bg[64]; int ng; long ldp; int M; int nframes; int64_t* lengths; int32_t* out2; };
 __global__ void stop_scan_kernel(StopScan p) {
     __shared__ int nstar;
     if (threadIdx.x == 0) nstar = 0;
@@ -228,7 +228,7 @@ extern "C" int t2_linear_rows(const float* x, int64_t ldx, const float* w, int64
 
 extern "C" int t2_stop_scan(const T2StopScan* s, int64_t* lengths, int32_t* out2, void* stream) {
     (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
-    T2_REQUIRE(s && lengths && out2 && s->ngroups >= 1 && s->ngroups <= 8 && s->nframes >= 1, "t2_stop_scan: bad arguments");
+    T2_REQUIRE(s && lengths && out2 && s->ngroups >= 1 && s->ngroups <= 64 && s->nframes >= 1, "t2_stop_scan: bad arguments");
     StopScan p;
     memset(&p, 0, sizeof(p));
     for (int g = 0; g < s->ngroups; ++g) {

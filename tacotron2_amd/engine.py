@@ -1021,17 +1021,17 @@ class Engine:
     # =============================================================================================
     # autoregressive inference: forward(teacher_forcing=False, max_len_override=N)  (model/tacotron2.py:262-325)
     # =============================================================================================
-    def _infer_group(self, g, chars_idx, chars_len, Tcap, speaker_id, description_embeddings, training, prenet_masks, controls):
-        """Encoder, conditioning and decode-loop operands of one group of <= 64 utterances (workspaces prefixed inf<g>.)."""
+    def _infer_group(self, g, enc, chars_len, Tcap, speaker_id, description_embeddings, training, prenet_masks, controls):
+        """Conditioning and decode-loop operands of one group of <= 64 utterances (workspaces prefixed inf<g>.); `enc` is the
+        group's slice of the encoder output, computed for the WHOLE batch by the caller."""
         d, P, ps = self.d, self.ps.P, self.ps
-        B, L = chars_idx.shape
+        B, L = enc.shape[0], enc.shape[1]
         M, E, Pd, A, D, Ad = d["num_mels"], d["encoded_dim"], d["prenet_dim"], d["att_rnn_dim"], d["rnn_hidden_dim"], d["att_dim"]
         Ef = E + (128 if d.get("description_embeddings") else 0)
         F = d.get("loc_filters", 32)
         st = _stream()
         pf = f"inf{g}."
         len32 = chars_len.to(torch.int32)
-        enc = self.encoder_fwd(chars_idx, len32, training, {}, {})
         memory = self.buf(pf + "memory", B, L, Ef)
         desc = None
         if d.get("description_embeddings"):
@@ -1091,7 +1091,7 @@ class Engine:
         prenet_masks: optional [n][2][B][P] scale masks (parity tests); otherwise Philox masks (AlwaysDropout)."""
         d, P, ps = self.d, self.ps.P, self.ps
         B, L = chars_idx.shape
-        assert B <= 512, "engine.infer handles up to 512 utterances per call"
+        assert B <= 4096, "engine.infer handles up to 4096 utterances per call (64 groups of 64)"
         self.generation += 1          # the encoder / postnet workspaces are shared with forward_tf
         M, E, Pd, A, D = d["num_mels"], d["encoded_dim"], d["prenet_dim"], d["att_rnn_dim"], d["rnn_hidden_dim"]
         Ef = E + (128 if d.get("description_embeddings") else 0)
@@ -1127,11 +1127,14 @@ class Engine:
         wc[:Nc, :Ef] = self._w_comb[:, D:]; wc[:Nc, Ef:] = self._w_comb[:, :D]
         self._w_comb_t = wc.view(Ncp, ldp // 16, 16).permute(1, 0, 2).contiguous()
         self._w_pre2_t = P["prenet.3.weight"].view(Pd, Pd // 16, 16).permute(1, 0, 2).contiguous()
+        # The encoder runs ONCE over the whole batch (model/tacotron2.py:197): in train() mode its BatchNorm layers then see the
+        # statistics of all utterances, as in the reference, whatever the grouping of the decode loop below
+        enc_all = self.encoder_fwd(chars_idx.contiguous(), chars_len.to(torch.int32), training, {}, {})
         groups = []
         for g, b0 in enumerate(range(0, B, 64)):
             sl = slice(b0, min(B, b0 + 64))
             groups.append(self._infer_group(
-                g, chars_idx[sl].contiguous(), chars_len[sl], Tcap,
+                g, enc_all[sl], chars_len[sl], Tcap,
                 speaker_id[sl] if speaker_id is not None else None,
                 description_embeddings[sl].contiguous() if description_embeddings is not None else None, training,
                 prenet_masks[:, :, sl].contiguous() if (prenet_masks is not None and B > 64) else prenet_masks,
@@ -1156,8 +1159,8 @@ class Engine:
         lengths = self.buf("inf.lengths", B, dtype=torch.int64)
         nfr = self.buf("inf.nframes", 2, dtype=torch.int32)
         ldo = (M + 1 + 3) // 4 * 4
-        scan = make("T2StopScan", proj=[G["proj"] for G in groups] + [0] * (8 - len(groups)),
-                    Bg=[G["B"] for G in groups] + [0] * (8 - len(groups)), ngroups=len(groups), ld_proj=ldo, M=M, nframes=t0)
+        scan = make("T2StopScan", proj=[G["proj"] for G in groups] + [0] * (64 - len(groups)),
+                    Bg=[G["B"] for G in groups] + [0] * (64 - len(groups)), ngroups=len(groups), ld_proj=ldo, M=M, nframes=t0)
         call("t2_stop_scan", scan, lengths, nfr, st)
         n = max(int(nfr.cpu()[0]), 1)
         self.check_persistent_kernels()      # (the encoder recurrence is a persistent launch; the host has just synchronised anyway)

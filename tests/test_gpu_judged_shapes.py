@@ -228,3 +228,49 @@ def test_bench_decode_call_properties():
     mels2, _, _, al2, _ = eng.infer(ci, cl, n_dec, speaker_id=spk, training=False, seed=2, check_every=64)
     torch.cuda.synchronize()
     assert torch.equal(mels, mels2) and torch.equal(al, al2)
+
+
+def test_descriptions_libritts_per_gpu_shape_forward_matches_oracle():
+    """BASELINE configs[3] at its per-GPU shape: description embeddings (768 -> 128, E' = 640) + 562 speaker tokens, 32 utterances
+    with LibriTTS-shaped lengths (synthetic.ljspeech_batch(shape="libritts"): L up to 238, T up to 938 - more frames than the LJSpeech
+    batch, so one more pipeline chunk), teacher-forced forward in training mode with replayed masks against the oracle
+    (config/descriptions-libritts.json:21,42-52 of the reference; model/tacotron2.py:99-107,201-212)."""
+    dev = _dev()
+    d = R.default_dims(speaker_tokens=True, num_speakers=562, description_embeddings=True, description_embeddings_dim=768)
+    P = R.init_params(d, seed=3)
+    b = ljspeech_batch(32, seed=1234, num_speakers=562, desc_dim=768, shape="libritts")
+    ci, cl, mel, tl = b["chars_idx"], b["chars_idx_len"], b["mel_spectrogram"], b["mel_spectrogram_len"]
+    spk, desc = b["speaker_id"], b["description_embeddings"]
+    B, L = ci.shape
+    T = mel.shape[1]
+    assert B == 32 and 872 < T <= 938 and L <= 238
+    masks = _scale_masks(d, B, L, T, 640)
+    with torch.no_grad():
+        ref = R.tacotron2_fwd(P, d, ci, cl, True, mel, tl, speaker_id=spk, description_embeddings=desc, training=True, masks=masks)
+    eng, ps = build_engine(d, P, dev)
+    outs, ctx = eng.forward_tf(ci.to(dev), cl.to(dev), mel.to(dev), tl.to(dev), speaker_id=spk.to(dev),
+                               description_embeddings=desc.to(dev), training=True, masks=masks_to_device(masks, dev))
+    torch.cuda.synchronize()
+    eng.check_persistent_kernels()
+    e0, e1, ea = l1(outs[0], ref[0]), l1(outs[1], ref[1]), mx(outs[3], ref[3])
+    print(f"configs[3] per-GPU shape (L={L}, T={T}): mel L1 {e0:.2e} / post {e1:.2e}, alignments max-abs {ea:.2e}")
+    assert e0 < MEL_L1_TOL and e1 < MEL_L1_TOL and ea < 2e-5, (e0, e1, ea)
+    assert ((outs[2].cpu() == -1000.0) == (ref[2] == -1000.0)).all()
+
+
+def test_vanilla_dims_batch64_train_step_matches_oracle():
+    """The shipped config's OWN batch size (config/vanilla-lj-hifi-stop.json:18: 64; the benchmark overrides it to 32): four 16-row
+    tiles in the attention-cell step and the backward products, the persistent decoder-LSTM launch as two consecutive blocks of 32
+    rows, the encoder recurrence as step launches (its persistent launch takes up to 32 rows).  Full training step - outputs, loss,
+    EVERY parameter gradient, BN statistics - against the oracle at vanilla dims."""
+    dev = _dev()
+    d = R.default_dims(speaker_tokens=True, num_speakers=4)
+    P = R.init_params(d, seed=64)
+    B, L, T = 64, 33, 21
+    from tests.test_gpu_model import random_case
+    case = random_case(d, B, L, T, 6400, dev)
+    spk = torch.randint(0, 4, (B,), generator=torch.Generator().manual_seed(64), dtype=torch.int32)
+
+    def check(eng):
+        assert eng.dec_chain == "persistent"
+    eng, ps = _hip_train_and_compare(d, P, case, dev, kw_cpu=dict(speaker_id=spk), kw_dev=dict(speaker_id=spk.to(dev)), check_engine=check)

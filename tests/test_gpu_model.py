@@ -648,6 +648,17 @@ def test_inference_above_64_utterances_is_one_loop_like_the_reference():
     assert mels.shape == ref[0].shape and (lengths.cpu() == trace["lengths"]).all()
     assert l1(mels, ref[0]) < MEL_L1_TOL and l1(post, ref[1]) < MEL_L1_TOL and mx(al, ref[3]) < 5e-5
     assert ((gates.cpu() == -1000.0) == (ref[2] == -1000.0)).all()
+    # train() mode (model.train(); forward(teacher_forcing=False)): encoder and postnet BatchNorm use BATCH statistics - of all 70
+    # utterances, not of a decode group: the encoder runs once over the whole batch
+    trace_t = {}
+    with torch.no_grad():
+        ref_t = R.tacotron2_fwd(P, d, ci, lens, False, max_len_override=N, training=True, masks=masks, trace=trace_t, new_stats={})
+    mels_t, post_t, gates_t, al_t, lengths_t = eng.infer(ci.to(dev), lens.to(dev), N, training=True, prenet_masks=pm.to(dev).contiguous(),
+                                                         check_every=3)
+    torch.cuda.synchronize()
+    assert float((trace_t["memory"] - trace["memory"]).abs().max()) > 1e-3        # the two modes really differ
+    assert mels_t.shape == ref_t[0].shape and (lengths_t.cpu() == trace_t["lengths"]).all()
+    assert l1(mels_t, ref_t[0]) < MEL_L1_TOL and l1(post_t, ref_t[1]) < MEL_L1_TOL and mx(al_t, ref_t[3]) < 5e-5
 
 
 @pytest.mark.parametrize("L", [1, 2, 15, 16, 17, 31, 33, 64, 97, 188, 231, 252, 253, 270, 431, 433, 649])
