@@ -165,6 +165,139 @@ __global__ __launch_bounds__(256, 1) void lstm_step_fwd_fast_kernel(LstmK2 pp) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same step for 33..64 batch rows with a SQUARE workgroup tile: 32 rows x 32 gate columns (8 hidden units) instead of 64 rows x
+// 16 columns.  At four row tiles the step is bound by the operand bytes a CU takes in (profiles/r04_ab_cell_mfma_ablation.txt: not
+// by the matrix pipe), and those are (rows + columns) x K x 4 bytes per workgroup: 64 K x 4 instead of 80 K x 4.  grid = (H/8 column
+// blocks, 2 row blocks): the two row blocks of a column block are workgroups x and x + H/8 - the same XCD under round-robin
+// dispatch (H/8 is a multiple of 8) - so their common weight tile is fetched into that XCD's L2 once.  Same packed weight stream
+// (two consecutive 16-column blocks), same x16-tiled activations, same chunk-granular software pipeline, same epilogue.
+// ---------------------------------------------------------------------------------------------------------
+template <int U>
+__global__ __launch_bounds__(256, 1) void lstm_step_fwd_sq_kernel(LstmK2 pp) {
+    T2_CHAIN_PRIO();
+    __shared__ float red[4 * 4 * 256];
+    const LstmK& p = pp.s[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int bx = blockIdx.x, b0 = blockIdx.y * 32, u0 = bx * 8;
+    const int H = p.H;
+    const int NT = p.seg[0].K >> 4, NTpad = (NT + 15) & ~15, G = NTpad / (4 * U);
+    const float* wb[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) wb[ct] = p.wpacked + (long)(2 * bx + ct) * NTpad * 256 + lane * 4;
+    const float* xb[2];
+    const long xcs = p.xt_cs;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {       // (tiled rows exist up to Bp = round_up(B, 16): clamp the row tiles past it)
+        const long row = b0 + m * 16 + r, rows = xcs >> 4;
+        xb[m] = p.xt + (row < rows ? row : rows - 1) * 16 + 4 * q;
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[m][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // epilogue operands of this thread's (row, unit): hoisted, in flight during the GEMM
+    const int bl = tid >> 3, uu8 = tid & 7, eb = b0 + bl, eu = u0 + uu8;
+    const long ebc = eb < p.B ? eb : p.B - 1;
+    float e_pre[4] = {0.f, 0.f, 0.f, 0.f}, e_b1[4] = {0.f, 0.f, 0.f, 0.f}, e_b2[4] = {0.f, 0.f, 0.f, 0.f};
+    float e_cp = 0.f, e_drop = 1.f;
+    int e_len = 0x7fffffff;
+    if (p.pre) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) e_pre[g] = p.pre[ebc * p.ldpre + g * H + eu];
+    }
+    if (p.bias1) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) e_b1[g] = p.bias1[g * H + eu];
+    }
+    if (p.bias2) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) e_b2[g] = p.bias2[g * H + eu];
+    }
+    if (p.c_prev) e_cp = p.c_prev[ebc * p.ldc_prev + eu];
+    if (p.drop) e_drop = p.drop[ebc * p.lddrop + eu];
+    if (p.len) e_len = p.len[ebc];
+    auto load_chunk = [&](int g, int j, f32x4 (&bw)[2], f32x4 (&ax)[2]) {
+        const int c = 4 * U * g + 4 * j + w;
+        const int cx = c < NT ? c : NT - 1;     // padding chunks: any finite activations x the zero weight chunk
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) bw[ct] = *reinterpret_cast<const f32x4*>(wb[ct] + (long)c * 256);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) ax[m] = *reinterpret_cast<const f32x4*>(xb[m] + xcs * cx);
+    };
+    auto mma_chunk = [&](const f32x4 (&bw)[2], const f32x4 (&ax)[2]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    acc[m][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[m][s], bw[ct][s], acc[m][ct], 0, 0, 0);
+    };
+    auto pipe_group = [&](int gl, f32x4 (&bwL)[U][2], f32x4 (&axL)[U][2], const f32x4 (&bwM)[U][2], const f32x4 (&axM)[U][2]) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            load_chunk(gl, j, bwL[j], axL[j]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_chunk(bwM[j], axM[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    {
+        f32x4 bwA[U][2], bwB[U][2], axA[U][2], axB[U][2];
+#pragma unroll
+        for (int j = 0; j < U; ++j) load_chunk(0, j, bwA[j], axA[j]);
+        int g = 0;
+        for (; g + 2 < G; g += 2) {
+            pipe_group(g + 1, bwB, axB, bwA, axA);
+            pipe_group(g + 2, bwA, axA, bwB, axB);
+        }
+        if (g + 1 < G) {
+            pipe_group(g + 1, bwB, axB, bwA, axA);
+#pragma unroll
+            for (int j = 0; j < U; ++j) mma_chunk(bwB[j], axB[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < U; ++j) mma_chunk(bwA[j], axA[j]);
+        }
+    }
+    // C layout 16x16: col = lane&15 (gate column of the tile), row = (lane>>4)*4 + reg (batch row of the tile)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) red[(((w * 2 + m) * 2 + ct) * 16 + (q * 4 + g)) * 16 + r] = acc[m][ct][g];
+    __syncthreads();
+    if (eb < p.B) {
+        const int m = bl >> 4, rl = bl & 15, ct = uu8 >> 2, uu = uu8 & 3;
+        float gsum[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float s = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) s += red[(((ww * 2 + m) * 2 + ct) * 16 + rl) * 16 + g * 4 + uu];
+            gsum[g] = s + (p.pre ? e_pre[g] : 0.f) + (p.bias1 ? e_b1[g] : 0.f) + (p.bias2 ? e_b2[g] : 0.f);
+        }
+        if (!p.c_prev) e_cp = 0.f;
+        if (!p.drop) e_drop = 1.f;
+        if (!p.len) e_len = 0x7fffffff;
+        const bool active = p.t < e_len;
+        float gi = t2_sigmoid(gsum[0]), gf = t2_sigmoid(gsum[1]), gg = t2_tanh(gsum[2]), go = t2_sigmoid(gsum[3]);
+        float cn = gf * e_cp + gi * gg;
+        float hn = go * t2_tanh(cn) * e_drop;
+        if (!active) { hn = 0.f; cn = 0.f; gi = gf = gg = go = 0.f; }
+        p.h_out[(long)eb * p.ldh + eu] = hn;
+        if (p.h_out2) p.h_out2[(long)eb * p.ldh2 + eu] = hn;
+        if (p.ht_out) { const int col = p.ht_col0 + eu; p.ht_out[(long)(col >> 4) * p.xt_cs + eb * 16 + (col & 15)] = hn; }
+        if (p.c_out) p.c_out[(long)eb * p.ldc_out + eu] = cn;
+        if (p.gates_out) *reinterpret_cast<f32x4*>(p.gates_out + (long)eb * p.ldg + 4 * eu) = (f32x4){gi, gf, gg, go};
+    }
+}
+
 int launch_fwd(const T2LstmStep* steps, int n, hipStream_t st) {
     T2_REQUIRE(n == 1 || n == 2, "lstm step: n must be 1 or 2");
     for (int i = 0; i < n; ++i) T2_TRY(t2_lstm_check_step(steps[i]));
@@ -183,8 +316,13 @@ int launch_fwd(const T2LstmStep* steps, int n, hipStream_t st) {
             // Measured in one session on the training step, 4 chunks per group beat 8 (82.05 against 82.37 ms), and every
             // deeper variant (two groups requested ahead, all loads of the step issued at entry) was slower still: past
             // ~24 KB per wave the first operands only arrive later.
+            static const int sq_tile = getenv("T2_CELL_SQ") ? atoi(getenv("T2_CELL_SQ")) : 1;
+            bool tiled_in = true;
+            for (int i = 0; i < n; ++i) tiled_in = tiled_in && steps[i].xt != nullptr;
             if (bn <= 16) hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<1, 4>), grid, block, 0, st, kk);
             else if (bn <= 32) hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<2, 4>), grid, block, 0, st, kk);
+            else if (sq_tile && tiled_in && steps[0].H % 64 == 0)      // 33..64 rows: 32 x 32 tiles, both row blocks of a column block on one XCD
+                hipLaunchKernelGGL((lstm_step_fwd_sq_kernel<4>), dim3(steps[0].H / 8, t2_cdiv(bn, 32), n), block, 0, st, kk);
             else hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<4, 4>), grid, block, 0, st, kk);
         } else {
             if (bn <= 16) hipLaunchKernelGGL((lstm_step_fwd_kernel<1>), grid, block, 0, st, kk);

@@ -286,7 +286,10 @@ def test_lstm_step_fwd_packed_tiled(dev, B, H, Ks, col0):
     st.xt = None; st.ht_out = None; st.h_out = h2.data_ptr()
     _lib.call("t2_lstm_step_fwd", st, 1, st_)
     torch.cuda.synchronize()
-    assert torch.equal(h2, h)
+    if B <= 32:
+        assert torch.equal(h2, h)
+    else:      # 33..64 rows: the tiled input takes the 32 x 32-tile kernel, row-major input the 64 x 16 one - same sums, two kernels
+        assert _rel(h2, h.double().cpu()) < 1e-6
 
 
 @pytest.mark.parametrize("B,H,S", [(32, 1024, 9), (5, 64, 6), (17, 128, 4), (64, 1024, 5), (35, 128, 4)])
