@@ -39,3 +39,14 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(tmp_path, "nope.so"))
     with pytest.raises(_lib.T2Error):
         _lib.lib()
+
+
+def test_integration_md_stub_mirrors_the_header():
+    """The ctypes stub a maintainer would paste from INTEGRATION.md must list every field of T2AttnStep in the header's order (a
+    shorter mirror makes the library read garbage behind it)."""
+    import re
+    md = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    block = md[md.index("class T2AttnStep(C.Structure)"):]
+    block = block[:block.index("]\n") + 1]
+    names = re.findall(r'\("(\w+)",\s*C\.', block)
+    assert names == [f[0] for f in _lib._structs["T2AttnStep"]], names
