@@ -3,12 +3,13 @@ Adam(L2) + MultiStepLR, i.e. what Lightning does around TTSModel.training_step i
 (run/train.py:210-243, model/tts_model.py:78-91,165-253), on the HIP engine.
 
 Data parallelism (new relative to the reference, which is single-device): one process per GPU, utterances sharded
-across ranks, the flat fp32 gradient buffer all-reduced per step over RCCL/xGMI (torch.distributed backend "nccl") - as
-two buckets, the larger one overlapped with the encoder backward (overlap_allreduce), or as ONE call - then identical
-clip + Adam on every rank.  Shards are padded to the global (L, T) maxima so that the mean of
-the per-rank loss means equals the single-device loss on the concatenated batch (the loss is a plain mean over padded
-tensors, model/tts_model.py:197-199).  BatchNorm statistics are per shard (the reference has no multi-device
-behaviour to match).
+across ranks, the flat fp32 gradient buffer all-reduced per step over RCCL/xGMI (torch.distributed backend "nccl") - ONE call
+after the backward by default, or two buckets with the larger one started behind the backward frame loop (overlap_allreduce) -
+then identical clip + Adam on every rank.  Shards are padded to the global (L, T) maxima so that the mean of the per-rank loss
+means equals the single-device loss on the concatenated batch (the loss is a plain mean over padded tensors,
+model/tts_model.py:197-199); the two lengths are agreed on the HOST, over a gloo group of the trainer's own, by the loader thread
+while the previous step runs (negotiate_shape / negotiate_collated): train_step(padded=True) reads no collective result.
+BatchNorm statistics are per shard unless sync_bn (the reference has no multi-device behaviour to match).
 """
 from __future__ import annotations
 
