@@ -401,10 +401,10 @@ def test_edge_shapes_match_oracle(B, L, T, lens, tls):
     assert torch.isfinite(ps.grad).all() and torch.isfinite(loss3).all()
 
 
-@pytest.mark.parametrize("L", [300, 768, 1024])
+@pytest.mark.parametrize("L", [300, 768, 2000])
 def test_long_text_forward_backward_match_oracle(L):
     """Texts longer than one 256-position round of the attention kernels: the forward kernels walk them in rounds, the backward
-    per-slice kernel in position tiles (2, 4 and 5 tiles here) - no length limit but the LDS images (the reference has none either,
+    per-slice kernel in position tiles (2, 4 and 10 tiles here) - no length limit but the LDS images (the reference has none either,
     model/attention.py:52-69).  Outputs and every parameter gradient against the CPU oracle."""
     dev = _dev()
     d = R.default_dims(num_chars=39, encoded_dim=64, prenet_dim=32, att_rnn_dim=64, att_dim=32, rnn_hidden_dim=64,
