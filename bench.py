@@ -2,7 +2,12 @@
 """Headline benchmark: LJSpeech-shaped teacher-forced TRAINING throughput (mel-frames/s, whole job) of the
 hand-written gfx950 path, one process per GPU (RCCL gradient all-reduce for N > 1).
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU.  Under an external launcher (torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+environment) this process IS one rank.  Without one (no WORLD_SIZE) it is the LAUNCHER: before any GPU call it starts N fresh child
+processes of this same command line, one per rank (launch_ranks below), relays rank 0's JSON line and exits with the worst child's
+return code.  `--dry-run-launch` prints the child commands and their environment instead of starting them.
 
 One step = dropout-mask generation + forward + 3-term loss + backward + [all-reduce] + global-norm clip + Adam on one
 synthetic batch of 32 utterances per GPU (SURVEY.md section 8d shapes, vanilla-lj-hifi-stop dims: 4 speaker tokens,
@@ -25,11 +30,12 @@ VANILLA = dict(num_chars=39, encoded_dim=512, encoder_kernel_size=5, num_mels=80
                att_dim=128, rnn_hidden_dim=1024, postnet_dim=512, dropout=0.5, speaker_tokens=True, num_speakers=4,
                description_embeddings=False, description_embeddings_dim=0)
 
-# What the driver's 1/2/4/8-GPU curve should show, so that a shortfall is attributable: weak scaling, identical
+# A PREDICTION, not a measurement (no multi-GPU run of this code exists yet: SCALE_r01..r04 were skipped): what the driver's
+# 1/2/4/8-GPU curve should show, so that a shortfall is attributable: weak scaling, identical
 # work per rank; per-rank step = the 1-GPU step (62.5 ms; 62.7 ms with a live RCCL communicator, measured at world size 1) + the
 # 112.5 MB gradient all-reduce, exposed behind the backward (ONE call; ring over 7 xGMI links x ~153 GB/s: 2 * 7/8 * 112.5 MB per
 # link pair = 1.3 ms at the link rate, 2.5 ms at half of it).
-EXPECTED_SCALING = dict(ms_per_step_n1=62.5, ms_per_step_with_process_group=62.7,
+PREDICTED_SCALING = dict(ms_per_step_n1=62.5, ms_per_step_with_process_group=62.7,
                         exposed_allreduce_ms=dict(one_call="1.0-2.5 (112.5 MB: 1.3 ms as a ring at the 7-link xGMI rate)", two_buckets=0.3),
                         speedup=dict(n2=1.96, n4=3.9, n8=7.7), floor_speedup_n8=7.4,
                         note="value(N) / value(1) with ONE all-reduce call after the backward (the default); below 7.4 at N=8 means a rank "
@@ -122,6 +128,81 @@ def cpu_baseline(dims, batch, t_cap=200, b_cap=32, timed_steps=3, n_inf=100):
                 decode_sample=f"{n_inf} autoregressive steps, batch {b_cap}, includes encoder and postnet of the call, {dti:.1f} s")
 
 
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as N fresh child processes of this command line
+    (one Popen per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1), wait for all of them and
+    return the worst return code.  Nothing here has touched the GPU (no HIP call, no torch.cuda.is_available()), and nothing is
+    exec'ed: the children initialise the runtime themselves.  Rank 0 inherits this process's stdout (its ONE JSON line is the
+    bench line); the other ranks' stdout goes to stderr.  A rank that fails takes the others down after a grace period (they would
+    wait in a collective for ever): terminate, then kill, by the exact PIDs started here."""
+    import subprocess
+    n = args.gpus
+    port = int(os.environ.get("MASTER_PORT", 0)) or _free_port()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    child_argv = [a for a in argv if a != "--dry-run-launch"]
+    plan = []
+    for r in range(n):
+        env = dict(RANK=str(r), LOCAL_RANK=str(0 if args.share_gpu else r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES", "16"),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", str(max(1, cores // n))))
+        plan.append(dict(cmd=[sys.executable, os.path.abspath(__file__)] + child_argv, env=env))
+    if args.dry_run_launch:
+        print(json.dumps(dict(launch=plan, note="dry run: nothing started, no GPU call made")), flush=True)
+        return 0
+    if not args.share_gpu:
+        have = torch.cuda.device_count()       # (counts devices without initialising the runtime on this image)
+        if have < n:
+            print(f"[bench] --gpus {n} but this node shows {have} GPU(s); use --share-gpu --backend gloo for a rehearsal on one card",
+                  file=sys.stderr, flush=True)
+            return 2
+    from tacotron2_amd.build import build
+    build(verbose=False)                       # hipcc, no GPU: once here instead of by rank 0 while the others wait in a barrier
+    procs = []
+    for r, p in enumerate(plan):
+        procs.append(subprocess.Popen(p["cmd"], env=dict(os.environ, **p["env"]), cwd=ROOT,
+                                      stdout=None if r == 0 else sys.stderr))
+    print(f"[bench] launcher: started {n} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}", file=sys.stderr, flush=True)
+    deadline, first_fail, grace = (time.time() + args.launch_timeout if args.launch_timeout > 0 else None), None, 20.0
+    while True:
+        rcs = [p.poll() for p in procs]
+        if all(rc is not None for rc in rcs):
+            break
+        now = time.time()
+        if first_fail is None and any(rc not in (None, 0) for rc in rcs):
+            first_fail = now
+            bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+            print(f"[bench] launcher: rank(s) failed {bad}; the others get {grace:.0f} s", file=sys.stderr, flush=True)
+        if (first_fail is not None and now - first_fail > grace) or (deadline is not None and now > deadline):
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_end = time.time() + 10
+            while time.time() < t_end and any(p.poll() is None for p in procs):
+                time.sleep(0.1)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            if first_fail is None:
+                print("[bench] launcher: --launch-timeout reached", file=sys.stderr, flush=True)
+        time.sleep(0.2)
+    rcs = [p.wait() for p in procs]
+    worst = next((rc for rc in rcs if rc != 0), 0)
+    if worst:
+        print(f"[bench] launcher: return codes per rank {rcs}", file=sys.stderr, flush=True)
+    return worst if worst > 0 else (1 if worst else 0)       # (a signal-killed child: negative code -> 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,11 +225,19 @@ def main():
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel step (process group, both gradient all-reduce buckets, Work.wait, [sync-BN reduces]) "
                          "also at --gpus 1: every RCCL call of the step on a single-GPU box; the sums are identities")
+    ap.add_argument("--dry-run-launch", action="store_true",
+                    help="with --gpus N and no launcher: print the N child commands / environments as one JSON line and exit (no GPU call)")
+    ap.add_argument("--launch-timeout", type=float, default=0.0, help="launcher: seconds after which all ranks are ended (0: none)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.dry_run_launch):
+        sys.exit(launch_ranks(args, sys.argv[1:]))     # this process is the launcher: it never touches the GPU
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world} in the environment (an external launcher with another rank count); "
+              "drop WORLD_SIZE to let bench.py start its own ranks", file=sys.stderr, flush=True)
+        sys.exit(2)
     dev = torch.device("cuda", local)
     if world > 1 or args.force_dp:        # (the process group first, before any GPU call of this process)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
@@ -162,7 +251,7 @@ def main():
 
     from tacotron2_amd.build import build
     if rank == 0:
-        build(verbose=False)
+        build(verbose=False)                  # (a no-op when bench.py's own launcher has built already)
     if world > 1:
         dist.barrier()
     from tacotron2_amd.init import init_parameters
@@ -191,20 +280,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # do the engine's two streams run side by side in THIS process (GPU_MAX_HW_QUEUES, tacotron2_amd/__init__.py)?  Trainer checks
+    # it when data-parallel (a live communicator brings streams of its own); measured here at N = 1 too, reported in the line
+    qc = tr.queue_check or tr.engine.stream_concurrency_check()
+
     # (the batch is fixed and already at the global shape: no per-step shape negotiation - it would put a host read of an
     #  all-reduce result in front of every step)
     for _ in range(args.warmup):
         tr.train_step(batch, padded=True)
     sync()
     tr.engine.profile = True
+    step_marks = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss3, _ = tr.train_step(batch, padded=True)
+        step_marks.append(tr.engine.marks)   # (train_step starts a new list per step; the events are read after the timed region)
+    t_enq = time.perf_counter() - t0         # host: all steps enqueued (far below dt when the GPU is the bound, as it should be)
     sync()
     dt = time.perf_counter() - t0
     tr.engine.profile = False
     tr.engine.check_persistent_kernels()     # (after the timed region: a host read of the persistent launches' timeout flag)
     seg = tr.engine.segment_times_ms()       # last timed step (events recorded inside the timed region)
+    # per rank, over all timed steps: GPU time of a step on the main stream (first to last mark), of which the gradient all-reduce
+    # segment (RCCL: the wire AND the wait for the slowest rank's backward) - so that "a rank was slow" (its own_step_ms - allreduce_ms
+    # is the largest) and "the wire was slow" (allreduce_ms large on every rank) can be told apart in a scaling run
+    ar_ms, gpu_ms = [], []
+    for marks in step_marks:
+        if len(marks) >= 2:
+            gpu_ms.append(marks[0][1].elapsed_time(marks[-1][1]))
+            ar_ms.append(sum(e0.elapsed_time(e1) for (_, e0), (n1, e1) in zip(marks[:-1], marks[1:]) if n1 == "allreduce"))
+    mine = dict(rank=rank, ms_per_step=dt / args.steps * 1e3, host_enqueue_ms_per_step=t_enq / args.steps * 1e3,
+                gpu_step_ms=sum(gpu_ms) / max(len(gpu_ms), 1), allreduce_ms=sum(ar_ms) / max(len(ar_ms), 1),
+                valid_frames=float(batch["mel_spectrogram_len"].sum()), queue_check_ok=(qc or {}).get("ok"))
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -289,10 +400,11 @@ def main():
                                sync_batchnorm=bool(tr.sync_bn),
                                allreduce=("none" if not tr.dp else "2 buckets, tail overlapped with the encoder backward"
                                           if tr.overlap_allreduce else "1 call after the backward"),
+                               queue_check=qc,
                                shape_negotiation="none inside the timed region: one fixed batch, padded to the global shape before "
                                                  "it (main.py train agrees the shape of step k+1 on the host, in the loader thread, "
                                                  "over its own gloo group while step k runs: nothing on the step path either)",
-                               expected_scaling=EXPECTED_SCALING),
+                               predicted_unmeasured=PREDICTED_SCALING),
                    padded_frames_per_s=float(frames[1]) * args.steps / dt,
                    loss=[float(x) for x in loss3.cpu()],
                    roofline=dict(bound="hbm", kernel="teacher-forced decoder frame loop, forward (pre_att GEMM + attention "
@@ -300,7 +412,9 @@ def main():
                                  achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                                  traffic=None, algorithmic_bytes_per_step=decoder_step_bytes(B, L, Ef),
                                  us_per_decoder_step=dec_fwd_ms * 1e3 / T if T else None),
-                   segments_ms={k: round(v, 3) for k, v in seg.items()}, decode=decode, matmul_precision_high=high)
+                   segments_ms={k: round(v, 3) for k, v in seg.items()},
+                   per_rank=[{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in per_rank],
+                   decode=decode, matmul_precision_high=high)
         # HBM-side bytes of the same kernels from rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE, profiles/):
         # recorded offline because counters cannot be collected inside this process
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")

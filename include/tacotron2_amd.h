@@ -150,6 +150,13 @@ int t2_lstm_seq_fwd_persist_n(const T2LstmStep* base, const T2LstmStride* inc, i
  * the same check itself and returns the same code. */
 int t2_lstm_persist_resident(int H, int K, int B);
 int t2_lstm_persist_resident_n(int H, int K, int B, int n);      /* the same for n cells per launch (n * H/4 workgroups) */
+/* Stream-concurrency probe (no reference counterpart: the reference is single-stream, run/train.py:235-243).  The engine needs
+ * its two streams on different hardware queues (tacotron2_amd/__init__.py); Trainer.queue_check times `n` dependent one-thread
+ * launches on one stream (t2_stream_probe_chain: word[0] += 1 per launch) alone and next to ONE idle wave that holds the other
+ * stream for `microseconds` of wall-clock time (t2_stream_probe_spin, bounded: <= 50 ms and <= 2^24 polls).  Streams that share a
+ * queue serialise: the chain then takes the spin's time longer. */
+int t2_stream_probe_chain(uint32_t* word, int n, void* stream);
+int t2_stream_probe_spin(uint32_t* word, int microseconds, void* stream);
 /* Debug / test hook: bound of the inter-workgroup waits of t2_lstm_seq_fwd_persist in polls (default 1 << 21; < 0: every wait
  * is treated as timed out, which raises the sticky flag sync[256] deterministically).  Returns the previous value. */
 int t2_debug_persist_spin_limit(int polls);

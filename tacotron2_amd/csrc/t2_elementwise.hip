@@ -524,9 +524,32 @@ __global__ void guard_poison_kernel(const uint32_t* flag, float* x, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] = __builtin_nanf("");
 }
 
+// Stream-concurrency probe (t2_stream_probe_*): a chain of dependent one-thread launches, and one wave that idles for a
+// bounded wall-clock time (s_memrealtime: 100 MHz, independent of the shader clock; s_sleep between polls).
+__global__ void probe_tick_kernel(uint32_t* word) { word[0] += 1u; }
+__global__ void probe_spin_kernel(uint32_t* word, unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned polls = 0;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks && polls < (1u << 24)) { __builtin_amdgcn_s_sleep(16); ++polls; }
+    word[0] = polls;
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
+
+extern "C" int t2_stream_probe_chain(uint32_t* word, int n, void* stream) {
+    (void)hipGetLastError();
+    T2_REQUIRE(word && n >= 0 && n <= 100000, "t2_stream_probe_chain: bad arguments");
+    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(probe_tick_kernel, dim3(1), dim3(1), 0, ST, word);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
+extern "C" int t2_stream_probe_spin(uint32_t* word, int microseconds, void* stream) {
+    (void)hipGetLastError();
+    T2_REQUIRE(word && microseconds >= 0 && microseconds <= 50000, "t2_stream_probe_spin: 0..50000 us");
+    hipLaunchKernelGGL(probe_spin_kernel, dim3(1), dim3(64), 0, ST, word, (unsigned long long)microseconds * 100ull);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
 
 extern "C" int t2_guard_poison(const uint32_t* flag, float* x, int64_t n, void* stream) {
     (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked

@@ -211,7 +211,13 @@ class DevicePrefetcher:
     will take (the thread stops there, so no rank is left inside a collective its peers never enter), `cycle` = start the loader
     again when it is exhausted (a new epoch: shuffling samplers draw their next permutation) instead of ending the iteration -
     ranks whose shards differ by an utterance have epochs of different length, the k-th batch of every rank still meets the k-th
-    batch of the others.  `device` may be the CPU (host-logic tests): no stream, no events."""
+    batch of the others.  `device` may be the CPU (host-logic tests): no stream, no events.
+
+    With `negotiate` the object is SINGLE-USE and must be consumed to its `limit`: `produced` counts batches when they are queued,
+    and a consumer that stops early (break, exception) discards queued batches whose shapes its peers have already agreed on - a
+    second iteration would then enter fewer collectives than they expect.  A peer that dies leaves this rank's loader thread inside
+    the negotiation's all-reduce until the host-side group's timeout (Trainer(shape_timeout_s=...), 300 s), after which the error
+    surfaces in the consumer."""
 
     _END = object()
 

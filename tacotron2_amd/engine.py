@@ -162,6 +162,39 @@ class Engine:
             self._side = torch.cuda.Stream(device=self.dev)
         return self._side
 
+    def stream_concurrency_check(self, n: int = 200, spin_us: int = 3000) -> dict:
+        """Do this engine's two streams run side by side?  `n` dependent one-thread launches on the main stream, timed with HIP
+        events alone and then next to one idle wave that holds the side stream for `spin_us` (t2_stream_probe_*).  Streams that
+        the runtime mapped onto ONE hardware queue (GPU_MAX_HW_QUEUES too small for the streams of this process - a live RCCL
+        communicator brings its own, tacotron2_amd/__init__.py) serialise: the chain then waits for the spin.  Synchronises the
+        host; meant for start-up (Trainer calls it once when data-parallel)."""
+        import os
+        main, side = torch.cuda.current_stream(), self.side_stream()
+        w = torch.zeros(8, dtype=torch.int32, device=self.dev)
+
+        def chain():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(main)
+            call("t2_stream_probe_chain", w, n, main.cuda_stream)
+            e1.record(main)
+            return e0, e1
+
+        call("t2_stream_probe_chain", w, 20, main.cuda_stream)          # warm-up (code object load)
+        call("t2_stream_probe_spin", _ptr(w, 4), 10, side.cuda_stream)
+        torch.cuda.synchronize(self.dev)
+        a0, a1 = chain()
+        torch.cuda.synchronize(self.dev)
+        alone_us = a0.elapsed_time(a1) * 1e3
+        side.wait_stream(main)
+        call("t2_stream_probe_spin", _ptr(w, 4), spin_us, side.cuda_stream)
+        b0, b1 = chain()
+        torch.cuda.synchronize(self.dev)
+        beside_us = b0.elapsed_time(b1) * 1e3
+        ok = beside_us < alone_us + 0.5 * spin_us
+        return dict(ok=bool(ok), launches=n, chain_alone_us=round(alone_us, 1), chain_beside_spin_us=round(beside_us, 1),
+                    spin_us=spin_us, us_per_dependent_launch=round(alone_us / n, 2),
+                    GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES"))
+
     def mark(self, name: str):
         if self.profile:
             ev = torch.cuda.Event(enable_timing=True)

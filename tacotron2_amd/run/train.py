@@ -122,7 +122,8 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
                                bucket_window=bucket_window, seed=0 if bucket_window else rank, rank=rank, world=world)
         # items and host->device copies of the next batches are prepared by a background thread on its own stream
         prefetch = DevicePrefetcher(loader, _to_dev, dev, depth=int(training_config.get("prefetch_batches", 2)),
-                                    negotiate=tr.negotiate_collated if tr.dp else None, limit=max(0, max_steps - start_step),
+                                    negotiate=tr.negotiate_collated if tr.loader_negotiation else None,
+                                    limit=max(0, max_steps - start_step),
                                     cycle=True)
         def batches():
             yield from prefetch
@@ -180,12 +181,15 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
     it = batches()
     steps_done = 0
     log_every = int(training_config["args"].get("log_every_n_steps", 50))
+    # (data-parallel without a host-side group - Trainer warned - : nothing was negotiated by the loader thread, train_step agrees
+    #  the shape itself on the main thread.  The synthetic generator pads on the main thread already.)
+    pre_padded = synthetic or not tr.dp or tr.loader_negotiation
     sync_debug = os.environ.get("T2_SYNC_DEBUG") == "1"      # tests: prove that a training step never blocks the host
     for step in range(start_step, max_steps):
         batch = next(it)
         if sync_debug:
             torch.cuda.set_sync_debug_mode("error")     # (diagnostic: any host synchronisation inside the step raises)
-        loss3, _ = tr.train_step(batch, padded=True)
+        loss3, _ = tr.train_step(batch, padded=pre_padded)
         if sync_debug:
             torch.cuda.set_sync_debug_mode("default")
         steps_done += 1

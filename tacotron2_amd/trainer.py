@@ -25,7 +25,7 @@ from .params import ParamStore
 class Trainer:
     def __init__(self, ps: ParamStore, lr: float, weight_decay: float, scheduler_milestones: Sequence[int] = (),
                  max_norm: float = 1.0, seed: int = 1234, sync_bn: bool = False, overlap_allreduce: bool = False,
-                 force_collectives: bool = False):
+                 force_collectives: bool = False, shape_timeout_s: float = 300.0):
         self.ps = ps
         self.engine = Engine(ps)
         self.base_lr, self.weight_decay, self.max_norm = lr, weight_decay, max_norm
@@ -68,12 +68,32 @@ class Trainer:
         # loader thread negotiate batch k+1 while step k runs (DevicePrefetcher(negotiate=...)); collectives of one communicator
         # must be issued in one order on every rank, two threads on the same group could not promise that.
         self._shape_group = None
+        self.queue_check = None
         if self.dp:
+            import datetime
             try:
-                self._shape_group = dist.new_group(backend="gloo")
-            except Exception as e:      # (no host transport: fall back to the default group, device tensors on an accelerator backend)
+                # (a short timeout: a rank that died leaves its peers' loader threads inside this group's all-reduce - they must
+                #  get an error, not wait for the default half hour)
+                self._shape_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=shape_timeout_s))
+            except Exception as e:
+                # No host transport.  The loader thread must then NOT negotiate (negotiate_collated is None below): the MAX reduce
+                # would go over the data-path communicator from a second thread, next to the main thread's gradient reduces -
+                # collectives of one communicator issued in different orders on different ranks.  The shape is agreed on the main
+                # thread instead, in train_step(padded=False), on the default group (one host read per step).
                 import warnings
-                warnings.warn(f"Trainer: no gloo group for the shape negotiation ({e}); using the default process group")
+                warnings.warn(f"Trainer: no gloo group for the shape negotiation ({e}); the padded shape of every step is agreed on "
+                              "the main thread over the default process group (one host synchronisation per step)")
+            if ps.device.type == "cuda":
+                # The engine's two streams must run side by side (tacotron2_amd/__init__.py: GPU_MAX_HW_QUEUES); with a live
+                # communicator in the process this is checked, not assumed - a step that silently serialises takes 86 instead of
+                # 62 ms (profiles/r04_rccl_hw_queues.txt) and nothing else would say why.
+                self.queue_check = self.engine.stream_concurrency_check()
+                if not self.queue_check["ok"]:
+                    import warnings
+                    warnings.warn("Trainer: the engine's main and side streams do NOT run concurrently in this process "
+                                  f"({self.queue_check}): they share a hardware queue.  Set GPU_MAX_HW_QUEUES=16 (or more) in the "
+                                  "environment BEFORE the first GPU call of the process (import tacotron2_amd first); every "
+                                  "training step will otherwise be ~35 % slower.")
 
     def _start_tail_allreduce(self):
         # (called by Engine.backward_tf with its side stream current: the collective is ordered behind that stream's work)
@@ -138,12 +158,21 @@ class Trainer:
         Lg, Tg = self.negotiate_shape(batch["chars_idx"].shape[1], batch["mel_spectrogram"].shape[1])
         return self.pad_to(batch, Lg, Tg)
 
+    @property
+    def loader_negotiation(self) -> bool:
+        """True when the padded shape of a step may be agreed from the loader thread (a host-side group of the trainer's own
+        exists); False: only on the main thread (train_step(padded=False) / global_pad)."""
+        return self.dp and self._shape_group is not None
+
     def negotiate_collated(self, collated):
         """`negotiate` hook of DevicePrefetcher: a collated HOST batch (data, metadata, extra) of the loader, padded to the step's
         global shape in the loader thread - one step ahead of the training loop, which then calls train_step(padded=True)."""
         data, meta, extra = collated
         if not self.dp:
             return collated
+        if self._shape_group is None:
+            raise RuntimeError("Trainer.negotiate_collated needs the host-side (gloo) group: without it the shape is agreed on the "
+                               "main thread (train_step(padded=False)); see Trainer.loader_negotiation")
         Lg, Tg = self.negotiate_shape(data["chars_idx"].shape[1], data["mel_spectrogram"].shape[1])
         return self.pad_to(data, Lg, Tg), meta, extra
 

@@ -167,3 +167,46 @@ def test_dp2_loader_thread_negotiates_the_global_shape_one_step_ahead():
         mp.spawn(_prefetch_worker, args=(world, port, out), nprocs=world, join=True)
         out = dict(out)
     assert out[0] == out[1] and len(out[0]) == 9
+
+
+def _no_host_group_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import warnings
+    from tacotron2_amd.params import ParamStore
+    from tacotron2_amd.trainer import Trainer
+    real_new_group = dist.new_group
+
+    def failing_new_group(*a, **k):
+        raise RuntimeError("no host transport (test)")
+    dist.new_group = failing_new_group
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            tr = Trainer(ParamStore(R.default_dims(**SMALL, dropout=0.0), "cpu"), lr=1e-3, weight_decay=1e-6)
+    finally:
+        dist.new_group = real_new_group
+    assert tr.dp and tr._shape_group is None and not tr.loader_negotiation
+    assert any("main thread" in str(x.message) for x in w)
+    # the loader-thread hook refuses (it would issue a collective of the data-path group from a second thread) ...
+    data = dict(chars_idx=torch.ones(2, 5 + rank, dtype=torch.int64), mel_spectrogram=torch.zeros(2, 9 - rank, 4), gate=torch.zeros(2, 9 - rank, 1))
+    with pytest.raises(RuntimeError, match="host-side"):
+        tr.negotiate_collated((data, {}, {}))
+    # ... and the main-thread negotiation still agrees the global shape, over the default group
+    padded = tr.global_pad(data)
+    out[rank] = (padded["chars_idx"].shape[1], padded["mel_spectrogram"].shape[1], padded["gate"].shape[1])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp2_without_a_host_side_group_the_shape_is_agreed_on_the_main_thread_only():
+    """when `dist.new_group(backend="gloo")` fails the loader thread must not negotiate (its MAX reduce would
+    run on the gradient all-reduce's communicator from a second thread).  Trainer then reports loader_negotiation = False,
+    negotiate_collated raises, run/train.py passes negotiate=None and train_step(padded=False) agrees the shape itself."""
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_no_host_group_worker, args=(world, port, out), nprocs=world, join=True)
+        out = dict(out)
+    assert out[0] == out[1] == (6, 9, 9)
