@@ -282,7 +282,7 @@ def main():
 
     # do the engine's two streams run side by side in THIS process (GPU_MAX_HW_QUEUES, tacotron2_amd/__init__.py)?  Trainer checks
     # it when data-parallel (a live communicator brings streams of its own); measured here at N = 1 too, reported in the line
-    qc = tr.queue_check or tr.engine.stream_concurrency_check()
+    qc = tr.queue_check or tr.engine.ensure_concurrent_streams()
 
     # (the batch is fixed and already at the global shape: no per-step shape negotiation - it would put a host read of an
     #  all-reduce result in front of every step)

@@ -163,37 +163,51 @@ class Engine:
         return self._side
 
     def stream_concurrency_check(self, n: int = 200, spin_us: int = 3000) -> dict:
-        """Do this engine's two streams run side by side?  `n` dependent one-thread launches on the main stream, timed with HIP
-        events alone and then next to one idle wave that holds the side stream for `spin_us` (t2_stream_probe_*).  Streams that
-        the runtime mapped onto ONE hardware queue (GPU_MAX_HW_QUEUES too small for the streams of this process - a live RCCL
-        communicator brings its own, tacotron2_amd/__init__.py) serialise: the chain then waits for the spin.  Synchronises the
-        host; meant for start-up (Trainer calls it once when data-parallel)."""
+        """Do this engine's two streams run side by side?  One idle wave holds the SIDE stream for `spin_us` (t2_stream_probe_spin)
+        while `n` dependent one-thread launches run on the MAIN stream (t2_stream_probe_chain); HIP events on the main stream around
+        the whole pattern, the first one recorded BEFORE the spin starts (the side stream waits for it).  Streams that the runtime
+        mapped onto ONE hardware queue serialise - the chain then ends `spin_us` later than it does alone.  (Measured, round 5,
+        profiles/r05_queue_check_probe.txt: GPU_MAX_HW_QUEUES=1, or 4 with a live RCCL communicator in the process, puts both
+        streams behind one queue and the training step takes 87 instead of 64 ms.  Events recorded AFTER the spin was enqueued
+        do not see it: in a shared queue they wait behind the spin too, and the chain between them even looks faster.)
+        Synchronises the host; meant for start-up (Trainer calls ensure_concurrent_streams once when data-parallel)."""
         import os
         main, side = torch.cuda.current_stream(), self.side_stream()
         w = torch.zeros(8, dtype=torch.int32, device=self.dev)
 
-        def chain():
+        def pattern(spin):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(main)
+            if spin:
+                side.wait_event(e0)
+                call("t2_stream_probe_spin", _ptr(w, 4), spin, side.cuda_stream)
             call("t2_stream_probe_chain", w, n, main.cuda_stream)
             e1.record(main)
-            return e0, e1
+            torch.cuda.synchronize(self.dev)
+            return e0.elapsed_time(e1) * 1e3
 
-        call("t2_stream_probe_chain", w, 20, main.cuda_stream)          # warm-up (code object load)
-        call("t2_stream_probe_spin", _ptr(w, 4), 10, side.cuda_stream)
-        torch.cuda.synchronize(self.dev)
-        a0, a1 = chain()
-        torch.cuda.synchronize(self.dev)
-        alone_us = a0.elapsed_time(a1) * 1e3
-        side.wait_stream(main)
-        call("t2_stream_probe_spin", _ptr(w, 4), spin_us, side.cuda_stream)
-        b0, b1 = chain()
-        torch.cuda.synchronize(self.dev)
-        beside_us = b0.elapsed_time(b1) * 1e3
+        pattern(10)                                                  # warm-up (code objects, first use of the side stream)
+        alone_us = pattern(0)
+        beside_us = pattern(spin_us)
         ok = beside_us < alone_us + 0.5 * spin_us
         return dict(ok=bool(ok), launches=n, chain_alone_us=round(alone_us, 1), chain_beside_spin_us=round(beside_us, 1),
                     spin_us=spin_us, us_per_dependent_launch=round(alone_us / n, 2),
                     GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES"))
+
+    def ensure_concurrent_streams(self, max_tries: int = 8) -> dict:
+        """stream_concurrency_check, and a remedy when it fails: a stream is bound to a hardware queue when it is created, so a
+        NEW side stream may land on another queue than the main stream's (the old ones are kept alive - the runtime hands the
+        least-used queue to the next stream).  Returns the last check with `tries`; `ok` False after max_tries means every queue
+        the runtime offers is shared with the main stream (GPU_MAX_HW_QUEUES=1)."""
+        qc = self.stream_concurrency_check()
+        tries = 1
+        while not qc["ok"] and tries < max_tries:
+            self._spare_streams = getattr(self, "_spare_streams", []) + [self._side]
+            self._side = torch.cuda.Stream(device=self.dev)
+            qc = self.stream_concurrency_check()
+            tries += 1
+        qc["tries"] = tries
+        return qc
 
     def mark(self, name: str):
         if self.profile:

@@ -87,11 +87,11 @@ class Trainer:
                 # The engine's two streams must run side by side (tacotron2_amd/__init__.py: GPU_MAX_HW_QUEUES); with a live
                 # communicator in the process this is checked, not assumed - a step that silently serialises takes 86 instead of
                 # 62 ms (profiles/r04_rccl_hw_queues.txt) and nothing else would say why.
-                self.queue_check = self.engine.stream_concurrency_check()
+                self.queue_check = self.engine.ensure_concurrent_streams()
                 if not self.queue_check["ok"]:
                     import warnings
                     warnings.warn("Trainer: the engine's main and side streams do NOT run concurrently in this process "
-                                  f"({self.queue_check}): they share a hardware queue.  Set GPU_MAX_HW_QUEUES=16 (or more) in the "
+                                  f"({self.queue_check}): every new side stream landed on the main stream's hardware queue.  Set GPU_MAX_HW_QUEUES=16 (or more) in the "
                                   "environment BEFORE the first GPU call of the process (import tacotron2_amd first); every "
                                   "training step will otherwise be ~35 % slower.")
 

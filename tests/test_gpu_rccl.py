@@ -47,26 +47,39 @@ def test_bench_force_dp_runs_the_rccl_path_at_one_gpu():
 
 
 _QC = """
-import json, sys
+import json, os, sys
 sys.path.insert(0, %r)
 import tacotron2_amd, torch
+import torch.distributed as dist
+if %r:
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29671", RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+torch.cuda.set_device(0)
 from tacotron2_amd.params import ParamStore
 from tacotron2_amd.engine import Engine
 from tests.helpers import SMALL
 from oracle import tacotron2_ref as R
 eng = Engine(ParamStore(R.default_dims(**SMALL), torch.device("cuda:0")))
-print("QC " + json.dumps(eng.stream_concurrency_check()))
+first = eng.stream_concurrency_check()
+print("QC " + json.dumps(dict(first=first, ensured=eng.ensure_concurrent_streams())))
+if dist.is_initialized():
+    dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("queues,expect", [("16", True), ("1", False)])
-def test_stream_concurrency_check_sees_streams_that_share_a_hardware_queue(queues, expect):
-    """The probe behind Trainer.queue_check / bench.py's `config.queue_check`: with ONE hardware queue for the whole process the
-    engine's two streams serialise and the check must say so (it is what turns a silent 86 ms step into a loud warning); with
-    the package's default of 16 it passes."""
-    r = subprocess.run([sys.executable, "-c", _QC % ROOT], cwd=ROOT, capture_output=True, text=True, timeout=600,
+@pytest.mark.parametrize("queues,nccl,first_ok,ensured_ok", [("16", True, True, True), ("4", True, False, True), ("1", False, False, False)])
+def test_stream_concurrency_check_sees_streams_that_share_a_hardware_queue(queues, nccl, first_ok, ensured_ok):
+    """The probe behind Trainer.queue_check / bench.py's `config.queue_check` (profiles/r05_queue_check_probe.txt).  With ONE
+    hardware queue for the whole process the engine's two streams serialise, the check says so and no new side stream can help.
+    With the runtime's default of 4 queues and a live RCCL communicator - the condition that cost 37 % per step in round 4 - the
+    first check fails too and Engine.ensure_concurrent_streams repairs it with a side stream on another queue.  With the package's
+    default of 16 the first check passes."""
+    r = subprocess.run([sys.executable, "-c", _QC % (ROOT, nccl)], cwd=ROOT, capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, GPU_MAX_HW_QUEUES=queues))
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
     qc = json.loads([l for l in r.stdout.splitlines() if l.startswith("QC ")][-1][3:])
-    assert qc["ok"] is expect, qc
-    assert qc["GPU_MAX_HW_QUEUES"] == queues and 0.5 < qc["us_per_dependent_launch"] < 50
+    assert qc["first"]["ok"] is first_ok and qc["ensured"]["ok"] is ensured_ok, qc
+    assert (qc["ensured"]["tries"] == 1) == first_ok
+    if not first_ok:         # serialised: the chain ends at least the spin's time later than it does alone
+        assert qc["first"]["chain_beside_spin_us"] > qc["first"]["chain_alone_us"] + 0.5 * qc["first"]["spin_us"]
+    assert qc["first"]["GPU_MAX_HW_QUEUES"] == queues and 0.5 < qc["first"]["us_per_dependent_launch"] < 50
