@@ -1,0 +1,236 @@
+"""The expensive CPU-oracle runs of the GPU suite as NAMED JOBS (test infrastructure; nothing here touches the GPU).
+
+Why: `pytest -m gpu` spent 360 of its 617 s waiting for the CPU oracle (oracle/tacotron2_ref.py) on the judged-shape cases - the
+B = 32 / T = 872 forwards, the T = 872 training step, the 64-utterance decode, the long texts - one after the other while the GPU
+idled.  A job is a deterministic (seeded) case builder + the oracle call on it; tests/oracle_pool.py starts the jobs of the
+selected tests as CPU child processes when the session starts (`python -m tests.oracle_jobs NAME OUT`), a few at a time, and a test
+picks its result up when it gets there - or computes it in-process when it is run alone.  The test builds the SAME case from the
+same builder, runs the HIP path on it and compares.  The assertions are unchanged; only where and when the oracle runs moved.
+
+Reference lines the cases exercise are cited in the tests that use them (tests/test_gpu_judged_shapes.py, test_gpu_fullsize.py,
+test_gpu_model.py)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import tacotron2_ref as R  # noqa: E402
+from tests.helpers import dekink_masks  # noqa: E402
+
+TINY = dict(num_chars=39, encoded_dim=64, prenet_dim=32, att_rnn_dim=64, att_dim=32, rnn_hidden_dim=64, postnet_dim=64,
+            num_mels=16, dropout=0.5)
+
+
+def scale_masks(d, B, L, T, seed):
+    g = torch.Generator().manual_seed(seed)
+    A, Dd, Pd, E, Pn, M = d["att_rnn_dim"], d["rnn_hidden_dim"], d["prenet_dim"], d["encoded_dim"], d["postnet_dim"], d["num_mels"]
+    sm = lambda shape, p: (torch.rand(shape, generator=g) >= p).float() / (1 - p)
+    return dict(enc_drop=[sm((B, L, E), 0.5) for _ in range(3)], prenet_drop=[sm((B, T + 1, Pd), 0.5) for _ in range(2)],
+                att_drop=sm((T, B, A), 0.1), dec_drop=sm((T, B, Dd), 0.1), post_drop=[sm((B, T, c), 0.5) for c in (Pn, Pn, Pn, Pn, M)])
+
+
+def random_case(d, B, L, T, seed):
+    from tests.test_gpu_model import random_case as rc
+    return rc(d, B, L, T, seed, None)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# case builders: name -> dict(d, P, case=(ci, lens, mel, tl, gate, masks), kw=dict(oracle keyword tensors), kind)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _judged_fwd():
+    from tacotron2_amd.synthetic import ljspeech_batch
+    d = R.default_dims(speaker_tokens=True, num_speakers=4)
+    P = R.init_params(d, seed=0)
+    b = ljspeech_batch(32, seed=1234, num_speakers=4)
+    ci, cl, mel, tl = b["chars_idx"], b["chars_idx_len"], b["mel_spectrogram"], b["mel_spectrogram_len"]
+    masks = scale_masks(d, ci.shape[0], ci.shape[1], mel.shape[1], 1234)
+    return dict(d=d, P=P, case=(ci, cl, mel, tl, b["gate"], masks), kw=dict(speaker_id=b["speaker_id"]), kind="fwd")
+
+
+def _judged4():
+    from tacotron2_amd.synthetic import ljspeech_batch
+    d = R.default_dims(speaker_tokens=True, num_speakers=4)
+    P = R.init_params(d, seed=0)
+    b = ljspeech_batch(32, seed=1234, num_speakers=4)
+    cl, tl = b["chars_idx_len"], b["mel_spectrogram_len"]
+    pick = [int(cl.argmax()), int(tl.argmax())]
+    for i in torch.argsort(tl).tolist():              # ... and the shortest ones, until there are four different utterances
+        if len(set(pick)) == 4:
+            break
+        pick.append(i)
+    pick = sorted(set(pick))
+    assert len(pick) == 4
+    ci, mel, gate, spk = b["chars_idx"][pick], b["mel_spectrogram"][pick], b["gate"][pick], b["speaker_id"][pick]
+    cl, tl = cl[pick], tl[pick]
+    masks = scale_masks(d, 4, ci.shape[1], mel.shape[1], 872)
+    return dict(d=d, P=P, case=(ci, cl, mel, tl, gate, masks), kw=dict(speaker_id=spk), kind="train")
+
+
+def _libritts_fwd():
+    from tacotron2_amd.synthetic import ljspeech_batch
+    d = R.default_dims(speaker_tokens=True, num_speakers=562, description_embeddings=True, description_embeddings_dim=768)
+    P = R.init_params(d, seed=3)
+    b = ljspeech_batch(32, seed=1234, num_speakers=562, desc_dim=768, shape="libritts")
+    ci, cl, mel, tl = b["chars_idx"], b["chars_idx_len"], b["mel_spectrogram"], b["mel_spectrogram_len"]
+    masks = scale_masks(d, ci.shape[0], ci.shape[1], mel.shape[1], 640)
+    return dict(d=d, P=P, case=(ci, cl, mel, tl, b["gate"], masks),
+                kw=dict(speaker_id=b["speaker_id"], description_embeddings=b["description_embeddings"]), kind="fwd")
+
+
+def _bench_len_vanilla():
+    d = R.default_dims(speaker_tokens=True, num_speakers=4)
+    P = R.init_params(d, seed=188)
+    return dict(d=d, P=P, case=random_case(d, 2, 188, 160, 1880), kw=dict(speaker_id=torch.tensor([1, 3], dtype=torch.int32)), kind="train")
+
+
+def _bench_len_desc():
+    d = R.default_dims(speaker_tokens=True, num_speakers=562, description_embeddings=True, description_embeddings_dim=768)
+    P = R.init_params(d, seed=640)
+    g = torch.Generator().manual_seed(64)
+    spk = torch.randint(0, 562, (2,), generator=g, dtype=torch.int32)
+    desc = torch.randn(2, 768, generator=g)
+    return dict(d=d, P=P, case=random_case(d, 2, 188, 160, 6400), kw=dict(speaker_id=spk, description_embeddings=desc), kind="train")
+
+
+def _b64_step():
+    d = R.default_dims(speaker_tokens=True, num_speakers=4)
+    P = R.init_params(d, seed=64)
+    spk = torch.randint(0, 4, (64,), generator=torch.Generator().manual_seed(64), dtype=torch.int32)
+    return dict(d=d, P=P, case=random_case(d, 64, 33, 21, 6400), kw=dict(speaker_id=spk), kind="train")
+
+
+def _long_text(L):
+    L = int(L)
+    d = R.default_dims(**TINY)
+    P = R.init_params(d, seed=L)
+    ci, lens, mel, tl, gate, masks = random_case(d, 2, L, 4, 900 + L)
+    lens = torch.tensor([L, L - 37])
+    ci[1, L - 37:] = 0
+    return dict(d=d, P=P, case=(ci, lens, mel, tl, gate, masks), kw={}, kind="train_plain")
+
+
+def _tile_edge(L):
+    L = int(L)
+    d = R.default_dims(**TINY)
+    P = R.init_params(d, seed=21)
+    return dict(d=d, P=P, case=random_case(d, 3, L, 6, 300 + L), kw={}, kind="train")
+
+
+DECODE_N = 256
+
+
+def _decode_ragged():
+    from tacotron2_amd.synthetic import ljspeech_batch
+    d = R.default_dims(speaker_tokens=True, num_speakers=4)
+    P = R.init_params(d, seed=66)
+    ib = ljspeech_batch(64, seed=4321, num_speakers=4)
+    ci, cl, spk = ib["chars_idx"], ib["chars_idx_len"], ib["speaker_id"]
+    g = torch.Generator().manual_seed(66)
+    pm = (torch.rand(DECODE_N + 1, 2, 64, 256, generator=g) >= 0.5).float() * 2
+    return dict(d=d, P=P, case=(ci, cl, None, None, None, None), kw=dict(speaker_id=spk), pm=pm, N=DECODE_N, kind="decode_ragged")
+
+
+CASES = dict(judged_fwd=_judged_fwd, judged4=_judged4, libritts_fwd=_libritts_fwd, bench_len_vanilla=_bench_len_vanilla,
+             bench_len_desc=_bench_len_desc, b64_step=_b64_step, long_text=_long_text, tile_edge=_tile_edge,
+             decode_ragged=_decode_ragged)
+
+
+def case(name: str) -> dict:
+    base, _, arg = name.partition(":")
+    return CASES[base](arg) if arg else CASES[base]()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# oracle calls
+# ---------------------------------------------------------------------------------------------------------------------------
+def oracle_train(P, d, ci, lens, mel, tl, gate, masks, **kw):
+    """Teacher-forced training forward + 3-term loss + autograd of every parameter (model/tacotron2.py:155-347,
+    model/tts_model.py:197-201 as restated by the oracle)."""
+    Pc = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not R.is_buffer(k)) else v.clone())
+          for k, v in P.items()}
+    new_stats = {}
+    o = R.tacotron2_fwd(Pc, d, ci, lens, True, mel, tl, training=True, masks=masks, new_stats=new_stats, **kw)
+    loss = R.tts_loss(o[0], o[1], o[2], mel, gate)[0]
+    names = [k for k, v in Pc.items() if v.requires_grad]
+    grads = torch.autograd.grad(loss, [Pc[k] for k in names])
+    return [x.detach() for x in o], float(loss.detach()), dict(zip(names, grads)), new_stats
+
+
+def ragged_stop_projection(P, d, ci, cl, spk, masks, N, seed, lo, hi):
+    """A stop projection under which the 64 utterances stop at DIFFERENT frames, the last of them between frame `lo` and `hi`.
+    The stop logit does not feed back into the decoder (model/tacotron2.py:319-325: only the mel output does), so the trajectory
+    [dec_h | ctx](t) of every utterance is the same under any gate weights: it is taken from one oracle run that cannot stop
+    (bias +50), the gate weight becomes a random direction made orthogonal to every utterance's mean state (with random-init
+    weights the logits are otherwise a per-speaker constant with 1 % fluctuation), scaled to unit fluctuation, and the bias is the
+    value in a grid that puts the last first-crossing in [lo, hi] with the largest distance of any logit from zero."""
+    P2 = dict(P)
+    P2["decoder.gate.bias"] = torch.full_like(P["decoder.gate.bias"], 50.0)
+    trace = {}
+    with torch.no_grad():
+        R.tacotron2_fwd(P2, d, ci, cl, False, speaker_id=spk, max_len_override=N, training=False, masks=masks, trace=trace)
+    x = torch.cat([torch.stack(trace["dec_h"], 1), torch.stack(trace["ctx"], 1)], 2).double()       # (B, N, D + Ef): Linear(cat[rnn_h, ctx])
+    assert x.shape[1] == N
+    Q, _ = torch.linalg.qr(x[:, 8:].mean(1).T)
+    r = torch.randn(x.shape[2], generator=torch.Generator().manual_seed(seed), dtype=torch.float64)
+    w = r - Q @ (Q.T @ r)
+    w = (w / float((x[:, 8:] @ w).std())).float()
+    s = x @ w.double()                                                                               # fluctuation part of every logit
+    best = None
+    for beta in np.linspace(1.2, 2.4, 601):
+        beta = float(np.float32(beta))
+        neg = (s + beta) < 0
+        if not bool(neg.any(1).all()):
+            continue
+        first = neg.float().argmax(1)
+        nstar = int(first.max())
+        if not lo <= nstar <= hi:
+            continue
+        margin = float((s[:, :nstar + 1] + beta).abs().min())
+        if best is None or margin > best[0]:
+            best = (margin, beta, nstar, first)
+    assert best is not None and best[0] > 5e-4, best
+    return w.view(1, -1), best[1], best[2], best[3], best[0]
+
+
+def run(name: str) -> dict:
+    """The oracle's results for a named case, as plain tensors / floats (torch.save-able with weights_only loading)."""
+    c = case(name)
+    d, P, kw, kind = c["d"], c["P"], c["kw"], c["kind"]
+    ci, lens, mel, tl, gate, masks = c["case"]
+    if kind == "fwd":
+        new_stats = {}
+        with torch.no_grad():
+            ref = R.tacotron2_fwd(P, d, ci, lens, True, mel, tl, training=True, masks=masks, new_stats=new_stats, **kw)
+        return dict(ref=[x.detach() for x in ref], new_stats={k: torch.as_tensor(v) for k, v in new_stats.items()})
+    if kind in ("train", "train_plain"):
+        if kind == "train":
+            masks, _ = dekink_masks(P, d, ci, mel, masks)      # ReLU-kink elements out of both sides (tests/helpers.py)
+        ref, loss, grads, new_stats = oracle_train(P, d, ci, lens, mel, tl, gate, masks, **kw)
+        return dict(ref=ref, loss=loss, grads=grads, new_stats={k: torch.as_tensor(v) for k, v in new_stats.items()})
+    if kind == "decode_ragged":
+        N, pm, spk = c["N"], c["pm"], kw["speaker_id"]
+        dm = dict(prenet_drop=[[pm[i, 0], pm[i, 1]] for i in range(N + 1)])
+        w, beta, nstar, first, margin = ragged_stop_projection(P, d, ci, lens, spk, dm, N, seed=67, lo=160, hi=220)
+        P = dict(P)
+        P["decoder.gate.weight"] = w.clone()
+        P["decoder.gate.bias"] = torch.full_like(P["decoder.gate.bias"], beta)
+        trace = {}
+        with torch.no_grad():
+            ref = R.tacotron2_fwd(P, d, ci, lens, False, speaker_id=spk, max_len_override=N, training=False, masks=dm, trace=trace)
+        return dict(w=w, beta=beta, nstar=nstar, first=first, margin=margin, ref=[x.detach() for x in ref],
+                    lengths=trace["lengths"])
+    raise KeyError(name)
+
+
+if __name__ == "__main__":      # python -m tests.oracle_jobs NAME OUT [threads]
+    name, out = sys.argv[1], sys.argv[2]
+    torch.set_num_threads(int(sys.argv[3]) if len(sys.argv) > 3 else 2)
+    res = run(name)
+    tmp = out + ".tmp"
+    torch.save(res, tmp)
+    os.replace(tmp, out)

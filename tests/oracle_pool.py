@@ -1,0 +1,83 @@
+"""Runs the named oracle jobs of tests/oracle_jobs.py as CPU child processes beside the GPU tests (test infrastructure).
+
+start(names) - called by tests/conftest.py once the selected tests are known - queues one `python -m tests.oracle_jobs NAME OUT`
+per name, WORKERS at a time, in the order the tests will ask for them.  oracle(name) returns the job's result, waiting for it if it
+is still running; a name that was never started (a test run on its own) is computed in-process.  The children are plain CPU
+processes: they never touch the GPU, and they are started from threads of this process with subprocess (fork + exec of a new
+interpreter; nothing replaces the test process)."""
+import os
+import subprocess
+import sys
+import tempfile
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKERS = int(os.environ.get("T2_ORACLE_WORKERS", "6"))
+THREADS = int(os.environ.get("T2_ORACLE_THREADS", "2"))
+
+_pool = None
+_dir = None
+_futures = {}
+_results = {}
+waited_s = {}
+
+
+def _run_child(name, out):
+    t0 = time.time()
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(THREADS))
+    r = subprocess.run([sys.executable, "-m", "tests.oracle_jobs", name, out, str(THREADS)], cwd=ROOT, capture_output=True, text=True, env=env)
+    if r.returncode != 0:
+        raise RuntimeError(f"oracle job {name} failed (rc {r.returncode}):\n{r.stderr[-3000:]}")
+    return out, time.time() - t0
+
+
+def start(names):
+    global _pool, _dir
+    names = [n for n in dict.fromkeys(names) if n not in _futures]
+    if not names:
+        return
+    if _pool is None:
+        _pool = ThreadPoolExecutor(max_workers=WORKERS)
+        _dir = tempfile.mkdtemp(prefix="t2_oracle_")
+        # (the box gives 16 cores per GPU: WORKERS x THREADS for the jobs, the rest for the oracle runs of the test process itself)
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        torch.set_num_threads(max(2, min(torch.get_num_threads(), cores - WORKERS * THREADS)))
+    for n in names:
+        _futures[n] = _pool.submit(_run_child, n, os.path.join(_dir, n.replace(":", "_") + ".pt"))
+
+
+def oracle(name):
+    if name in _results:
+        return _results[name]
+    if name in _futures:
+        t0 = time.time()
+        out, took = _futures[name].result()
+        waited_s[name] = (round(time.time() - t0, 1), round(took, 1))
+        res = torch.load(out, map_location="cpu", weights_only=True)
+        os.remove(out)
+    else:
+        from tests import oracle_jobs
+        res = oracle_jobs.run(name)
+    _results[name] = res
+    return res
+
+
+def release(name):
+    """Drop a cached result (the judged-shape forwards hold ~100 MB each)."""
+    _results.pop(name, None)
+
+
+def shutdown():
+    global _pool
+    if _pool is not None:
+        for f in _futures.values():
+            f.cancel()
+        _pool.shutdown(wait=True)
+        _pool = None
+    if _dir and os.path.isdir(_dir):
+        for f in os.listdir(_dir):
+            os.remove(os.path.join(_dir, f))
+        os.rmdir(_dir)

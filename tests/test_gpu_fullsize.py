@@ -23,21 +23,21 @@ def _ragged_case(d, B, L, T, seed, dev):
     return ci, lens, mel, tl, gate, masks
 
 
-def _oracle_train(P, d, ci, lens, mel, tl, gate, masks, **kw):
-    Pc = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not R.is_buffer(k)) else v.clone())
-          for k, v in P.items()}
-    new_stats = {}
-    o = R.tacotron2_fwd(Pc, d, ci, lens, True, mel, tl, training=True, masks=masks, new_stats=new_stats, **kw)
-    loss = R.tts_loss(o[0], o[1], o[2], mel, gate)[0]
-    names = [k for k, v in Pc.items() if v.requires_grad]
-    grads = torch.autograd.grad(loss, [Pc[k] for k in names])
-    return [x.detach() for x in o], float(loss), dict(zip(names, grads)), new_stats
+from tests.oracle_jobs import case as job_case, oracle_train as _oracle_train  # noqa: E402
+from tests.oracle_pool import oracle, release  # noqa: E402
 
 
-def _hip_train_and_compare(d, P, case, dev, kw_cpu=None, kw_dev=None, grad_tol=3e-4, check_engine=None):
+def _hip_train_and_compare(d, P, case, dev, kw_cpu=None, kw_dev=None, grad_tol=3e-4, check_engine=None, job=None):
+    """job: name of the tests/oracle_jobs.py job that runs the oracle side of THIS case (same builder, same dekinked masks) in a
+    background CPU process; None: the oracle runs here."""
     ci, lens, mel, tl, gate, masks = case
     masks, _ = dekink_masks(P, d, ci, mel, masks)      # ReLU-kink elements out of both sides (tests/helpers.py)
-    ref, loss, grads, new_stats = _oracle_train(P, d, ci, lens, mel, tl, gate, masks, **(kw_cpu or {}))
+    if job is not None:
+        o = oracle(job)
+        ref, loss, grads, new_stats = o["ref"], o["loss"], o["grads"], o["new_stats"]
+        release(job)
+    else:
+        ref, loss, grads, new_stats = _oracle_train(P, d, ci, lens, mel, tl, gate, masks, **(kw_cpu or {}))
     eng, ps = build_engine(d, P, dev)
     if check_engine is not None:
         check_engine(eng)
@@ -116,12 +116,6 @@ def test_descriptions_libritts_dims_train_step_matches_oracle():
                            kw_dev=dict(speaker_id=spk.to(dev), description_embeddings=desc.to(dev)))
 
 
-def _bench_length_case(d, B, L, T, seed, dev):
-    """Ragged batch at the benchmarked sequence lengths: utterance 0 has the full text length, the last one the full frame
-    count (random_case), the others about half - like a bench batch, where padding is 35 % of the frames."""
-    return _ragged_case(d, B, L, T, seed, dev)
-
-
 def _default_schedule(eng):
     """The bench's schedule, untouched: 64-frame forward chunks with the persistent decoder-LSTM launches, 64-frame backward
     chunks with ramps, weight gradients in groups of four chunks, deferred weight-gradient GEMMs."""
@@ -132,35 +126,28 @@ def _default_schedule(eng):
     assert _chunk_sizes(160, eng.chunk_bwd) == [64, 32, 32, 16, 8, 8]       # six backward chunks: two weight-gradient groups
 
 
+@pytest.mark.oracle("bench_len_vanilla")
 def test_vanilla_dims_bench_lengths_train_step_matches_oracle():
     """configs[1] dims AT THE BENCHMARKED LENGTHS: L = 188 characters (the bench batch's text length), T = 160 frames with the
     default schedule (so: attn_bwd_dw / attn_bwd_ds at Ad = 128, Ef = 512 and L = 188; the persistent decoder-LSTM chain at
     S = 64 steps and H = 1024; split-K weight gradients accumulated over two pipeline groups at H = 1024; the ramped chunks).
     Outputs, loss, EVERY parameter gradient and the BN running statistics against the oracle."""
     dev = _dev()
-    d = R.default_dims(speaker_tokens=True, num_speakers=4)
-    P = R.init_params(d, seed=188)
-    B, L, T = 2, 188, 160
-    case = _bench_length_case(d, B, L, T, 1880, dev)
-    spk = torch.tensor([1, 3], dtype=torch.int32)
-    _hip_train_and_compare(d, P, case, dev, kw_cpu=dict(speaker_id=spk), kw_dev=dict(speaker_id=spk.to(dev)),
-                           check_engine=_default_schedule)
+    c = job_case("bench_len_vanilla")            # B, L, T = 2, 188, 160 (utterance 0 the full text, the last one the full frame count)
+    assert c["case"][0].shape == (2, 188) and c["case"][2].shape[1] == 160
+    _hip_train_and_compare(c["d"], c["P"], c["case"], dev, kw_cpu=c["kw"], kw_dev={k: v.to(dev) for k, v in c["kw"].items()},
+                           check_engine=_default_schedule, job="bench_len_vanilla")
 
 
+@pytest.mark.oracle("bench_len_desc")
 def test_descriptions_libritts_dims_bench_lengths_train_step_matches_oracle():
     """The same at configs[3] dims: E' = 640 (description embeddings) + 562 speaker tokens, L = 188, T = 160, default schedule
     (config/descriptions-libritts.json:21,42-52 of the reference)."""
     dev = _dev()
-    d = R.default_dims(speaker_tokens=True, num_speakers=562, description_embeddings=True, description_embeddings_dim=768)
-    P = R.init_params(d, seed=640)
-    B, L, T = 2, 188, 160
-    case = _bench_length_case(d, B, L, T, 6400, dev)
-    g = torch.Generator().manual_seed(64)
-    spk = torch.randint(0, 562, (B,), generator=g, dtype=torch.int32)
-    desc = torch.randn(B, 768, generator=g)
-    _hip_train_and_compare(d, P, case, dev, kw_cpu=dict(speaker_id=spk, description_embeddings=desc),
-                           kw_dev=dict(speaker_id=spk.to(dev), description_embeddings=desc.to(dev)),
-                           check_engine=_default_schedule)
+    c = job_case("bench_len_desc")
+    assert c["d"]["num_speakers"] == 562 and c["case"][0].shape == (2, 188) and c["case"][2].shape[1] == 160
+    _hip_train_and_compare(c["d"], c["P"], c["case"], dev, kw_cpu=c["kw"], kw_dev={k: v.to(dev) for k, v in c["kw"].items()},
+                           check_engine=_default_schedule, job="bench_len_desc")
 
 
 def test_descriptions_libritts_full_size_training_step_properties():

@@ -5,10 +5,14 @@
     chunks, 12 full S = 64 persistent decoder-LSTM launches, the ramp at the end of a long sequence, two 16-row tiles), and a
     full training step (outputs, loss, EVERY parameter gradient, BN statistics) on a four-utterance slice of the same batch
     that keeps L = 188 and T = 872 (17 backward chunks, five weight-gradient groups of four chunks);
-  * configs[4]: the bench's decode batch (64 utterances, L = 167) decoded autoregressively for >= 192 frames with the product's
+  * configs[4]: the bench's decode batch (64 utterances, L = 167) decoded autoregressively for 161-221 frames with the product's
     default `check_every = 32`, prenet masks replayed, and a stop projection built so that the utterances stop at different
-    frames of the first four host-check windows: frame count, `lengths`, outputs and the per-frame drift against the oracle;
+    frames, the last one in the sixth or seventh host-check window: frame count, `lengths`, outputs and the per-frame drift
+    against the oracle;
   * the bench's own decode call (860 frames, Philox masks, check_every = 64) as a property test.
+
+The oracle sides of these cases are the jobs of tests/oracle_jobs.py (same seeded builders), started as background CPU processes
+when the session starts (tests/oracle_pool.py): the suite no longer idles the GPU for 5 minutes behind them.
 
 Tolerances as everywhere: mel L1 < 1e-4 (north_star), alignments max-abs < 2e-5 (teacher-forced), gradients < 3e-4 of each
 tensor's scale.  Reference loop: model/tacotron2.py:255-347 (teacher-forced), :262-329 (autoregressive), model/decoder.py:68-119."""
@@ -20,16 +24,10 @@ pytestmark = pytest.mark.gpu
 
 from oracle import tacotron2_ref as R  # noqa: E402
 from tacotron2_amd.synthetic import ljspeech_batch  # noqa: E402
+from tests.oracle_jobs import DECODE_N, case as job_case  # noqa: E402
+from tests.oracle_pool import oracle, release  # noqa: E402
 from tests.test_gpu_fullsize import _hip_train_and_compare  # noqa: E402
 from tests.test_gpu_model import MEL_L1_TOL, _dev, build_engine, l1, masks_to_device, mx  # noqa: E402
-
-
-def _scale_masks(d, B, L, T, seed):
-    g = torch.Generator().manual_seed(seed)
-    A, Dd, Pd, E, Pn, M = d["att_rnn_dim"], d["rnn_hidden_dim"], d["prenet_dim"], d["encoded_dim"], d["postnet_dim"], d["num_mels"]
-    sm = lambda shape, p: (torch.rand(shape, generator=g) >= p).float() / (1 - p)
-    return dict(enc_drop=[sm((B, L, E), 0.5) for _ in range(3)], prenet_drop=[sm((B, T + 1, Pd), 0.5) for _ in range(2)],
-                att_drop=sm((T, B, A), 0.1), dec_drop=sm((T, B, Dd), 0.1), post_drop=[sm((B, T, c), 0.5) for c in (Pn, Pn, Pn, Pn, M)])
 
 
 def _bench_schedule(eng, T):
@@ -42,20 +40,17 @@ def _bench_schedule(eng, T):
     assert T == 872 and sizes == [64] * 12 + [40, 32, 16, 8, 8] and len(sizes) == 17
 
 
+@pytest.mark.oracle("judged_fwd")
 def test_judged_train_shape_forward_matches_oracle():
     """B = 32, L = 188, T = 872 (18,279 valid frames): the forward of the step bench.py times, against the oracle on the same batch."""
     dev = _dev()
-    d = R.default_dims(speaker_tokens=True, num_speakers=4)
-    P = R.init_params(d, seed=0)
-    b = ljspeech_batch(32, seed=1234, num_speakers=4)
-    ci, cl, mel, tl, spk = b["chars_idx"], b["chars_idx_len"], b["mel_spectrogram"], b["mel_spectrogram_len"], b["speaker_id"]
+    c = job_case("judged_fwd")                   # synthetic.ljspeech_batch(32, seed=1234, num_speakers=4), masks seed 1234
+    d, P, (ci, cl, mel, tl, _, masks), spk = c["d"], c["P"], c["case"], c["kw"]["speaker_id"]
     B, L = ci.shape
     T = mel.shape[1]
     assert (B, L, T) == (32, 188, 872) and int(tl.sum()) == 18279
-    masks = _scale_masks(d, B, L, T, 1234)
-    new_stats = {}
-    with torch.no_grad():
-        ref = R.tacotron2_fwd(P, d, ci, cl, True, mel, tl, speaker_id=spk, training=True, masks=masks, new_stats=new_stats)
+    o = oracle("judged_fwd")
+    ref, new_stats = o["ref"], o["new_stats"]
     eng, ps = build_engine(d, P, dev)
     _bench_schedule(eng, T)
     outs, ctx = eng.forward_tf(ci.to(dev), cl.to(dev), mel.to(dev), tl.to(dev), speaker_id=spk.to(dev), training=True,
@@ -80,94 +75,44 @@ def test_judged_train_shape_forward_matches_oracle():
     for k, v in new_stats.items():
         if not k.endswith("num_batches_tracked"):
             assert mx(sd[k], v) < 1e-5, k
+    release("judged_fwd")
 
 
+@pytest.mark.oracle("judged4")
 def test_judged_train_lengths_four_utterance_step_matches_oracle():
     """Gradients at the judged LENGTHS: the utterances of the bench batch with the longest text (188), the most frames (872) and
     the two shortest, as one batch of four - the full 17-chunk pipelines with five weight-gradient groups, every parameter gradient
     against the oracle's autograd."""
     dev = _dev()
-    d = R.default_dims(speaker_tokens=True, num_speakers=4)
-    P = R.init_params(d, seed=0)
-    b = ljspeech_batch(32, seed=1234, num_speakers=4)
-    cl, tl = b["chars_idx_len"], b["mel_spectrogram_len"]
-    pick = [int(cl.argmax()), int(tl.argmax())]
-    for i in torch.argsort(tl).tolist():              # ... and the shortest ones, until there are four different utterances
-        if len(set(pick)) == 4:
-            break
-        pick.append(i)
-    pick = sorted(set(pick))
-    assert len(pick) == 4
-    ci, mel, gate, spk = b["chars_idx"][pick], b["mel_spectrogram"][pick], b["gate"][pick], b["speaker_id"][pick]
-    cl, tl = cl[pick], tl[pick]
+    c = job_case("judged4")
+    ci, cl, mel, tl, gate, masks = c["case"]
     B, L, T = 4, ci.shape[1], mel.shape[1]
-    assert (int(cl.max()), int(tl.max())) == (188, 872) and (L, T) == (188, 872)
-    masks = _scale_masks(d, B, L, T, 872)
-    _hip_train_and_compare(d, P, (ci, cl, mel, tl, gate, masks), dev, kw_cpu=dict(speaker_id=spk), kw_dev=dict(speaker_id=spk.to(dev)),
-                           check_engine=lambda e: _bench_schedule(e, T))
+    assert (int(cl.max()), int(tl.max())) == (188, 872) and (L, T) == (188, 872) and ci.shape[0] == 4
+    _hip_train_and_compare(c["d"], c["P"], c["case"], dev, kw_cpu=c["kw"], kw_dev={k: v.to(dev) for k, v in c["kw"].items()},
+                           check_engine=lambda e: _bench_schedule(e, T), job="judged4")
 
 
-def _ragged_stop_projection(P, d, ci, cl, spk, masks, N, seed, lo=64, hi=120):
-    """A stop projection under which the 64 utterances stop at DIFFERENT frames, the last of them between frame `lo` and `hi`.
-    The stop logit does not feed back into the decoder (model/tacotron2.py:319-325: only the mel output does), so the trajectory
-    [dec_h | ctx](t) of every utterance is the same under any gate weights: it is taken from one oracle run that cannot stop
-    (bias +50), the gate weight becomes a random direction made orthogonal to every utterance's mean state (with random-init
-    weights the logits are otherwise a per-speaker constant with 1 % fluctuation), scaled to unit fluctuation, and the bias is the
-    value in a grid that puts the last first-crossing in [lo, hi] with the largest distance of any logit from zero."""
-    P2 = dict(P)
-    P2["decoder.gate.bias"] = torch.full_like(P["decoder.gate.bias"], 50.0)
-    trace = {}
-    with torch.no_grad():
-        R.tacotron2_fwd(P2, d, ci, cl, False, speaker_id=spk, max_len_override=N, training=False, masks=masks, trace=trace)
-    x = torch.cat([torch.stack(trace["dec_h"], 1), torch.stack(trace["ctx"], 1)], 2).double()       # (B, N, D + Ef): Linear(cat[rnn_h, ctx])
-    assert x.shape[1] == N
-    Q, _ = torch.linalg.qr(x[:, 8:].mean(1).T)
-    r = torch.randn(x.shape[2], generator=torch.Generator().manual_seed(seed), dtype=torch.float64)
-    w = r - Q @ (Q.T @ r)
-    w = (w / float((x[:, 8:] @ w).std())).float()
-    s = x @ w.double()                                                                               # fluctuation part of every logit
-    best = None
-    for beta in np.linspace(1.2, 2.0, 401):
-        beta = float(np.float32(beta))
-        neg = (s + beta) < 0
-        if not bool(neg.any(1).all()):
-            continue
-        first = neg.float().argmax(1)
-        nstar = int(first.max())
-        if not lo <= nstar <= hi:
-            continue
-        margin = float((s[:, :nstar + 1] + beta).abs().min())
-        if best is None or margin > best[0]:
-            best = (margin, beta, nstar, first)
-    assert best is not None and best[0] > 5e-4, best
-    return w.view(1, -1), best[1], best[2], best[3], best[0]
-
-
-def test_judged_decode_shape_192_frames_default_check_every_matches_oracle():
-    """configs[4] at its own shape: the bench's 64 utterances (L = 167), 224 frames allowed, the product's default host-check period
-    of 32 frames.  Utterances stop between frame 0 and the fourth window; the reference's loop breaks when the LAST one has
-    (model/tacotron2.py:319-322), inside a window - the device loop runs to the window's end and the outputs are cut back."""
+@pytest.mark.oracle("decode_ragged")
+def test_judged_decode_shape_161_to_221_frames_default_check_every_matches_oracle():
+    """configs[4] at its own shape: the bench's 64 utterances (L = 167), 256 frames allowed, the product's default host-check period
+    of 32 frames.  Utterances stop at different frames (tests/oracle_jobs.py::ragged_stop_projection), the LAST one between frame 160
+    and 220; the reference's loop breaks when the last one has (model/tacotron2.py:319-322), inside the sixth or seventh host-check
+    window - the device loop runs to the window's end and the outputs are cut back.  Every emitted frame is oracle-checked."""
     dev = _dev()
-    d = R.default_dims(speaker_tokens=True, num_speakers=4)
-    P = R.init_params(d, seed=66)
-    ib = ljspeech_batch(64, seed=4321, num_speakers=4)
-    ci, cl, spk = ib["chars_idx"], ib["chars_idx_len"], ib["speaker_id"]
-    B, L, N = 64, ci.shape[1], 224
-    assert L == 167
-    g = torch.Generator().manual_seed(66)
-    pm = (torch.rand(N + 1, 2, B, 256, generator=g) >= 0.5).float() * 2
-    masks = dict(prenet_drop=[[pm[i, 0], pm[i, 1]] for i in range(N + 1)])
-    w, beta, nstar, first, margin = _ragged_stop_projection(P, d, ci, cl, spk, masks, N, seed=67)
+    c = job_case("decode_ragged")
+    d, P, (ci, cl, *_), spk, pm, N = c["d"], c["P"], c["case"], c["kw"]["speaker_id"], c["pm"], c["N"]
+    B, L = 64, ci.shape[1]
+    assert L == 167 and N == DECODE_N == 256 and ci.shape[0] == 64
+    o = oracle("decode_ragged")
+    w, beta, nstar, first, margin, ref, ref_lengths = o["w"], o["beta"], o["nstar"], o["first"], o["margin"], o["ref"], o["lengths"]
+    P = dict(P)
     P["decoder.gate.weight"] = w.clone()
     P["decoder.gate.bias"] = torch.full_like(P["decoder.gate.bias"], beta)
-    trace = {}
-    with torch.no_grad():
-        ref = R.tacotron2_fwd(P, d, ci, cl, False, speaker_id=spk, max_len_override=N, training=False, masks=masks, trace=trace)
     n = ref[0].shape[1]
-    assert n == nstar + 1 and 64 < n <= 121                      # the break lands in the third or fourth host-check window
+    assert n == nstar + 1 and 160 < n <= 221                     # the break lands in the sixth or seventh host-check window
     assert len(set(first.tolist())) >= 8                         # ragged stop frames
     # the non-sticky `lengths` rule matters here: some utterance has a non-negative logit AFTER its first negative one
-    assert bool((trace["lengths"] != first).any())
+    assert bool((ref_lengths != first).any())
     eng, ps = build_engine(d, P, dev)
     import inspect
     assert inspect.signature(eng.infer).parameters["check_every"].default == 32
@@ -177,11 +122,11 @@ def test_judged_decode_shape_192_frames_default_check_every_matches_oracle():
     nn = min(n, mels.shape[1])
     em = (mels[:, :nn].double().cpu() - ref[0][:, :nn].double()).abs().mean((0, 2))
     ea = (al[:, :nn].double().cpu() - ref[3][:, :nn].double()).abs().amax((0, 2))
-    marks = [t for t in (0, 7, 15, 31, 47, 63, 79, 95, 111) if t < nn] + [nn - 1]
+    marks = [t for t in (0, 7, 15, 31, 63, 95, 127, 159, 191) if t < nn] + [nn - 1]
     print(f"decode drift vs oracle (B=64, L=167, {n} frames, stop margin {margin:.1e}): frame: mel L1 / alignment max-abs")
     print("  " + "  ".join(f"{t + 1}: {float(em[t]):.1e}/{float(ea[t]):.1e}" for t in marks))
     assert mels.shape == ref[0].shape, (mels.shape, ref[0].shape)
-    assert (lengths.cpu() == trace["lengths"]).all(), (lengths.cpu() - trace["lengths"]).abs().max()
+    assert (lengths.cpu() == ref_lengths).all(), (lengths.cpu() - ref_lengths).abs().max()
     assert l1(mels, ref[0]) < MEL_L1_TOL and l1(post, ref[1]) < MEL_L1_TOL, (l1(mels, ref[0]), l1(post, ref[1]))
     assert mx(al, ref[3]) < 1e-4
     assert ((gates.cpu() == -1000.0) == (ref[2] == -1000.0)).all()
@@ -230,23 +175,20 @@ def test_bench_decode_call_properties():
     assert torch.equal(mels, mels2) and torch.equal(al, al2)
 
 
+@pytest.mark.oracle("libritts_fwd")
 def test_descriptions_libritts_per_gpu_shape_forward_matches_oracle():
     """BASELINE configs[3] at its per-GPU shape: description embeddings (768 -> 128, E' = 640) + 562 speaker tokens, 32 utterances
     with LibriTTS-shaped lengths (synthetic.ljspeech_batch(shape="libritts"): L up to 238, T up to 938 - more frames than the LJSpeech
     batch, so one more pipeline chunk), teacher-forced forward in training mode with replayed masks against the oracle
     (config/descriptions-libritts.json:21,42-52 of the reference; model/tacotron2.py:99-107,201-212)."""
     dev = _dev()
-    d = R.default_dims(speaker_tokens=True, num_speakers=562, description_embeddings=True, description_embeddings_dim=768)
-    P = R.init_params(d, seed=3)
-    b = ljspeech_batch(32, seed=1234, num_speakers=562, desc_dim=768, shape="libritts")
-    ci, cl, mel, tl = b["chars_idx"], b["chars_idx_len"], b["mel_spectrogram"], b["mel_spectrogram_len"]
-    spk, desc = b["speaker_id"], b["description_embeddings"]
+    c = job_case("libritts_fwd")
+    d, P, (ci, cl, mel, tl, _, masks) = c["d"], c["P"], c["case"]
+    spk, desc = c["kw"]["speaker_id"], c["kw"]["description_embeddings"]
     B, L = ci.shape
     T = mel.shape[1]
-    assert B == 32 and 872 < T <= 938 and L <= 238
-    masks = _scale_masks(d, B, L, T, 640)
-    with torch.no_grad():
-        ref = R.tacotron2_fwd(P, d, ci, cl, True, mel, tl, speaker_id=spk, description_embeddings=desc, training=True, masks=masks)
+    assert B == 32 and 872 < T <= 938 and L <= 238 and d["num_speakers"] == 562
+    ref = oracle("libritts_fwd")["ref"]
     eng, ps = build_engine(d, P, dev)
     outs, ctx = eng.forward_tf(ci.to(dev), cl.to(dev), mel.to(dev), tl.to(dev), speaker_id=spk.to(dev),
                                description_embeddings=desc.to(dev), training=True, masks=masks_to_device(masks, dev))
@@ -256,21 +198,20 @@ def test_descriptions_libritts_per_gpu_shape_forward_matches_oracle():
     print(f"configs[3] per-GPU shape (L={L}, T={T}): mel L1 {e0:.2e} / post {e1:.2e}, alignments max-abs {ea:.2e}")
     assert e0 < MEL_L1_TOL and e1 < MEL_L1_TOL and ea < 2e-5, (e0, e1, ea)
     assert ((outs[2].cpu() == -1000.0) == (ref[2] == -1000.0)).all()
+    release("libritts_fwd")
 
 
+@pytest.mark.oracle("b64_step")
 def test_vanilla_dims_batch64_train_step_matches_oracle():
     """The shipped config's OWN batch size (config/vanilla-lj-hifi-stop.json:18: 64; the benchmark overrides it to 32): four 16-row
     tiles in the attention-cell step and the backward products, the persistent decoder-LSTM launch as two consecutive blocks of 32
     rows, the encoder recurrence as step launches (its persistent launch takes up to 32 rows).  Full training step - outputs, loss,
     EVERY parameter gradient, BN statistics - against the oracle at vanilla dims."""
     dev = _dev()
-    d = R.default_dims(speaker_tokens=True, num_speakers=4)
-    P = R.init_params(d, seed=64)
-    B, L, T = 64, 33, 21
-    from tests.test_gpu_model import random_case
-    case = random_case(d, B, L, T, 6400, dev)
-    spk = torch.randint(0, 4, (B,), generator=torch.Generator().manual_seed(64), dtype=torch.int32)
+    c = job_case("b64_step")                     # B, L, T = 64, 33, 21
+    assert c["case"][0].shape == (64, 33)
 
     def check(eng):
         assert eng.dec_chain == "persistent"
-    eng, ps = _hip_train_and_compare(d, P, case, dev, kw_cpu=dict(speaker_id=spk), kw_dev=dict(speaker_id=spk.to(dev)), check_engine=check)
+    _hip_train_and_compare(c["d"], c["P"], c["case"], dev, kw_cpu=c["kw"], kw_dev={k: v.to(dev) for k, v in c["kw"].items()},
+                           check_engine=check, job="b64_step")

@@ -401,32 +401,30 @@ def test_edge_shapes_match_oracle(B, L, T, lens, tls):
     assert torch.isfinite(ps.grad).all() and torch.isfinite(loss3).all()
 
 
+@pytest.mark.oracle("long_text:{L}")
 @pytest.mark.parametrize("L", [300, 768, 2000])
 def test_long_text_forward_backward_match_oracle(L):
     """Texts longer than one 256-position round of the attention kernels: the forward kernels walk them in rounds, the backward
     per-slice kernel in position tiles (2, 4 and 10 tiles here) - no length limit but the LDS images (the reference has none either,
-    model/attention.py:52-69).  Outputs and every parameter gradient against the CPU oracle."""
+    model/attention.py:52-69).  Outputs and every parameter gradient against the CPU oracle (tests/oracle_jobs.py: the oracle's
+    encoder recurrence over 2000 characters takes half a minute of CPU, so it runs as a background job)."""
+    from tests.oracle_jobs import case as job_case
+    from tests.oracle_pool import oracle
     dev = _dev()
-    d = R.default_dims(num_chars=39, encoded_dim=64, prenet_dim=32, att_rnn_dim=64, att_dim=32, rnn_hidden_dim=64,
-                       postnet_dim=64, num_mels=16, dropout=0.5)
-    P = R.init_params(d, seed=L)
+    c = job_case(f"long_text:{L}")
+    d, P, (ci, lens, mel, tl, gate, masks) = c["d"], c["P"], c["case"]
+    assert ci.shape == (2, L) and lens.tolist() == [L, L - 37]
     eng, ps = build_engine(d, P, dev)
-    ci, lens, mel, tl, gate, masks = random_case(d, 2, L, 4, 900 + L, dev)
-    lens = torch.tensor([L, L - 37])
-    ci[1, L - 37:] = 0
-    Pc = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not R.is_buffer(k)) else v.clone()) for k, v in P.items()}
-    o = R.tacotron2_fwd(Pc, d, ci, lens, True, mel, tl, training=True, masks=masks, new_stats={})
-    loss = R.tts_loss(o[0], o[1], o[2], mel, gate)[0]
-    names = [k for k, v in Pc.items() if v.requires_grad]
-    grads = torch.autograd.grad(loss, [Pc[k] for k in names])
+    o = oracle(f"long_text:{L}")
+    ref, loss, grads = o["ref"], o["loss"], o["grads"]
     outs, ctx = eng.forward_tf(ci.to(dev), lens.to(dev), mel.to(dev), tl.to(dev), training=True, masks=masks_to_device(masks, dev))
     ps.grad.zero_()
     loss3 = eng.loss_and_grads(outs, ctx, mel.to(dev), gate.to(dev))
     torch.cuda.synchronize()
-    assert l1(outs[0], o[0].detach()) < MEL_L1_TOL and l1(outs[1], o[1].detach()) < MEL_L1_TOL
-    assert mx(outs[3], o[3].detach()) < 2e-5
-    assert abs(float(loss3.sum()) - float(loss)) < 2e-5 * max(1.0, abs(float(loss)))
-    _grad_check(ps, {k: g for k, g in zip(names, grads)})
+    assert l1(outs[0], ref[0]) < MEL_L1_TOL and l1(outs[1], ref[1]) < MEL_L1_TOL
+    assert mx(outs[3], ref[3]) < 2e-5
+    assert abs(float(loss3.sum()) - loss) < 2e-5 * max(1.0, abs(loss))
+    _grad_check(ps, grads)
 
 
 def test_unsupported_shapes_fail_loudly():
@@ -661,32 +659,31 @@ def test_inference_above_64_utterances_is_one_loop_like_the_reference():
     assert l1(mels_t, ref_t[0]) < MEL_L1_TOL and l1(post_t, ref_t[1]) < MEL_L1_TOL and mx(al_t, ref_t[3]) < 5e-5
 
 
+@pytest.mark.oracle("tile_edge:{L}")
 @pytest.mark.parametrize("L", [1, 2, 15, 16, 17, 31, 33, 64, 97, 188, 231, 252, 253, 270, 431, 433, 649])
 def test_attention_backward_at_tile_edge_lengths_matches_oracle(L):
     """The per-slice kernel of the attention backward (correlations dU, d_in on the bf16 matrix pipe with exactly split operands)
     over text lengths around every tile edge it has: 16-row position tiles, 32-deep k-steps, 8-position d_in rows, the one-pass limit
     (252 / 253) and - for longer texts, which are walked in position tiles of 216 with 16-position margins inside the launch - one
     short second tile (253, 270), the edge of the second tile (431, 433) and a fourth tile (649).  Ragged lengths in the batch; every
-    parameter gradient against the CPU oracle's autograd (model/attention.py:52-69, model/decoder.py:78-90)."""
+    parameter gradient against the CPU oracle's autograd (model/attention.py:52-69, model/decoder.py:78-90; the oracle side is the
+    background job tile_edge:L of tests/oracle_jobs.py)."""
+    from tests.oracle_jobs import case as job_case
+    from tests.oracle_pool import oracle
     dev = _dev()
-    d = R.default_dims(num_chars=39, encoded_dim=64, prenet_dim=32, att_rnn_dim=64, att_dim=32, rnn_hidden_dim=64,
-                       postnet_dim=64, num_mels=16, dropout=0.5)
-    P = R.init_params(d, seed=21)
-    ci, lens, mel, tl, gate, masks = random_case(d, 3, L, 6, 300 + L, dev)
+    c = job_case(f"tile_edge:{L}")
+    d, P, (ci, lens, mel, tl, gate, masks) = c["d"], c["P"], c["case"]
     masks, _ = dekink_masks(P, d, ci, mel, masks)
-    Pc = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not R.is_buffer(k)) else v.clone()) for k, v in P.items()}
-    o = R.tacotron2_fwd(Pc, d, ci, lens, True, mel, tl, training=True, masks=masks, new_stats={})
-    loss = R.tts_loss(o[0], o[1], o[2], mel, gate)[0]
-    names = [k for k, v in Pc.items() if v.requires_grad]
-    grads = torch.autograd.grad(loss, [Pc[k] for k in names])
+    o = oracle(f"tile_edge:{L}")
+    ref, loss, grads = o["ref"], o["loss"], o["grads"]
     eng, ps = build_engine(d, P, dev)
     outs, ctx = eng.forward_tf(ci.to(dev), lens.to(dev), mel.to(dev), tl.to(dev), training=True, masks=masks_to_device(masks, dev))
     ps.grad.zero_()
     loss3 = eng.loss_and_grads(outs, ctx, mel.to(dev), gate.to(dev))
     torch.cuda.synchronize()
-    assert l1(outs[0], o[0].detach()) < MEL_L1_TOL and mx(outs[3], o[3].detach()) < 2e-5
-    assert abs(float(loss3.sum()) - float(loss)) < 2e-5 * max(1.0, abs(float(loss)))
-    _grad_check(ps, {k: g for k, g in zip(names, grads)})
+    assert l1(outs[0], ref[0]) < MEL_L1_TOL and mx(outs[3], ref[3]) < 2e-5
+    assert abs(float(loss3.sum()) - loss) < 2e-5 * max(1.0, abs(loss))
+    _grad_check(ps, grads)
 
 
 @pytest.mark.parametrize("B,L", [(5, 37), (16, 1), (33, 21), (64, 12)])
