@@ -425,6 +425,21 @@ int t2_logmel_frames(int64_t n_samples, int hop);
 int t2_logmel_fwd(const float* wav, int64_t n, const float* basis, const float* fb, float* padded, float* spec, float* mag,
                   float* out, int n_fft, int hop, int n_mels, void* stream);
 
+/* The same front-end for ONE TRAINING BATCH in one pass - what the reference's 8 DataLoader workers + collate produce on the host
+ * (run/train.py:150-158, datasets/tts_dataset.py:184-214, datasets/tts_dataloader.py:8-35): wavs [B][ld_wav] = the B decoded (trimmed,
+ * silence-padded) utterances, zero-filled rows; n_dev [B] = their sample counts (DEVICE array, int64; n_max = the largest of
+ * them, known to the host); every utterance's reflect-padded signal becomes one row of `padded` [B][Tp*hop], so that the analysis
+ * windows of the WHOLE batch are the overlapping rows of ONE DFT GEMM (row b*Tp + f = frame f of utterance b, lda = hop; the
+ * n_fft/hop - 1 rows that straddle two utterances are computed and dropped).  Outputs in the batch layout of the model:
+ * mel (B, T_out, n_mels) zero behind each utterance's 1 + n_b/hop frames (T_out >= the longest: the caller may pad further, e.g. to a
+ * data-parallel step's global shape), gate (B, T_out, 1) ones with the last valid frame 0 (datasets/tts_dataset.py:213-214; may be
+ * NULL), mel_len [B] int32 (may be NULL).  Per frame the arithmetic is exactly t2_logmel_fwd's: results are bit-identical.
+ * t2_logmel_batch_workspace: element counts of padded / spec / mag / tmp and Tp (out5[0..4]). */
+int t2_logmel_batch_workspace(int B, int64_t n_max, int n_fft, int hop, int n_mels, int64_t* out5);
+int t2_logmel_batch_fwd(const float* wavs, int64_t ld_wav, const int64_t* n_dev, int B, int64_t n_max, const float* basis,
+                        const float* fb, float* padded, float* spec, float* mag, float* tmp, float* mel, int64_t T_out,
+                        float* gate, int32_t* mel_len, int n_fft, int hop, int n_mels, void* stream);
+
 /* dropout scale masks (Philox4x32-10, counter = element index) and the optimizer of model/tts_model.py:78-91 +
  * Lightning gradient_clip_val=1.0 (run/train.py:240) on one flat fp32 parameter buffer. */
 int t2_philox_mask(float* out, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream);

@@ -7,6 +7,8 @@ import math
 import numpy as np
 import torch
 
+import ctypes
+
 from .._lib import call
 
 
@@ -61,3 +63,25 @@ class TacotronMelSpectrogram:
         call("t2_logmel_fwd", wav, n, self.basis, self.fb, padded, spec, mag, out, self.n_fft, self.hop, self.n_mels,
              torch.cuda.current_stream().cuda_stream)
         return out
+
+    def batch(self, wavs: torch.Tensor, n: torch.Tensor, n_max: int, T_out: int = 0, want_gate: bool = True):
+        """One training batch in one pass (t2_logmel_batch_fwd): wavs (B, ld) fp32 DEVICE rows (zero-filled behind each utterance),
+        n (B,) int64 DEVICE sample counts, n_max = their maximum as a HOST integer (the caller decoded the files, it knows).  Returns
+        mel (B, T, n_mels) zero-padded, gate (B, T, 1) (ones, last valid frame 0, zero padding) and mel_len (B,) int32 - all on
+        the device, T = max(T_out, 1 + n_max // hop).  Enqueued on the current stream; nothing is read back."""
+        assert wavs.is_cuda and wavs.dtype == torch.float32 and wavs.dim() == 2 and wavs.stride(1) == 1
+        assert n.is_cuda and n.dtype == torch.int64 and n.numel() == wavs.shape[0]
+        B = wavs.shape[0]
+        T = max(int(T_out), 1 + int(n_max) // self.hop)
+        sizes = (ctypes.c_int64 * 5)()
+        call("t2_logmel_batch_workspace", B, int(n_max), self.n_fft, self.hop, self.n_mels, sizes)
+        ws = getattr(self, "_batch_ws", None)
+        if ws is None or any(w.numel() < need for w, need in zip(ws, sizes[:4])):
+            ws = [torch.empty(int(need * 1.25) + 1024, device=self.device) for need in sizes[:4]]
+            self._batch_ws = ws
+        mel = torch.empty(B, T, self.n_mels, device=self.device)
+        gate = torch.empty(B, T, 1, device=self.device) if want_gate else None
+        mel_len = torch.empty(B, dtype=torch.int32, device=self.device)
+        call("t2_logmel_batch_fwd", wavs, wavs.stride(0), n, B, int(n_max), self.basis, self.fb, ws[0], ws[1], ws[2], ws[3], mel, T,
+             gate, mel_len, self.n_fft, self.hop, self.n_mels, torch.cuda.current_stream().cuda_stream)
+        return mel, gate, mel_len

@@ -1,7 +1,15 @@
 """TTSDataset / collate with the reference's item and batch layout (datasets/tts_dataset.py:184-302,
 datasets/tts_dataloader.py:8-35): three dicts (data, metadata, extra); chars (B,L) int64 pad 0, mel (B,T,M) pad 0,
 gate (B,T,1) = ones with the last valid frame 0, lengths stacked to (B,).  The log-mel runs on the DEVICE
-(tacotron2_amd.datasets.logmel).  PCM WAV decoding uses the stdlib `wave` module (torchaudio/librosa are absent)."""
+(tacotron2_amd.datasets.logmel).  PCM WAV decoding uses the stdlib `wave` module (torchaudio/librosa are absent).
+
+Two ways to batches:
+  * the reference's: TTSDataset.__getitem__ + collate (validation, `main.py test`, `train-mel-export`) - one item at a time, the
+    item's mel computed on the device and LEFT there;
+  * training: DeviceBatchLoader - what the reference's 8 DataLoader workers + pin_memory are for (run/train.py:150-158), re-planned:
+    the B WAVs of a batch are decoded and trimmed by a small thread pool (`wave` / numpy release the GIL), packed into ONE pinned
+    buffer, copied up ONCE, and ONE batched log-mel pass (t2_logmel_batch_fwd) writes the padded (B, T, 80) tensor, the gate and
+    the lengths on the device.  Nothing comes back to the host."""
 from __future__ import annotations
 
 import os
@@ -35,14 +43,18 @@ def load_wav(path: str):
 
 
 def trim_silence(x: np.ndarray, top_db: float = 60, frame_length: int = 2048, hop_length: int = 512) -> np.ndarray:
-    """librosa.effects.trim semantics: keep from the first to the last frame whose RMS is within top_db of the peak."""
+    """librosa.effects.trim semantics: keep from the first to the last frame whose RMS is within top_db of the peak
+    (centred frames, zero padding).  Frame energies from one running sum of squares (float64): O(n), no (frames x 2048) gather."""
     if len(x) < frame_length:
         return x
     pad = frame_length // 2
-    xp = np.pad(x, (pad, pad), mode="constant")
-    nfr = 1 + (len(xp) - frame_length) // hop_length
-    idx = np.arange(frame_length)[None, :] + hop_length * np.arange(nfr)[:, None]
-    rms = np.sqrt(np.mean(xp[idx] ** 2, axis=1))
+    cs = np.zeros(len(x) + 2 * pad + 1, np.float64)
+    np.cumsum(np.square(x, dtype=np.float64), out=cs[pad + 1:pad + 1 + len(x)])
+    cs[pad + 1 + len(x):] = cs[pad + len(x)]
+    nfr = 1 + (len(x) + 2 * pad - frame_length) // hop_length
+    i0 = hop_length * np.arange(nfr)
+    ms = np.maximum(cs[i0 + frame_length] - cs[i0], 0.0) / frame_length
+    rms = np.sqrt(ms)
     db = 20 * np.log10(np.maximum(rms, 1e-10)) - 20 * np.log10(max(rms.max(), 1e-10))
     nz = np.nonzero(db > -top_db)[0]
     if len(nz) == 0:
@@ -74,6 +86,35 @@ class TTSDataset(torch.utils.data.Dataset):
     def __len__(self):
         return len(self.filenames)
 
+    def cache_writer(self):
+        if getattr(self, "_cache_writer", None) is None:
+            self._cache_writer = _CacheWriter()
+        return self._cache_writer
+
+    def flush_cache(self):
+        if getattr(self, "_cache_writer", None) is not None:
+            self._cache_writer.flush()
+
+    def cache_path(self, i: int):
+        return os.path.join(self.cache_dir, f"{self.filenames[i].replace('/', '_')}.pt") if self.cache else None
+
+    def load_audio(self, i: int) -> np.ndarray:
+        """Decoded, trimmed, silence-padded utterance i as contiguous float32 (datasets/tts_dataset.py:191-202): host work only."""
+        wav, _ = load_wav(os.path.join(self.base_dir, self.filenames[i]))
+        if self.trim:
+            wav = trim_silence(wav, self.trim_top_db, self.trim_frame_length)
+        if self.silence:
+            wav = np.pad(wav, (0, self.silence))
+        return np.ascontiguousarray(wav, dtype=np.float32)
+
+    @staticmethod
+    def write_cache(cache_path: str, mel_host: torch.Tensor):
+        # several readers share one cache directory (validation set, the prefetch thread, N data-parallel ranks): the
+        # entry appears under its final name only when complete (same pattern as checkpoint.save_atomic)
+        tmp = f"{cache_path}.tmp.{os.getpid()}.{threading.get_ident()}"
+        torch.save(mel_host.clone(), tmp)
+        os.replace(tmp, cache_path)
+
     def __getitem__(self, i: int):
         fn = self.filenames[i]
         mel = None
@@ -81,23 +122,17 @@ class TTSDataset(torch.utils.data.Dataset):
         if self.cache:
             cache_path = os.path.join(self.cache_dir, f"{fn.replace('/', '_')}.pt")
             if os.path.exists(cache_path):
-                try:
-                    mel = torch.load(cache_path, weights_only=True)
+                try:        # (items are device-resident either way: a batch may mix cache hits and misses)
+                    mel = torch.load(cache_path, weights_only=True).to(self.melspectrogram.device)
                 except Exception:       # unreadable entry (e.g. left by a killed run): a cache miss, recomputed below
                     mel = None
         if mel is None:
-            wav, _ = load_wav(os.path.join(self.base_dir, fn))
-            if self.trim:
-                wav = trim_silence(wav, self.trim_top_db, self.trim_frame_length)
-            wav = np.pad(wav, (0, self.silence))
-            mel = self.melspectrogram(torch.from_numpy(np.ascontiguousarray(wav)), id=str(i)).cpu()
+            wav = self.load_audio(i)
+            # (the item's mel is computed on the device and stays there: collate pads device tensors, nothing is copied back)
+            mel = self.melspectrogram(torch.from_numpy(wav), id=str(i))
             if cache_path is not None:
-                # several readers share one cache directory (validation set, the prefetch thread, N data-parallel ranks): the
-                # entry appears under its final name only when complete (same pattern as checkpoint.save_atomic)
-                tmp = f"{cache_path}.tmp.{os.getpid()}.{threading.get_ident()}"
-                torch.save(mel, tmp)
-                os.replace(tmp, cache_path)
-        gate = torch.ones(len(mel), 1)
+                self.write_cache(cache_path, mel.cpu())       # the optional on-disk cache is written from a side copy
+        gate = torch.ones(len(mel), 1, device=mel.device)
         gate[-1] = 0.0
         data = {"chars_idx": self.ids[i], "mel_spectrogram": mel, "gate": gate}
         meta = {"chars_idx_len": torch.tensor([len(self.ids[i])], dtype=torch.int64),
@@ -192,6 +227,165 @@ def TTSDataLoader(dataset, batch_size=1, num_workers=0, shuffle=None, drop_last=
         return torch.utils.data.DataLoader(dataset, batch_sampler=sampler, collate_fn=collate, num_workers=0)
     return torch.utils.data.DataLoader(dataset, batch_size=batch_size, collate_fn=collate if batch_size > 1 else None,
                                        num_workers=0, shuffle=shuffle, drop_last=drop_last)
+
+
+class HostWavBatch:
+    """One training batch between the host and the device: decoded audio of the cache misses packed in ONE pinned buffer, cached
+    mels of the hits, text ids and metadata - everything the host knows, including the batch's own padded lengths (L, T) as HOST
+    integers (frames = 1 + samples // hop: no device value is needed to know the shape).  `set_global_shape` records the
+    data-parallel step's global (L, T) (Trainer.negotiate_collated); `to_device` does the copies and the ONE batched log-mel pass."""
+
+    def __init__(self, ds, idxs, wav, n, hit_mels, frames):
+        self.ds, self.idxs, self.wav, self.n, self.hit_mels, self.frames = ds, idxs, wav, n, hit_mels, frames
+        self.L = max(len(ds.ids[i]) for i in idxs)
+        self.T = max(frames)
+        self.Lg, self.Tg = self.L, self.T
+
+    def set_global_shape(self, Lg: int, Tg: int):
+        assert Lg >= self.L and Tg >= self.T
+        self.Lg, self.Tg = int(Lg), int(Tg)
+
+    def to_device(self, dev):
+        ds, idxs, B, M = self.ds, self.idxs, len(self.idxs), ds_num_mels(self.ds)
+        pin = dev.type == "cuda"
+        up = lambda t: t.to(dev, non_blocking=True)
+        chars = torch.zeros(B, self.Lg, dtype=torch.int64, pin_memory=pin)
+        for b, i in enumerate(idxs):
+            chars[b, :len(ds.ids[i])] = ds.ids[i]
+        out = dict(chars_idx=up(chars), chars_idx_len=up(torch.tensor([len(ds.ids[i]) for i in idxs], dtype=torch.int64)))
+        miss = [b for b in range(B) if b not in self.hit_mels]
+        mel = gate = mel_len = None
+        if miss:
+            n_dev = up(torch.tensor([self.n[b] for b in miss], dtype=torch.int64))
+            mel_m, gate_m, len_m = ds.melspectrogram.batch(up(self.wav), n_dev, max(self.n[b] for b in miss), T_out=self.Tg)
+            if ds.cache:       # side copy for the on-disk cache: leaves through the writer thread once the copy has landed
+                ds.cache_writer().submit([ds.cache_path(idxs[b]) for b in miss], [self.frames[b] for b in miss], mel_m)
+            if len(miss) == B:
+                mel, gate, mel_len = mel_m, gate_m, len_m
+        if mel is None:            # cache hits in the batch: their mels go up from the host, padded, and the batch is assembled
+            hit = sorted(self.hit_mels)
+            hm = torch.zeros(len(hit), self.Tg, M, pin_memory=pin)
+            for r, b in enumerate(hit):
+                hm[r, :self.frames[b]] = self.hit_mels[b]
+            mel = torch.empty(B, self.Tg, M, device=dev)
+            mel[torch.tensor(hit, device=dev)] = up(hm)
+            if miss:
+                mel[torch.tensor(miss, device=dev)] = mel_m
+            mel_len = up(torch.tensor(self.frames, dtype=torch.int32))
+            t = torch.arange(self.Tg, device=dev)[None, :, None]
+            gate = (t < (mel_len.to(torch.int64)[:, None, None] - 1)).float()
+        out.update(mel_spectrogram=mel, gate=gate, mel_spectrogram_len=mel_len)
+        if ds.speaker_ids is not None:
+            out["speaker_id"] = up(torch.tensor([ds.speaker_ids[i] for i in idxs], dtype=torch.int32))
+        if ds.description_embeddings is not None:
+            rows = []
+            for i in idxs:
+                p = ds.description_embeddings[i]
+                rows.append(torch.load(os.path.join(ds.base_dir, p), map_location="cpu", weights_only=True).view(-1).float()
+                            if p is not None else torch.zeros(ds.description_embeddings_dim))
+            out["description_embeddings"] = up(torch.stack(rows))
+        if ds.features is not None:
+            out["controls"] = up(torch.tensor([ds.features[i] for i in idxs], dtype=torch.float32))
+        return out
+
+
+def ds_num_mels(ds) -> int:
+    return ds.melspectrogram.n_mels
+
+
+class _CacheWriter:
+    """Writes mel-cache entries from a side copy: the loader thread enqueues a device->pinned-host copy behind the batched log-mel
+    and goes on; this thread waits for the copy's event and saves one file per utterance (atomic rename)."""
+
+    def __init__(self):
+        import queue
+        self.q = queue.Queue()
+        self.th = threading.Thread(target=self._work, daemon=True)
+        self.th.start()
+
+    def submit(self, paths, frames, mel_dev):
+        host = torch.empty(mel_dev.shape, dtype=mel_dev.dtype, pin_memory=True)
+        host.copy_(mel_dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(mel_dev.device))
+        self.q.put((paths, frames, host, ev))
+
+    def _work(self):
+        while True:
+            item = self.q.get()
+            try:
+                if item is None:
+                    return
+                paths, frames, host, ev = item
+                ev.synchronize()
+                for r, (p, f) in enumerate(zip(paths, frames)):
+                    if not os.path.exists(p):
+                        TTSDataset.write_cache(p, host[r, :f])
+            finally:
+                self.q.task_done()
+
+    def flush(self):
+        self.q.join()
+
+
+class DeviceBatchLoader:
+    """Training batches, assembled for the device (see the module docstring).  Iterating yields HostWavBatch objects in the
+    sampler's order; DevicePrefetcher(loader, lambda b, dev: b.to_device(dev), ...) moves them up a step ahead of the training loop.
+    Sampling as TTSDataLoader: shuffled batches of `batch_size` (drop_last), or length buckets (`bucket_window`, sharded over ranks)."""
+
+    def __init__(self, dataset, batch_size: int, shuffle: bool = True, drop_last: bool = True, bucket_window: int = 0, seed: int = 0,
+                 rank: int = 0, world: int = 1, decode_threads: int = 4):
+        from concurrent.futures import ThreadPoolExecutor
+        self.ds, self.batch_size = dataset, batch_size
+        if bucket_window and batch_size > 1:
+            self.sampler = LengthBucketBatchSampler([len(i) for i in dataset.ids], batch_size, bucket_window, drop_last, seed, rank, world)
+        else:
+            g = torch.Generator().manual_seed(seed)
+            base = torch.utils.data.RandomSampler(dataset, generator=g) if shuffle else torch.utils.data.SequentialSampler(dataset)
+            self.sampler = torch.utils.data.BatchSampler(base, batch_size, drop_last)
+        self.pool = ThreadPoolExecutor(max_workers=max(1, decode_threads))
+        self.decode_s = 0.0           # host seconds spent decoding / packing (all batches so far), for the throughput record
+        self.batches = 0
+
+    def __len__(self):
+        return len(self.sampler)
+
+    def _load(self, i):
+        ds = self.ds
+        if ds.cache:
+            cp = ds.cache_path(i)
+            if os.path.exists(cp):
+                try:
+                    return torch.load(cp, weights_only=True)
+                except Exception:       # unreadable entry (e.g. left by a killed run): a cache miss
+                    pass
+        return ds.load_audio(i)
+
+    def host_batch(self, idxs) -> HostWavBatch:
+        import time
+        t0 = time.perf_counter()
+        ds, hop = self.ds, self.ds.melspectrogram.hop
+        items = list(self.pool.map(self._load, idxs))
+        hit_mels = {b: x for b, x in enumerate(items) if torch.is_tensor(x)}
+        miss = [b for b in range(len(idxs)) if b not in hit_mels]
+        n = [0 if b in hit_mels else len(items[b]) for b in range(len(idxs))]
+        frames = [len(hit_mels[b]) if b in hit_mels else 1 + n[b] // hop for b in range(len(idxs))]
+        wav = None
+        if miss:
+            short = [idxs[b] for b in miss if n[b] <= ds.melspectrogram.n_fft // 2]
+            assert not short, f"utterances shorter than half an analysis window (reflect padding needs more): {short}"
+            ld = (max(n) + 63) // 64 * 64
+            wav = torch.zeros(len(miss), ld, pin_memory=torch.cuda.is_available())
+            w = wav.numpy()
+            for r, b in enumerate(miss):
+                w[r, :n[b]] = items[b]
+        self.decode_s += time.perf_counter() - t0
+        self.batches += 1
+        return HostWavBatch(ds, list(idxs), wav, n, hit_mels, frames)
+
+    def __iter__(self):
+        for idxs in self.sampler:
+            yield self.host_batch(idxs)
 
 
 class DevicePrefetcher:

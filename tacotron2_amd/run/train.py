@@ -35,7 +35,7 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
              speech_dir: str, results_dir: Optional[str], resume_ckpt: Optional[str], finetune: bool = False,
              finetune_steps: Optional[int] = None, max_steps_override: Optional[int] = None, synthetic: bool = False):
     import pandas as pd
-    from ..datasets.tts_dataset import DevicePrefetcher, TTSDataLoader, TTSDataset
+    from ..datasets.tts_dataset import DeviceBatchLoader, DevicePrefetcher, TTSDataLoader, TTSDataset
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
     force_dp = bool(training_config.get("force_collectives", False)) or os.environ.get("T2_FORCE_DP") == "1"
     own_group = (world > 1 or force_dp) and not dist.is_initialized()
@@ -118,10 +118,20 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
                         cache_dir=os.path.join(results_dir, "mel_cache"), description_embeddings=desc, device=dev,
                         **dataset_config["preprocessing"])
         # training.bucket_window (not a reference key): batches of similar text length, see LengthBucketBatchSampler
-        loader = TTSDataLoader(ds, batch_size=training_config["batch_size"], shuffle=True, drop_last=True,
-                               bucket_window=bucket_window, seed=0 if bucket_window else rank, rank=rank, world=world)
-        # items and host->device copies of the next batches are prepared by a background thread on its own stream
-        prefetch = DevicePrefetcher(loader, _to_dev, dev, depth=int(training_config.get("prefetch_batches", 2)),
+        # training.loader (not a reference key): "batched" (default) = DeviceBatchLoader - the batch's WAVs decoded by a thread pool
+        # (training.decode_threads, 4), ONE host->device copy, ONE batched log-mel pass into the padded (B, T, 80) tensor, nothing
+        # read back; "items" = the reference's item-at-a-time path (TTSDataset.__getitem__ + collate), kept for A/B runs
+        batched = training_config.get("loader", "batched") == "batched"
+        if batched:
+            loader = DeviceBatchLoader(ds, batch_size=training_config["batch_size"], shuffle=True, drop_last=True,
+                                       bucket_window=bucket_window, seed=0 if bucket_window else rank, rank=rank, world=world,
+                                       decode_threads=int(training_config.get("decode_threads", 4)))
+        else:
+            loader = TTSDataLoader(ds, batch_size=training_config["batch_size"], shuffle=True, drop_last=True,
+                                   bucket_window=bucket_window, seed=0 if bucket_window else rank, rank=rank, world=world)
+        # the next batches are prepared by a background thread on its own stream
+        prefetch = DevicePrefetcher(loader, (lambda b, d_: b.to_device(d_)) if batched else _to_dev, dev,
+                                    depth=int(training_config.get("prefetch_batches", 2)),
                                     negotiate=tr.negotiate_collated if tr.loader_negotiation else None,
                                     limit=max(0, max_steps - start_step),
                                     cycle=True)
@@ -212,6 +222,11 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
             healthy(f"checkpoint after step {step + 1}")
             save(os.path.join(results_dir, "last.ckpt"), step + 1)
     torch.cuda.synchronize()
+    if not synthetic:
+        ds.flush_cache()                     # (mel-cache entries still on their way to the disk)
+        if rank == 0 and hasattr(loader, "decode_s") and loader.batches:
+            print(f"input pipeline: {loader.batches} batches decoded and packed in {loader.decode_s:.2f} s of loader-thread time "
+                  f"({loader.batches * training_config['batch_size'] / max(loader.decode_s, 1e-9):.0f} utterances/s)", flush=True)
     healthy("the end of training", [float(x) for x in loss3.cpu()] if steps_done else None)
     if rank == 0:
         path = os.path.join(results_dir, "finetuned.ckpt" if finetune else "final.ckpt")

@@ -167,9 +167,12 @@ class Trainer:
     def negotiate_collated(self, collated):
         """`negotiate` hook of DevicePrefetcher: a collated HOST batch (data, metadata, extra) of the loader, padded to the step's
         global shape in the loader thread - one step ahead of the training loop, which then calls train_step(padded=True)."""
-        data, meta, extra = collated
         if not self.dp:
             return collated
+        if hasattr(collated, "set_global_shape"):        # a HostWavBatch of DeviceBatchLoader: its (L, T) are host integers already
+            collated.set_global_shape(*self.negotiate_shape(collated.L, collated.T))
+            return collated
+        data, meta, extra = collated
         if self._shape_group is None:
             raise RuntimeError("Trainer.negotiate_collated needs the host-side (gloo) group: without it the shape is agreed on the "
                                "main thread (train_step(padded=False)); see Trainer.loader_negotiation")

@@ -211,7 +211,10 @@ def run(name: str) -> dict:
         if kind == "train":
             masks, _ = dekink_masks(P, d, ci, mel, masks)      # ReLU-kink elements out of both sides (tests/helpers.py)
         ref, loss, grads, new_stats = oracle_train(P, d, ci, lens, mel, tl, gate, masks, **kw)
-        return dict(ref=ref, loss=loss, grads=grads, new_stats={k: torch.as_tensor(v) for k, v in new_stats.items()})
+        # (the masks the oracle ran with travel back: the HIP side must replay exactly these - a kink test recomputed in another
+        #  process with another thread count could classify a borderline element differently)
+        return dict(ref=ref, loss=loss, grads=grads, new_stats={k: torch.as_tensor(v) for k, v in new_stats.items()},
+                    enc_drop=list(masks["enc_drop"]), prenet_drop=list(masks["prenet_drop"]))
     if kind == "decode_ragged":
         N, pm, spk = c["N"], c["pm"], kw["speaker_id"]
         dm = dict(prenet_drop=[[pm[i, 0], pm[i, 1]] for i in range(N + 1)])

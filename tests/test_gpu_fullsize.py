@@ -31,12 +31,13 @@ def _hip_train_and_compare(d, P, case, dev, kw_cpu=None, kw_dev=None, grad_tol=3
     """job: name of the tests/oracle_jobs.py job that runs the oracle side of THIS case (same builder, same dekinked masks) in a
     background CPU process; None: the oracle runs here."""
     ci, lens, mel, tl, gate, masks = case
-    masks, _ = dekink_masks(P, d, ci, mel, masks)      # ReLU-kink elements out of both sides (tests/helpers.py)
     if job is not None:
         o = oracle(job)
         ref, loss, grads, new_stats = o["ref"], o["loss"], o["grads"], o["new_stats"]
+        masks = dict(masks, enc_drop=o["enc_drop"], prenet_drop=o["prenet_drop"])     # the (dekinked) masks the oracle ran with
         release(job)
     else:
+        masks, _ = dekink_masks(P, d, ci, mel, masks)      # ReLU-kink elements out of both sides (tests/helpers.py)
         ref, loss, grads, new_stats = _oracle_train(P, d, ci, lens, mel, tl, gate, masks, **(kw_cpu or {}))
     eng, ps = build_engine(d, P, dev)
     if check_engine is not None:

@@ -150,10 +150,15 @@ def _grad_check(ps, ref_grads, tol=3e-4, floor=1e-3):
     for name, g in ps.reference_layout(ps.G).items():     # reference names/shapes (controls columns appended)
         r = torch.as_tensor(ref_grads[name]).double()
         got = g.double().cpu()
-        if name in ZERO_GRADIENT_BY_CONSTRUCTION and float(r.abs().max()) < 5e-6:
-            if not float(got.abs().max()) < 5e-6:
-                bad.append((name, float(got.abs().max()), 0.0))
-            continue
+        if name in ZERO_GRADIENT_BY_CONSTRUCTION:
+            # (the residue is rounding noise of the summed dx terms: its bound follows their size, read off the same layer's
+            #  weight gradient - a batch of three single-character texts has a tiny batch variance and large dx)
+            wscale = float(torch.as_tensor(ref_grads[name[:-4] + "weight"]).abs().max())
+            bound = 5e-6 * max(1.0, wscale)
+            if float(r.abs().max()) < bound:
+                if not float(got.abs().max()) < 2 * bound:
+                    bad.append((name, float(got.abs().max()), 0.0))
+                continue
         scale = max(float(r.abs().max()), floor)
         err = float((got - r).abs().max()) / scale
         if not err < tol:
@@ -673,9 +678,9 @@ def test_attention_backward_at_tile_edge_lengths_matches_oracle(L):
     dev = _dev()
     c = job_case(f"tile_edge:{L}")
     d, P, (ci, lens, mel, tl, gate, masks) = c["d"], c["P"], c["case"]
-    masks, _ = dekink_masks(P, d, ci, mel, masks)
     o = oracle(f"tile_edge:{L}")
     ref, loss, grads = o["ref"], o["loss"], o["grads"]
+    masks = dict(masks, enc_drop=o["enc_drop"], prenet_drop=o["prenet_drop"])      # the (dekinked) masks the oracle ran with
     eng, ps = build_engine(d, P, dev)
     outs, ctx = eng.forward_tf(ci.to(dev), lens.to(dev), mel.to(dev), tl.to(dev), training=True, masks=masks_to_device(masks, dev))
     ps.grad.zero_()
