@@ -144,12 +144,28 @@ int t2_lstm_seq_fwd_persist(const T2LstmStep* base, const T2LstmStride* inc, int
  * base[i].t + s * inc[i].dt give the packed-sequence masking).  n * H/4 <= 256 workgroups; cell i counts arrivals in words
  * [128 i, 128 i + 128) of `sync`, the timeout flag is word 256 for all. */
 int t2_lstm_seq_fwd_persist_n(const T2LstmStep* base, const T2LstmStride* inc, int n, int S, uint32_t* sync, void* stream);
+/* The same with the scratch split and the clearing left to the caller: `counters` = [ceil(B/32)][256] words that the caller has
+ * ZEROED on this stream since their last use (the engine clears a ring of them once per step with t2_zero_regions instead of one
+ * memset per launch), `flag` = the sticky timeout word. */
+int t2_lstm_seq_fwd_persist_pz(const T2LstmStep* base, const T2LstmStride* inc, int n, int S, uint32_t* counters, uint32_t* flag,
+                               void* stream);
 /* Residency check of the persistent launch above, without launching anything: T2_OK when H/4 workgroups with this K's weight
  * slice in LDS are all co-resident (compute units of the current device x hipOccupancyMaxActiveBlocksPerMultiprocessor),
  * T2_ERR_RESIDENCY otherwise - the caller then runs the same steps as t2_lstm_seq_fwd launches.  t2_lstm_seq_fwd_persist makes
  * the same check itself and returns the same code. */
 int t2_lstm_persist_resident(int H, int K, int B);
 int t2_lstm_persist_resident_n(int H, int K, int B, int n);      /* the same for n cells per launch (n * H/4 workgroups) */
+/* Clears up to 64 memory regions with ONE launch (the reference's `torch.zeros` / `zero_()` of its state tensors, e.g.
+ * model/tacotron2.py:126-153 init_hidden - one ATen fill each).  Region i: nrows[i] rows of row_bytes[i] bytes, stride_bytes[i] apart
+ * (nrows = 1: one contiguous run); pointers and sizes are multiples of 4 bytes. */
+typedef struct {
+    void* p[64];
+    int64_t row_bytes[64];
+    int64_t nrows[64];
+    int64_t stride_bytes[64];
+    int n;
+} T2ZeroRegions;
+int t2_zero_regions(const T2ZeroRegions* r, void* stream);
 /* Stream-concurrency probe (no reference counterpart: the reference is single-stream, run/train.py:235-243).  The engine needs
  * its two streams on different hardware queues (tacotron2_amd/__init__.py); Trainer.queue_check times `n` dependent one-thread
  * launches on one stream (t2_stream_probe_chain: word[0] += 1 per launch) alone and next to ONE idle wave that holds the other
@@ -336,6 +352,7 @@ typedef struct {
     float* dx; int Lp_dx, pad_dx;
     float* dgamma; float* dbeta;
     int phase; const float* shift; float grad_share;
+    int sums_prezeroed;          /* 1: the caller has cleared `sums` on this stream (e.g. as one region of t2_zero_regions) */
 } T2Bn;
 int t2_bn_fwd(const T2Bn* s, void* stream);
 int t2_bn_bwd(const T2Bn* s, void* stream);
@@ -353,6 +370,11 @@ int t2_outgrad_pack(const float* d_mels, const float* d_post, const float* d_gat
 int t2_loss_fwd_bwd(const float* mels, const float* post, const float* gates, const float* mel_tgt, const float* gate_tgt,
                     const int32_t* len, int B, int T, int M, double* loss3 /* gate, mel, post */, float* d_post, float* dproj,
                     float grad_scale, void* stream);
+/* The same three loss terms for the nn.Module surface (TTSModel.training_step / validation_step, model/tts_model.py:165-253): loss3
+ * and - each optional - the dense gradients w.r.t. mels (B,T,M), mels_post (B,T,M) and gates (B,T,1), zero at masked positions. */
+int t2_loss_terms(const float* mels, const float* post, const float* gates, const float* mel_tgt, const float* gate_tgt,
+                  const int32_t* len, int B, int T, int M, double* loss3, float* d_mels, float* d_post, float* d_gates,
+                  float grad_scale, void* stream);
 int t2_relu_mask_bwd(const float* g, const float* y, const float* mask, float* out, int64_t n, void* stream);
 int t2_condition_fwd(const float* enc, const float* spk_table, const int32_t* spk, const float* desc, float* memory, int B,
                      int L, int E, int Ef, void* stream);

@@ -127,8 +127,13 @@ def _addr(x):
     return x
 
 
+PRE_CALL = []      # hooks run in front of every library call (tacotron2_amd.engine: the deferred multi-region zero)
+
+
 def call(name: str, *args):
     L = lib()
+    for hook in PRE_CALL:
+        hook()
     fn = getattr(L, name)
     conv = []
     for a, at in zip(args, fn.argtypes):

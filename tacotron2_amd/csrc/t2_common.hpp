@@ -70,6 +70,14 @@ void t2_set_error(const char* msg, const char* file, int line);
 #define T2_RING_END() do { } while (0)
 #endif
 
+// A/B knobs of kernel selection: compile-time constants in the product library.  Only the DIAGNOSTIC build
+// (python -m tacotron2_amd.build --variant ab T2_AB_KNOBS, loaded through T2_LIB_PATH) reads them from the environment.
+#ifdef T2_AB_KNOBS
+#define T2_KNOB(env, dflt) (getenv(env) ? atoi(getenv(env)) : (dflt))
+#else
+#define T2_KNOB(env, dflt) (dflt)
+#endif
+
 static inline int t2_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool t2_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 

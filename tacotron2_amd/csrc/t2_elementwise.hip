@@ -324,7 +324,8 @@ __global__ void finalize_fwd_kernel(const float* proj, long ldp, const int32_t* 
 //   d_post (B,T,M) dense;  dproj [T][B][M+1] time-major gets d_mels + d_post in cols < M and d_gate in col M.
 __global__ __launch_bounds__(256) void loss_kernel(const float* mels, const float* post, const float* gates, const float* mel_tgt,
                                                    const float* gate_tgt, const int32_t* len, int B, int T, int M,
-                                                   double* loss3, float* d_post, float* dproj, float gscale) {
+                                                   double* loss3, float* d_post, float* dproj, float gscale,
+                                                   float* d_mels = nullptr, float* d_gates = nullptr) {
     __shared__ double red[3][4];
     const long nm = (long)B * T * M, ng = (long)B * T;
     const float sm = 1.f / (float)nm, sg = 1.f / (float)ng;
@@ -341,6 +342,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* mels, const floa
             const float g1 = masked ? 0.f : 2.f * e1 * sm * gscale;
             const float g2 = masked ? 0.f : 2.f * e2 * sm * gscale;
             if (d_post) d_post[i] = g2;
+            if (d_mels) d_mels[i] = g1;
             if (dproj) dproj[((long)t * B + b) * (M + 1) + m] = g1 + g2;
         } else {
             const long r = i - nm;
@@ -350,6 +352,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* mels, const floa
             a_g += (double)(fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x))));
             const float g = masked ? 0.f : (t2_sigmoid(x) - y) * sg * gscale;
             if (dproj) dproj[((long)t * B + b) * (M + 1) + M] = g;
+            if (d_gates) d_gates[r] = g;
         }
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -524,6 +527,32 @@ __global__ void guard_poison_kernel(const uint32_t* flag, float* x, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] = __builtin_nanf("");
 }
 
+// t2_zero_regions: up to 64 regions (contiguous, or rows of row_bytes at a stride) cleared by ONE launch; blockIdx.y = region.
+struct ZeroK { T2ZeroRegions r; };
+__global__ __launch_bounds__(256) void zero_regions_kernel(ZeroK k) {
+    const int y = blockIdx.y;
+    char* base = (char*)k.r.p[y];
+    const long rb = k.r.row_bytes[y], nr = k.r.nrows[y], sb = k.r.stride_bytes[y];
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
+    if (nr == 1 || sb == rb) {                 // one contiguous run
+        const long n = rb * nr;
+        if ((((uintptr_t)base) & 15) == 0 && (n & 15) == 0) {
+            f32x4* q = (f32x4*)base;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            for (long i = tid; i < (n >> 4); i += nth) q[i] = z;
+        } else {
+            uint32_t* q = (uint32_t*)base;
+            for (long i = tid; i < (n >> 2); i += nth) q[i] = 0u;
+        }
+    } else {
+        const long rw = rb >> 2;
+        for (long i = tid; i < rw * nr; i += nth) {
+            const long row = i / rw, c = i - row * rw;
+            ((uint32_t*)(base + row * sb))[c] = 0u;
+        }
+    }
+}
+
 // Stream-concurrency probe (t2_stream_probe_*): a chain of dependent one-thread launches, and one wave that idles for a
 // bounded wall-clock time (s_memrealtime: 100 MHz, independent of the shader clock; s_sleep between polls).
 __global__ void probe_tick_kernel(uint32_t* word) { word[0] += 1u; }
@@ -538,6 +567,24 @@ __global__ void probe_spin_kernel(uint32_t* word, unsigned long long ticks) {
 
 #define ST ((hipStream_t)stream)
 
+extern "C" int t2_zero_regions(const T2ZeroRegions* r, void* stream) {
+    (void)hipGetLastError();
+    T2_REQUIRE(r && r->n >= 0 && r->n <= 64, "t2_zero_regions: 0..64 regions");
+    if (r->n == 0) return T2_OK;
+    long most = 0;
+    for (int i = 0; i < r->n; ++i) {
+        T2_REQUIRE(r->p[i] && r->row_bytes[i] > 0 && r->nrows[i] > 0 && (r->row_bytes[i] & 3) == 0 && ((uintptr_t)r->p[i] & 3) == 0 &&
+                   (r->nrows[i] == 1 || ((r->stride_bytes[i] & 3) == 0 && r->stride_bytes[i] >= r->row_bytes[i])),
+                   "t2_zero_regions: regions are 4-byte aligned runs of whole words (rows: stride >= row, a multiple of 4)");
+        const long n = r->row_bytes[i] * r->nrows[i];
+        if (n > most) most = n;
+    }
+    long gx = (most + 16 * 256 * 8 - 1) / (16 * 256 * 8);          // ~8 x 16-byte stores per thread of the largest region
+    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    ZeroK k; k.r = *r;
+    hipLaunchKernelGGL(zero_regions_kernel, dim3((unsigned)gx, r->n), dim3(256), 0, ST, k);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
 extern "C" int t2_stream_probe_chain(uint32_t* word, int n, void* stream) {
     (void)hipGetLastError();
     T2_REQUIRE(word && n >= 0 && n <= 100000, "t2_stream_probe_chain: bad arguments");
@@ -592,7 +639,7 @@ extern "C" int t2_bn_fwd(const T2Bn* s, void* stream) {
                "t2_bn_fwd: phases 1/2 (sync-BN) need training statistics and a rank-independent shift");
     BnK k; to_bnk(s, k);
     if (s->training && s->phase != 2) {
-        (void)hipMemsetAsync(s->sums, 0, sizeof(double) * (2 * s->C + 2), ST);
+        if (!s->sums_prezeroed) (void)hipMemsetAsync(s->sums, 0, sizeof(double) * (2 * s->C + 2), ST);
         const long R = (long)s->B * s->L;
         const int rpb = 128;
         hipLaunchKernelGGL(bn_stats_kernel, dim3(t2_cdiv(s->C, 64), t2_cdiv(R, rpb)), dim3(256), 0, ST, k, rpb);
@@ -611,7 +658,7 @@ extern "C" int t2_bn_bwd(const T2Bn* s, void* stream) {
     T2_REQUIRE(s->phase >= 0 && s->phase <= 2, "t2_bn_bwd: bad phase");
     BnK k; to_bnk(s, k);
     if (s->phase != 2) {
-        (void)hipMemsetAsync(s->sums, 0, sizeof(double) * (2 * s->C + 2), ST);
+        if (!s->sums_prezeroed) (void)hipMemsetAsync(s->sums, 0, sizeof(double) * (2 * s->C + 2), ST);
         const long R = (long)s->B * s->L;
         const int rpb = 128;
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(t2_cdiv(s->C, 64), t2_cdiv(R, rpb)), dim3(256), 0, ST, k, rpb);
@@ -662,6 +709,16 @@ extern "C" int t2_loss_fwd_bwd(const float* mels, const float* post, const float
     (void)hipMemsetAsync(loss3, 0, 3 * sizeof(double), ST);
     hipLaunchKernelGGL(loss_kernel, dim3(ew_grid((long)B * T * (M + 1))), dim3(256), 0, ST, mels, post, gates, mel_tgt, gate_tgt,
                        len, B, T, M, loss3, d_post, dproj, grad_scale);
+    T2_CHECK_LAUNCH(); return T2_OK;
+}
+extern "C" int t2_loss_terms(const float* mels, const float* post, const float* gates, const float* mel_tgt, const float* gate_tgt,
+                             const int32_t* len, int B, int T, int M, double* loss3, float* d_mels, float* d_post, float* d_gates,
+                             float grad_scale, void* stream) {
+    (void)hipGetLastError();
+    T2_REQUIRE(mels && post && gates && mel_tgt && gate_tgt && len && loss3, "t2_loss_terms: null");
+    (void)hipMemsetAsync(loss3, 0, 3 * sizeof(double), ST);
+    hipLaunchKernelGGL(loss_kernel, dim3(ew_grid((long)B * T * (M + 1))), dim3(256), 0, ST, mels, post, gates, mel_tgt, gate_tgt,
+                       len, B, T, M, loss3, d_post, (float*)nullptr, grad_scale, d_mels, d_gates);
     T2_CHECK_LAUNCH(); return T2_OK;
 }
 extern "C" int t2_outgrad_pack(const float* d_mels, const float* d_post, const float* d_gates, const int32_t* len,

@@ -13,7 +13,7 @@ extern "C" int t2_version(void) { return 100; }
 extern "C" int t2_sizeof(const char* name) {
 #define T2_SZ(T) if (strcmp(name, #T) == 0) return (int)sizeof(T)
     T2_SZ(T2Gemm); T2_SZ(T2Seg); T2_SZ(T2LstmStep); T2_SZ(T2LstmStride); T2_SZ(T2LstmBwdStep); T2_SZ(T2LstmBwdStride);
-    T2_SZ(T2AttnStep); T2_SZ(T2AttnSeq); T2_SZ(T2AttnSeqBwd); T2_SZ(T2Bn); T2_SZ(T2Infer); T2_SZ(T2StopScan);
+    T2_SZ(T2AttnStep); T2_SZ(T2AttnSeq); T2_SZ(T2AttnSeqBwd); T2_SZ(T2Bn); T2_SZ(T2Infer); T2_SZ(T2StopScan); T2_SZ(T2ZeroRegions);
 #undef T2_SZ
     return -1;
 }

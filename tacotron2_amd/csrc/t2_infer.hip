@@ -165,7 +165,7 @@ int launch_linear(const LinK& k, hipStream_t st) {
     // blocks) and 16 activation rows
     const int ny = t2_cdiv(k.B, 16);
     dim3 grid(t2_cdiv(k.N, 16) + (k.stop_proj ? 1 : 0), ny);
-    static const int nw8_min_k = getenv("T2_LINEAR_NW8_MIN_K") ? atoi(getenv("T2_LINEAR_NW8_MIN_K")) : 1024;
+    static const int nw8_min_k = T2_KNOB("T2_LINEAR_NW8_MIN_K", 1024);
     if (k.K >= nw8_min_k) hipLaunchKernelGGL((linear_rows_kernel<1, 8>), grid, dim3(512), 0, st, k);
     else hipLaunchKernelGGL((linear_rows_kernel<1, 4>), grid, dim3(256), 0, st, k);
     T2_CHECK_LAUNCH();

@@ -316,7 +316,7 @@ int launch_fwd(const T2LstmStep* steps, int n, hipStream_t st) {
             // Measured in one session on the training step, 4 chunks per group beat 8 (82.05 against 82.37 ms), and every
             // deeper variant (two groups requested ahead, all loads of the step issued at entry) was slower still: past
             // ~24 KB per wave the first operands only arrive later.
-            static const int sq_tile = getenv("T2_CELL_SQ") ? atoi(getenv("T2_CELL_SQ")) : 1;
+            static const int sq_tile = T2_KNOB("T2_CELL_SQ", 1);
             bool tiled_in = true;
             for (int i = 0; i < n; ++i) tiled_in = tiled_in && steps[i].xt != nullptr;
             if (bn <= 16) hipLaunchKernelGGL((lstm_step_fwd_fast_kernel<1, 4>), grid, block, 0, st, kk);
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_bwd_fast8_kernel(BwdK2 pp) {
     __shared__ float red[8 * 256];
     t2_lstm_bwd_fast_body<8, 2>(pp.s[blockIdx.z], blockIdx.x, blockIdx.y, red);
 }
-static int g_bwd8_max_wgs = getenv("T2_BWD8_MAX_WGS") ? atoi(getenv("T2_BWD8_MAX_WGS")) : 64;
+static int g_bwd8_max_wgs = T2_KNOB("T2_BWD8_MAX_WGS", 64);
 
 int launch_bwd(const T2LstmBwdStep* steps, int n, hipStream_t st, unsigned long long* clk = nullptr) {
     T2_REQUIRE(n == 1 || n == 2, "lstm bwd step: n must be 1 or 2");
@@ -810,9 +810,12 @@ extern "C" int t2_lstm_persist_resident_n(int H, int K, int B, int n) {
 }
 extern "C" int t2_lstm_persist_resident(int H, int K, int B) { return t2_lstm_persist_resident_n(H, K, B, 1); }
 
-extern "C" int t2_lstm_seq_fwd_persist_n(const T2LstmStep* base, const T2LstmStride* inc, int n, int S, uint32_t* sync, void* stream) {
+// counters: 256 words per launch (row block); flag: the sticky timeout word.  prezeroed: the caller cleared the counters of every
+// row block ([ceil(B/32)][256] words) on this stream; otherwise each launch clears its 256 words itself.
+static int persist_launch(const T2LstmStep* base, const T2LstmStride* inc, int n, int S, uint32_t* sync, uint32_t* flag, bool prezeroed,
+                          void* stream) {
     (void)hipGetLastError();   // drop stale sticky errors of other HIP users in this thread: only OUR launches are checked
-    T2_REQUIRE(base && inc && sync && S >= 0 && (n == 1 || n == 2), "t2_lstm_seq_fwd_persist: bad arguments");
+    T2_REQUIRE(base && inc && sync && flag && S >= 0 && (n == 1 || n == 2), "t2_lstm_seq_fwd_persist: bad arguments");
     if (S == 0) return T2_OK;
     for (int i = 0; i < n; ++i) {
         T2_TRY(t2_lstm_check_step(base[i]));
@@ -841,10 +844,11 @@ extern "C" int t2_lstm_seq_fwd_persist_n(const T2LstmStep* base, const T2LstmStr
             k.i_pre = inc[i].pre; k.i_drop = inc[i].drop; k.i_h_out = inc[i].h_out; k.i_h_out2 = inc[i].h_out2;
             k.i_c_out = inc[i].c_out; k.i_gates = inc[i].gates_out;
             k.i_xt = inc[i].xt; k.i_ht = inc[i].ht_out; k.i_dt = inc[i].dt; k.steps = S;
-            k.sync = sync + i * 128; k.tmo = sync + 256; k.spin_limit = g_persist_spin_limit;
+            k.sync = sync + i * 128; k.tmo = flag; k.spin_limit = g_persist_spin_limit;
         }
         if (n == 1) kk.c[1] = kk.c[0];
-        (void)hipMemsetAsync(sync, 0, 16 * 16 * sizeof(uint32_t), st);
+        if (prezeroed) sync += 256;          // (the next row block's own counters)
+        else (void)hipMemsetAsync(sync, 0, 16 * 16 * sizeof(uint32_t), st);
         dim3 grid(b.H / 4, n), block(256);
         if (bn <= 16) hipLaunchKernelGGL((lstm_seq_persist_fwd_kernel<1>), grid, block, lds, st, kk);
         else hipLaunchKernelGGL((lstm_seq_persist_fwd_kernel<2>), grid, block, lds, st, kk);
@@ -853,8 +857,15 @@ extern "C" int t2_lstm_seq_fwd_persist_n(const T2LstmStep* base, const T2LstmStr
     return T2_OK;
 }
 
+extern "C" int t2_lstm_seq_fwd_persist_n(const T2LstmStep* base, const T2LstmStride* inc, int n, int S, uint32_t* sync, void* stream) {
+    return persist_launch(base, inc, n, S, sync, sync ? sync + 256 : nullptr, false, stream);
+}
 extern "C" int t2_lstm_seq_fwd_persist(const T2LstmStep* base, const T2LstmStride* inc, int S, uint32_t* sync, void* stream) {
     return t2_lstm_seq_fwd_persist_n(base, inc, 1, S, sync, stream);
+}
+extern "C" int t2_lstm_seq_fwd_persist_pz(const T2LstmStep* base, const T2LstmStride* inc, int n, int S, uint32_t* counters,
+                                          uint32_t* flag, void* stream) {
+    return persist_launch(base, inc, n, S, counters, flag, true, stream);
 }
 
 extern "C" int t2_lstm_pack_fwd(const T2Seg* segs, int nseg, int H, float* out, void* stream) {

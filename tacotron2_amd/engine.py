@@ -55,13 +55,20 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_k=1, b_k=1, alpha=1.0, bias=None, bi
     call("t2_gemm", g, _stream())
 
 
+_PREZEROED: Dict[int, bool] = {}      # data_ptr of buffers a phase's prologue has already put on the zero list (one-shot marks)
+
+
+def fill_splits(M: int, N: int, K: int) -> bool:
+    return ((M + 127) // 128) * ((N + 127) // 128) < 256 and K >= 1024
+
+
 def gemm_fill(A, B, C, M, N, K, lda, ldb, ldc, a_k=1, b_k=1, bias=None):
     """Plain C = A.B (+ bias) for shapes that leave the chip under-filled (fewer than 256 output tiles of 128 x 128, long K): two
     K slices accumulate into the zeroed C with atomics - encoder convolution 178 -> 123 us, BiLSTM dgrad 123 -> 94 us
     (tools/bench_gemm_small.py).  C must be a tensor whose first M rows of ldc floats are exactly the output."""
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles < 256 and K >= 1024 and torch.is_tensor(C):
-        C.view(-1)[:M * ldc].zero_()
+    if fill_splits(M, N, K) and torch.is_tensor(C):
+        if not _PREZEROED.pop(C.data_ptr(), False):      # (cleared ahead, with the phase's other regions: Engine.prezero)
+            zero_later(C.view(-1)[:M * ldc])
         gemm(A, B, C, M, N, K, lda, ldb, ldc, a_k=a_k, b_k=b_k, bias=bias, accumulate=2, splitk=2)
     else:
         gemm(A, B, C, M, N, K, lda, ldb, ldc, a_k=a_k, b_k=b_k, bias=bias)
@@ -69,6 +76,60 @@ def gemm_fill(A, B, C, M, N, K, lda, ldb, ldc, a_k=1, b_k=1, bias=None):
 
 def _ptr(t: torch.Tensor, elem_off: int = 0) -> int:
     return t.data_ptr() + 4 * elem_off
+
+
+# ---- deferred zeroing: ONE launch for the state tensors a phase clears ----------------------------------------------------------
+# The reference clears its recurrent state with one ATen fill per tensor (model/tacotron2.py:126-153); the engine has ~55 such
+# regions per training step (slot 0 of every time-major stash, split-K accumulators, gradient accumulators, BatchNorm sums, the
+# arrival counters of the persistent launches, the flat gradient buffer).  zero_later() only RECORDS a region, keyed by the torch
+# stream that was current; the list of every stream is cleared by one t2_zero_regions launch on that stream in front of the next
+# library call of the process (a hook in _lib.call), i.e. before anything enqueued later can read or accumulate into it.  Code that
+# reads such a buffer with a torch operation and no library call in between must call flush_zeros() itself.
+# Per THREAD: a loader thread that calls into the library (log-mel) must not flush - or delay - the training thread's list.
+import threading as _threading
+_TLS = _threading.local()
+
+
+def _pending() -> Dict[int, list]:
+    d = getattr(_TLS, "pending", None)
+    if d is None:
+        d = _TLS.pending = {}
+    return d
+
+
+def zero_later(t: torch.Tensor) -> torch.Tensor:
+    """Record `t` (contiguous, or 2-D with unit inner stride) for the next t2_zero_regions launch on the current stream."""
+    if t.numel() == 0:
+        return t
+    es = t.element_size()
+    if t.is_contiguous():
+        reg = (t.data_ptr(), t.numel() * es, 1, t.numel() * es)
+    else:
+        assert t.dim() == 2 and t.stride(1) == 1, "zero_later: contiguous tensors or rows with unit inner stride"
+        reg = (t.data_ptr(), t.shape[1] * es, t.shape[0], t.stride(0) * es)
+    assert reg[0] % 4 == 0 and reg[1] % 4 == 0 and reg[3] % 4 == 0, "zero_later: regions are runs of whole 4-byte words"
+    st = torch.cuda.current_stream(t.device)
+    _pending().setdefault(st.cuda_stream, []).append((reg, t))       # (the tensor is kept alive until the launch is enqueued)
+    return t
+
+
+def flush_zeros() -> None:
+    mine = _pending()
+    if not mine:
+        return
+    pending = list(mine.items())
+    mine.clear()                               # (first: the t2_zero_regions calls below come back through the hook)
+    for stream, regs in pending:
+        for i0 in range(0, len(regs), 64):
+            part = regs[i0:i0 + 64]
+            z = _lib.S["T2ZeroRegions"]()
+            for i, ((ptr, rb, nr, sb), _) in enumerate(part):
+                z.p[i] = ptr; z.row_bytes[i] = rb; z.nrows[i] = nr; z.stride_bytes[i] = sb
+            z.n = len(part)
+            call("t2_zero_regions", z, stream)
+
+
+_lib.PRE_CALL.append(flush_zeros)
 
 
 def splitk_for(M: int, N: int, K: int) -> int:
@@ -106,6 +167,8 @@ class Engine:
         self.d = ps.dims
         self.dev = ps.device
         self._ws: Dict[str, torch.Tensor] = {}
+        self._prez: Dict[str, bool] = {}
+        self._persist_next = 0
         self._side = None
         self.chunk = 64               # frames per pipeline chunk of the forward frame loop
         self.chunk_bwd = 64           # frames per chunk of the backward pipeline (r03: 64 beats 80 by 0.2 ms with the BPTT launches at default wave priority)
@@ -147,7 +210,7 @@ class Engine:
     def persist_sync(self):
         """Scratch of the persistent launches: arrival counters (words 0..255), sticky timeout flag (word 256)."""
         if self._persist_sync is None:
-            self._persist_sync = torch.zeros(320, dtype=torch.int32, device=self.dev)
+            self._persist_sync = torch.zeros(self.PERSIST_RING0 + 256 * self.PERSIST_RING, dtype=torch.int32, device=self.dev)
         return self._persist_sync
 
     def check_persistent_kernels(self):
@@ -275,9 +338,51 @@ class Engine:
             t = torch.empty(max(n, 1), dtype=dtype, device=self.dev)
             self._ws[name] = t
         v = t[:n].view(*shape)
-        if zero:
-            v.zero_()
+        if zero and not self._prez.pop(name, False):
+            zero_later(v)       # cleared by the next t2_zero_regions launch, in front of the next library call
         return v
+
+    def prezero(self, name: str, *shape, dtype=torch.float32) -> torch.Tensor:
+        """Allocate the named workspace and put it on the zero list NOW (a phase's prologue: one launch clears everything the phase
+        accumulates into); the later `buf(name, ..., zero=True)` of the code that uses it is then a plain lookup."""
+        v = self.buf(name, *shape, dtype=dtype)
+        zero_later(v)
+        self._prez[name] = True
+        return v
+
+    BN_SLOTS = {"enc.conv0": 0, "enc.conv1": 1, "enc.conv2": 2, "post.conv0": 3, "post.conv1": 4, "post.conv2": 5, "post.conv3": 6,
+                "post.conv4": 7}
+
+    def bn_sums(self, tag: str, backward: bool) -> torch.Tensor:
+        """The statistics workspace (2C + 2 doubles) of one BatchNorm layer: a slot of ONE arena, cleared per phase by
+        begin_phase (T2Bn.sums_prezeroed) instead of one memset per layer."""
+        C = max(self.d["encoded_dim"], self.d["postnet_dim"], self.d["num_mels"])
+        arena = self.buf("bn.sums", 16, 2 * C + 2, dtype=torch.float64)
+        return arena[self.BN_SLOTS[tag] + (8 if backward else 0)]
+
+    def begin_phase(self, backward: bool):
+        """Start of a forward (teacher-forced or inference) / of a backward: the BatchNorm sums of the phase's 8 layers and - forward
+        - the arrival-counter ring of the persistent launches go on the zero list."""
+        C = max(self.d["encoded_dim"], self.d["postnet_dim"], self.d["num_mels"])
+        arena = self.buf("bn.sums", 16, 2 * C + 2, dtype=torch.float64)
+        zero_later(arena[8:] if backward else arena[:8])
+        if not backward:
+            zero_later(self.persist_sync()[self.PERSIST_RING0:])
+            self._persist_next = 0
+
+    PERSIST_RING0 = 320              # words 0..255 legacy counters, 256 sticky flag; from 320: ring of 256-word counter blocks
+    PERSIST_RING = 96
+
+    def persist_flag(self) -> int:
+        return self.persist_sync().data_ptr() + 4 * 256
+
+    def persist_counters(self, nblocks: int) -> int:
+        """Device address of `nblocks` fresh 256-word arrival-counter blocks (cleared by begin_phase; one per row block of a
+        persistent launch: t2_lstm_seq_fwd_persist_pz)."""
+        assert self._persist_next + nblocks <= self.PERSIST_RING, "persistent launches per forward exceed the counter ring"
+        a = self.persist_sync().data_ptr() + 4 * (self.PERSIST_RING0 + 256 * self._persist_next)
+        self._persist_next += nblocks
+        return a
 
     # ---- lane-contiguous weight streams for the LSTM step kernels (re-laid once per step) ------------
     def pack_fwd(self, name, segs, H):
@@ -312,7 +417,7 @@ class Engine:
         gemm_fill(x_pad, wp, raw, B * Lp - 4, Co, 5 * Ci, Ci, 5 * Ci, Co, bias=bias)
         mean = self.buf(f"{tag}.mean", Co)
         invstd = self.buf(f"{tag}.invstd", Co)
-        sums = self.buf(f"{tag}.sums", 2 * Co + 2, dtype=torch.float64)
+        sums = self.bn_sums(tag, backward=False)
         if y is None:
             y = self.buf(f"{tag}.y", B, Lp, Co)
             Lp_y = Lp
@@ -320,7 +425,8 @@ class Engine:
         bn = make("T2Bn", B=B, L=L, C=Co, x=raw, Lp_x=Lp, gamma=P[bn_prefix + ".weight"], beta=P[bn_prefix + ".bias"],
                   running_mean=Bf[bn_prefix + ".running_mean"], running_var=Bf[bn_prefix + ".running_var"],
                   training=1 if training else 0, momentum=0.1, eps=1e-5, sums=sums, mean=mean, invstd=invstd, act=act,
-                  drop=drop, res=res, Lp_res=Lp_res, pad_res=pad_res, len=length, fill=fill, y=y, Lp_y=Lp_y, pad_y=pad_y)
+                  drop=drop, res=res, Lp_res=Lp_res, pad_res=pad_res, len=length, fill=fill, y=y, Lp_y=Lp_y, pad_y=pad_y,
+                  sums_prezeroed=1)
         if sync:
             # synchronised batch statistics: every rank sums (x - shift), (x - shift)^2 and its row count, ONE all-reduce of
             # 2C + 2 doubles per layer, then every rank normalises with the statistics of the global batch (what the
@@ -361,7 +467,8 @@ class Engine:
         hs = self.buf("enc.h", 2, S + 1, B, H)
         cs = self.buf("enc.c", 2, S + 1, B, H)
         gs = self.buf("enc.gates", 2, S, B, 4 * H)
-        hs[0, 0].zero_(); cs[0, 0].zero_(); hs[1, S].zero_(); cs[1, S].zero_()
+        for z in (hs[0, 0], cs[0, 0], hs[1, S], cs[1, S]):
+            zero_later(z)
         enc = self.buf("enc.out", B, L, E)
         steps = (_lib.S["T2LstmStep"] * 2)()
         incs = (_lib.S["T2LstmStride"] * 2)()
@@ -373,7 +480,7 @@ class Engine:
         if persist:
             Bp = (B + 15) // 16 * 16
             ht = self.buf("enc.ht", 2, S + 1, H // 16, Bp, 16, zero=(B != Bp))
-            ht[0, 0].zero_(); ht[1, S].zero_()
+            zero_later(ht[0, 0]); zero_later(ht[1, S])
         for dr in range(2):
             t0 = 0 if dr == 0 else S - 1
             sg = 1 if dr == 0 else -1
@@ -401,7 +508,7 @@ class Engine:
                 ic.xt = sg * H * Bp; ic.ht_out = sg * H * Bp
         self.mark("fwd.enc.convs")
         if persist:
-            call("t2_lstm_seq_fwd_persist_n", steps, incs, 2, S, self.persist_sync(), _stream())
+            call("t2_lstm_seq_fwd_persist_pz", steps, incs, 2, S, self.persist_counters((B + 31) // 32), self.persist_flag(), _stream())
             # (a wait that timed out - sticky device flag - turns the encoder output into NaN: every later result of this forward,
             #  training or inference, carries it; the host raises at its next check_persistent_kernels)
             call("t2_guard_poison", self._persist_sync.data_ptr() + 4 * 256, enc, B * L * E, _stream())
@@ -450,6 +557,7 @@ class Engine:
         mlen32 = mel_len.to(torch.int32)
         ctx["len32"], ctx["mlen32"], ctx["chars_idx"] = len32, mlen32, chars_idx
 
+        self.begin_phase(backward=False)
         self.mark("start")
         # The prenet and the hoisted prenet part of the attention-RNN input projection depend only on the mel input: they run
         # on the side stream next to the encoder, whose BiLSTM recurrence is a chain of small latency-bound launches.
@@ -496,20 +604,20 @@ class Engine:
         call("t2_attn_fold_location", P["decoder.attention.location_dense.weight"],
              P["decoder.attention.location_conv.weight"], U, Ad, F, KL, st)
         xdec = self.buf("xdec", T + 1, B, A + Ef)
-        xdec[0].zero_()
+        zero_later(xdec[0])
         att_c = self.buf("att_c", T + 1, B, A)
-        att_c[0].zero_()
+        zero_later(att_c[0])
         cum = self.buf("cum", T + 1, B, L)
-        cum[0].zero_()
+        zero_later(cum[0])
         xproj = self.buf("xproj", T + 1, B, D + Ef)
-        xproj[0].zero_()
+        zero_later(xproj[0])
         # x16-tiled copies of the recurrent inputs ([K/16][Bp][16] per slot): the step kernels' activation loads become
         # contiguous 1 KB blocks (include/tacotron2_amd.h, T2LstmStep.xt)
         Bp = (B + 15) // 16 * 16
         xdec_t = self.buf("xdec_t", T + 1, (A + Ef) // 16, Bp, 16, zero=(B != Bp))
-        xdec_t[0].zero_()
+        zero_later(xdec_t[0])
         dech_t = self.buf("dech_t", T + 1, D // 16, Bp, 16, zero=(B != Bp))
-        dech_t[0].zero_()
+        zero_later(dech_t[0])
         gates_att = self.buf("gates_att", T, B, 4 * A) if save_for_backward else None
         # tanh terms of the energies, kept for the backward: [T][B][Ad][L4] floats, 2.7 GB per step at b=32, T=870, L=188 - sized for
         # 288 GB of HBM (a backward that recomputes them instead was built and measured in round 3: +1.0 ms per step,
@@ -529,7 +637,7 @@ class Engine:
         # decoder-LSTM chain operands (prepared before the pipeline below)
         pre_dec = self.buf("pre_dec", T, B, 4 * D)
         dec_c = self.buf("dec_c", T + 1, B, D)
-        dec_c[0].zero_()
+        zero_later(dec_c[0])
         gates_dec = self.buf("gates_dec", T, B, 4 * D) if save_for_backward else None
         dd = masks.get("dec_drop")
         ldp = D + Ef
@@ -564,13 +672,21 @@ class Engine:
             # sit on the exposed tail of the forward: K slices accumulate into the pre-filled block with atomics
             tiles = (((c1 - c0) * B + 127) // 128) * ((4 * D + 127) // 128)
             sk = max(1, min(4, 256 // max(tiles, 1))) if self.splitk_small_chunks else 1
-            if sk > 1 and cterm is None:
-                pre_dec[c0:c1].zero_()
+            if sk > 1 and cterm is None and not _PREZEROED.pop(_ptr(pre_dec, c0 * B * 4 * D), False):
+                zero_later(pre_dec[c0:c1])
             gemm(_ptr(xdec, (c0 + 1) * B * (A + Ef)), P["decoder.lstm.weight_ih"], _ptr(pre_dec, c0 * B * 4 * D), (c1 - c0) * B,
                  4 * D, A + Ef, A + Ef, A + Ef, 4 * D, bias=P["decoder.lstm.bias_ih"], bias2=P["decoder.lstm.bias_hh"],
                  accumulate=2 if sk > 1 else (1 if cterm is not None else 0), splitk=sk)
 
         main, side = torch.cuda.current_stream(), self.side_stream()
+        if cterm is None and self.splitk_small_chunks:
+            # the short chunks of the ramp run their hoisted GEMM split-K into a cleared block: cleared here, with everything else
+            c0_ = 0
+            for n_ in _chunk_sizes(T, self.chunk, ramp_at_end=self.ramp_chunks):
+                if max(1, min(4, 256 // max(((n_ * B + 127) // 128) * ((4 * D + 127) // 128), 1))) > 1:
+                    zero_later(pre_dec[c0_:c0_ + n_]); _PREZEROED[_ptr(pre_dec, c0_ * B * 4 * D)] = True
+                c0_ += n_
+            flush_zeros()              # (on the main stream, in front of the side stream's wait below)
         side.wait_stream(main)
         # Pipeline chunks; the LAST ones shrink (CH/2, CH/4, CH/8, CH/8): what follows the attention chain's end on the side stream
         # (the decoder-LSTM frames of the final chunk) is exposed time, proportional to that chunk's length.
@@ -597,7 +713,8 @@ class Engine:
                 if persist:
                     # The decoder-LSTM chain of a chunk as ONE persistent, weight-stationary launch (t2_lstm_seq_fwd_persist):
                     # W_hh stays in LDS, the workgroups exchange h through the tiled stash
-                    call("t2_lstm_seq_fwd_persist", stp, inc, c1 - c0, sync, side.cuda_stream)
+                    call("t2_lstm_seq_fwd_persist_pz", stp, inc, 1, c1 - c0, self.persist_counters((B + 31) // 32), self.persist_flag(),
+                         side.cuda_stream)
                 else:
                     call("t2_lstm_seq_fwd", stp, inc, 1, c1 - c0, side.cuda_stream)
         self.mark("fwd.dec.attn_chain")
@@ -659,9 +776,9 @@ class Engine:
         Lp = L + 4
         st = _stream()
         draw = self.buf(f"{tag}.draw", B, Lp, Co)
-        sums = self.buf(f"{tag}.sums", 2 * Co + 2, dtype=torch.float64)
+        sums = self.bn_sums(tag, backward=True)
         bn = make("T2Bn", B=B, L=L, C=Co, x=c["raw"], Lp_x=Lp, gamma=P[bn_prefix + ".weight"], beta=P[bn_prefix + ".bias"],
-                  training=1 if training else 0, momentum=0.1, eps=1e-5, sums=sums, mean=c["mean"], invstd=c["invstd"],
+                  training=1 if training else 0, momentum=0.1, eps=1e-5, sums=sums, sums_prezeroed=1, mean=c["mean"], invstd=c["invstd"],
                   act=act, drop=c["drop"], dy=dy, Lp_dy=Lp_dy, pad_dy=pad_dy, dx=draw, Lp_dx=Lp, pad_dx=2,
                   dgamma=G[bn_prefix + ".weight"], dbeta=G[bn_prefix + ".bias"])
         if training and self.sync_bn_group is not None:
@@ -714,6 +831,7 @@ class Engine:
         masks = ctx["masks"]
         R, R1 = T * B, (T + 1) * B
         ldp, ldx = D + Ef, A + Ef
+        self.begin_phase(backward=True)
 
         # ---- postnet --------------------------------------------------------------------------------
         chans = [M, Pn, Pn, Pn, Pn, M]
@@ -757,20 +875,20 @@ class Engine:
         # The attention chain of a frame only needs the decoder chain's gradient of the SAME frame, so chunk k+1 of the
         # decoder chain overlaps chunk k of the attention chain; the decoder weight-gradient GEMMs overlap the tail.
         dgd = self.buf("dgd", T + 1, B, 4 * D)
-        dgd[T].zero_()
+        zero_later(dgd[T])
         # x16-tiled copies of the gate gradients (A operands of the per-frame backward products; T2LstmBwdStep.dgt_next)
         Bp = (B + 15) // 16 * 16
         dgd_t = self.buf("dgd_t", T + 1, 4 * D // 16, Bp, 16)
-        dgd_t[T].zero_()
+        zero_later(dgd_t[T])
         Zt = self.buf("Zatt_t", T + 1, 4 * A // 16, Bp, 16)
-        Zt[T].zero_()
+        zero_later(Zt[T])
         dc_dec = self.buf("dc_dec", B, D, zero=True)
         dd = masks.get("dec_drop")
         wtp_dec = self.pack_bwd("dec.t", P["decoder.lstm.weight_hh"], D, 4 * D, D)
         dxdec = self.buf("dxdec", T, B, ldx)
         ldz = 4 * A + Ad
         Z = self.buf("Zatt", T + 1, B, ldz)       # Z[s][b] = [dgates_s | dq_{s-1}]
-        Z[T, :, :4 * A].zero_()
+        zero_later(Z[T, :, :4 * A])
         dga = Z                                   # dgates_t = Z[t][:, :4A]   (row stride ldz)
         dctx_tot = self.buf("dctx_tot", T, B, Ef)
         dpmT = self.buf("dpmT", B, Ad, L, zero=True)
@@ -939,7 +1057,7 @@ class Engine:
                  sA=Ad * L, sB=L * Ef, sC=0)
             # ---- prenet ----
             dp2 = self.buf("dp2", T + 1, B, Pd)
-            dp2[T].zero_()
+            zero_later(dp2[T])
             gemm(dga, P["decoder.att_rnn.weight_ih"], dp2, R, Pd, 4 * A, ldz, Pd + Ef, Pd, a_k=1, b_k=0)
             pd = ctx["pd"]
             g2 = self.buf("g2", T + 1, B, Pd)
@@ -975,7 +1093,7 @@ class Engine:
         S, Lp = L, L + 4
         hs, cs, gs = e["hs"], e["cs"], e["gs"]
         dgt = self.buf("enc.dgt", 2, S + 1, B, 4 * H)   # dir 0: dgates_t at slot t (zero slot S); dir 1: at slot t+1 (zero slot 0)
-        dgt[0, S].zero_(); dgt[1, 0].zero_()
+        zero_later(dgt[0, S]); zero_later(dgt[1, 0])
         dpre = self.buf("enc.dpre", B * Lp, 8 * H, zero=True)
         dc_enc = self.buf("enc.dc", 2, B, H, zero=True)
         steps = (_lib.S["T2LstmBwdStep"] * 2)()
@@ -1140,6 +1258,7 @@ class Engine:
         B, L = chars_idx.shape
         assert B <= 4096, "engine.infer handles up to 4096 utterances per call (64 groups of 64)"
         self.generation += 1          # the encoder / postnet workspaces are shared with forward_tf
+        self.begin_phase(backward=False)
         M, E, Pd, A, D = d["num_mels"], d["encoded_dim"], d["prenet_dim"], d["att_rnn_dim"], d["rnn_hidden_dim"]
         Ef = E + (128 if d.get("description_embeddings") else 0)
         F = d.get("loc_filters", 32)

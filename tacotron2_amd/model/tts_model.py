@@ -8,9 +8,33 @@ from typing import List, Optional
 
 import torch
 from torch import Tensor, nn
-from torch.nn import functional as F
 
+from .._lib import call
 from .tacotron2 import Tacotron2
+
+
+class _LossTermsFn(torch.autograd.Function):
+    """(gate BCE-with-logits, mel MSE, post MSE) of model/tts_model.py:197-199 - plain means over the padded tensors - as ONE
+    device kernel (t2_loss_terms); with autograd on, the same launch also writes the three dense gradients, which backward scales
+    by the upstream gradient of each term."""
+
+    @staticmethod
+    def forward(ctx, mel, post, gate, mel_tgt, gate_tgt, mel_len):
+        B, T, M = mel.shape
+        need = any(ctx.needs_input_grad[:3])
+        mel, post, gate = mel.contiguous().float(), post.contiguous().float(), gate.contiguous().float()
+        loss3 = torch.empty(3, dtype=torch.float64, device=mel.device)
+        grads = [torch.empty_like(t) if need else None for t in (mel, post, gate)]
+        call("t2_loss_terms", mel, post, gate, mel_tgt.contiguous().float(), gate_tgt.contiguous().float(),
+             mel_len.to(torch.int32), B, T, M, loss3, grads[0], grads[1], grads[2], 1.0, torch.cuda.current_stream().cuda_stream)
+        ctx.grads = grads
+        return loss3.float()
+
+    @staticmethod
+    def backward(ctx, g3):
+        d_mel, d_post, d_gate = ctx.grads
+        return (d_mel * g3[1] if d_mel is not None else None, d_post * g3[2] if d_post is not None else None,
+                d_gate * g3[0] if d_gate is not None else None, None, None, None)
 
 
 class TTSModel(nn.Module):
@@ -75,10 +99,10 @@ class TTSModel(nn.Module):
         mel, post, gate, alignment = self(chars_idx=data["chars_idx"], chars_idx_len=meta["chars_idx_len"],
                                           teacher_forcing=True, mel_spectrogram=data["mel_spectrogram"],
                                           mel_spectrogram_len=meta["mel_spectrogram_len"], **self._args(meta))
-        gate_loss = F.binary_cross_entropy_with_logits(gate, data["gate"])
-        mel_loss = F.mse_loss(mel, data["mel_spectrogram"])
-        post_loss = F.mse_loss(post, data["mel_spectrogram"])
-        return gate_loss + mel_loss + post_loss, (gate_loss, mel_loss, post_loss), (mel, post, gate, alignment)
+        # the three terms of model/tts_model.py:197-199 from the library's loss kernel (no ATen arithmetic on this path)
+        l3 = _LossTermsFn.apply(mel, post, gate, data["mel_spectrogram"], data["gate"], meta["mel_spectrogram_len"])
+        gate_loss, mel_loss, post_loss = l3[0], l3[1], l3[2]
+        return l3.sum(), (gate_loss, mel_loss, post_loss), (mel, post, gate, alignment)
 
     def training_step(self, batch, batch_idx=0):
         return self._loss(batch)[0]

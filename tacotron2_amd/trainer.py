@@ -18,7 +18,7 @@ from typing import Optional, Sequence
 import torch
 import torch.distributed as dist
 
-from .engine import Engine
+from .engine import Engine, zero_later
 from .params import ParamStore
 
 
@@ -197,7 +197,7 @@ class Trainer:
                                    speaker_id=batch.get("speaker_id"),
                                    description_embeddings=batch.get("description_embeddings"), training=True, masks=masks,
                                    controls=batch.get("controls"))
-        ps.grad.zero_()
+        zero_later(ps.grad)       # (one region of the backward's first t2_zero_regions launch)
         loss3 = eng.loss_and_grads(outs, ctx, mel, batch["gate"])
         if self.dp:
             if self._tail_work is not None:       # two buckets: the tail has been in flight since the frame loop ended
@@ -211,7 +211,7 @@ class Trainer:
         # excluded from the global-norm clip (Lightning's clip_grad_norm_ skips them) and neither the parameters nor their
         # Adam moments move (torch.optim.Adam skips parameters without a gradient; no L2 term either).
         for name in self.frozen:
-            ps.G[name].zero_()
+            zero_later(ps.G[name])
         self.global_step += 1
         # MultiStepLR: the k-th optimiser step (k = global_step, 1-based) runs after k-1 scheduler steps
         eng.adam_step(self.global_step, self.lr_at(self.global_step - 1), self.weight_decay, self.max_norm,

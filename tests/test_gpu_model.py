@@ -357,6 +357,48 @@ def test_module_forward_backward_autograd_matches_reference_golden():
         if not err < 3e-4:
             bad.append((name, err))
     assert not bad, bad[:8]
+    # the same through the library's loss kernel, as TTSModel.training_step computes it (model/tts_model.py:197-201):
+    # loss value and, through autograd, every parameter gradient again
+    from tacotron2_amd.model.tts_model import _LossTermsFn
+    m.zero_grad()
+    mels, post, gates, al = m(t("chars_idx"), t("chars_len"), True, t("mel"), t("mel_len"), dropout_masks=masks)
+    l3 = _LossTermsFn.apply(mels, post, gates, t("mel"), t("gate"), t("mel_len"))
+    assert l3.shape == (3,) and abs(float(l3.sum()) - z["o_loss"][0]) < 1e-5 * max(1.0, abs(z["o_loss"][0]))
+    assert abs(float(l3[0]) - float(F.binary_cross_entropy_with_logits(gates, t("gate")))) < 1e-6
+    assert abs(float(l3[1]) - float(F.mse_loss(mels, t("mel")))) < 1e-5 and abs(float(l3[2]) - float(F.mse_loss(post, t("mel")))) < 1e-5
+    l3.sum().backward()
+    torch.cuda.synchronize()
+    bad = []
+    for name, p in m.named_parameters():
+        r = torch.from_numpy(z["g." + name]).double()
+        err = float((p.grad.double().cpu() - r).abs().max()) / max(float(r.abs().max()), 1e-3)
+        if not err < 3e-4:
+            bad.append((name, err))
+    assert not bad, bad[:8]
+
+
+def test_ttsmodel_validation_step_loss_is_the_reference_loss_of_its_outputs():
+    """TTSModel.validation_step (model/tts_model.py:204-253) on the reference-generated eval fixture (dropout 0: deterministic): the
+    returned loss - computed by the library's loss kernel, not by ATen - equals BCE-with-logits + 2 x MSE of the fixture's outputs
+    against the targets (plain means over the padded tensors), and the prediction slices follow the reference's indexing."""
+    import torch.nn.functional as F
+    from tacotron2_amd.model import TTSModel
+    dev = _dev()
+    z = load_golden("tf_eval")
+    tm = TTSModel(lr=1e-3, weight_decay=1e-6, num_chars=39, dropout=0.0, device=dev, **{k: v for k, v in SMALL.items() if k != "num_chars"})
+    tm.tacotron2.load_state_dict(params_from(z))
+    tm.eval()
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    batch = ({"chars_idx": t("chars_idx"), "mel_spectrogram": t("mel"), "gate": t("gate")},
+             {"chars_idx_len": t("chars_len"), "mel_spectrogram_len": t("mel_len")}, {})
+    out = tm.validation_step(batch, 0)
+    ref = lambda k: torch.from_numpy(z[k])
+    want = float(F.binary_cross_entropy_with_logits(ref("o_gates"), ref("gate")) + F.mse_loss(ref("o_mels"), ref("mel"))
+                 + F.mse_loss(ref("o_post"), ref("mel")))
+    assert abs(float(out["loss"]) - want) < 1e-5 * max(1.0, abs(want)), (float(out["loss"]), want)
+    n0 = int(z["mel_len"][0])
+    assert out["mel_spectrogram_pred"].shape == (n0, 16) and mx(out["mel_spectrogram_pred"], z["o_post"][0, :n0]) < 2e-4
+    assert out["alignment"].shape == (n0, int(z["chars_len"][0]))
 
 
 def test_module_inference_and_eval_mode():
