@@ -358,6 +358,8 @@ class Engine:
         begin_phase (T2Bn.sums_prezeroed) instead of one memset per layer."""
         C = max(self.d["encoded_dim"], self.d["postnet_dim"], self.d["num_mels"])
         arena = self.buf("bn.sums", 16, 2 * C + 2, dtype=torch.float64)
+        if tag not in self.BN_SLOTS:      # a layer driven from outside the engine's phases (model/submodules.py): its own workspace
+            return zero_later(self.buf(f"{tag}.sums", 2 * C + 2, dtype=torch.float64))
         return arena[self.BN_SLOTS[tag] + (8 if backward else 0)]
 
     def begin_phase(self, backward: bool):
@@ -451,6 +453,10 @@ class Engine:
         E, H = d["encoded_dim"], d["encoded_dim"] // 2
         Lp = L + 4
         x = self.buf("enc.x0", B, Lp, E)
+        if fill_splits(B * Lp - 4, E, 5 * E):      # (gemm_fill: the convolutions accumulate two K slices into a cleared output)
+            for li in range(3):
+                raw = self.buf(f"enc.conv{li}.raw", B * Lp, E)
+                zero_later(raw.view(-1)[:(B * Lp - 4) * E]); _PREZEROED[raw.data_ptr()] = True
         call("t2_embedding_fwd", chars_idx, P["encoder.embedding.weight"], x, B, L, E, 2, _stream())
         enc_drop = masks.get("enc_drop") if masks else None
         for li, i in enumerate((0, 4, 8)):
@@ -832,6 +838,20 @@ class Engine:
         R, R1 = T * B, (T + 1) * B
         ldp, ldx = D + Ef, A + Ef
         self.begin_phase(backward=True)
+        # accumulators of the deferred weight-gradient GEMMs (run later, mostly on the side stream) and the split-K outputs of the
+        # encoder's data-gradient GEMMs: cleared here, in the backward's first launch, not one launch each
+        pchans = [M, Pn, Pn, Pn, Pn, M]
+        for li in range(5):
+            self.prezero(f"post.conv{li}.dwp", pchans[li + 1], 5 * pchans[li])
+        Lp_e = L + 4
+        for li in range(3):
+            self.prezero(f"enc.conv{li}.dwp", E, 5 * E)
+            if fill_splits(B * Lp_e - 4, E, 5 * E):
+                dxe = self.buf(f"enc.conv{li}.dx", B * Lp_e, E)
+                zero_later(dxe.view(-1)[:(B * Lp_e - 4) * E]); _PREZEROED[dxe.data_ptr()] = True
+        if fill_splits(B * Lp_e - 4, E, 8 * H):
+            dxe = self.buf("enc.dx3", B * Lp_e, E)
+            zero_later(dxe.view(-1)[:(B * Lp_e - 4) * E]); _PREZEROED[dxe.data_ptr()] = True
 
         # ---- postnet --------------------------------------------------------------------------------
         chans = [M, Pn, Pn, Pn, Pn, M]
