@@ -265,6 +265,11 @@ def main():
     init_parameters(ps, seed=0)           # identical replicas on every rank
     tr = Trainer(ps, lr=1e-3, weight_decay=1e-6, scheduler_milestones=(50000, 75000), sync_bn=args.sync_bn,
                  overlap_allreduce=args.overlap_allreduce and not args.one_allreduce, force_collectives=args.force_dp)
+    if args.share_gpu and world > 1:
+        # several ranks on ONE card (rehearsals): a persistent launch needs all of its workgroups co-resident, which two processes
+        # launching theirs at the same moment cannot promise each other (the bounded waits then time out and poison the step) -
+        # the recurrences run as per-step launches here.  One rank per GPU (the real thing) keeps the persistent launches.
+        tr.engine.dec_chain = "steps"; tr.engine.enc_chain = "steps"
     cpu_batch = ljspeech_batch(args.batch, seed=1234 + rank, num_speakers=4,
                                fixed_shape=(160, 860) if args.fixed_shape else None)
     batch = {k: v.to(dev) for k, v in cpu_batch.items()}

@@ -78,6 +78,9 @@ def do_train(dataset_config: dict, training_config: dict, model_config: dict, ex
                  sync_bn=bool(training_config.get("sync_batchnorm", False)),
                  overlap_allreduce=bool(training_config.get("overlap_allreduce", False)),
                  force_collectives=force_dp)
+    if world > 1 and os.environ.get("T2_SHARE_GPU") == "1":
+        # rehearsal of N ranks on ONE card: persistent launches of different processes cannot promise each other co-residency
+        tr.engine.dec_chain = "steps"; tr.engine.enc_chain = "steps"
     if resume_ckpt:
         # trainer.fit(ckpt_path=...) (run/train.py:245): weights, global_step, Adam moments and the scheduler state all come
         # back, for plain resumes and for --finetune alike (the fine-tune then runs exactly `finetune_steps` more steps)

@@ -226,7 +226,7 @@ def test_bench_four_ranks_rehearsal_on_one_gpu(tmp_path):
            "--master-port", "29614", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
            "--batch", "3", "--backend", "gloo", "--share-gpu", "--overlap-allreduce"]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-12000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                                     # rank 0 only
     d = json.loads(lines[0])
