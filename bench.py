@@ -348,6 +348,7 @@ def main():
     # secondary metric of BASELINE.json ("decode steps/sec"): batched autoregressive inference, 64 utterances (configs[4]),
     # fixed 860 frames with the stop checks live (random weights never emit a stop), rank 0 only, outside the timed region
     decode = None
+    decode_b1 = None
     if rank == 0 and world == 1 and not args.no_decode:      # (reported by the N = 1 run only: the other ranks would idle)
         ib = ljspeech_batch(64, seed=4321, num_speakers=4)
         eng = tr.engine
@@ -365,16 +366,45 @@ def main():
         loop_ms = eng.segment_times_ms().get("inf.frame_loop", 0.0)      # HIP events around the frame loop only
         Ld = int(ci.shape[1])
         us_step = loop_ms * 1e3 / n_dec
-        gbs = decoder_step_bytes(64, Ld, 512) / (us_step * 1e-6) / 1e9 if us_step > 0 else 0.0
-        tfs = decoder_step_flops(64, Ld, 512) / (us_step * 1e-6) / 1e12 if us_step > 0 else 0.0
+
+        def decode_roofline(Bd, L_, us):
+            """Both fractions of one autoregressive decoder step, and what actually bounds it.  Measured (round 4,
+            profiles/r04_ab_cell_mfma_ablation.txt): with 3/4 of the cells' MFMAs removed the frame gets 1 % shorter - the step is
+            NOT matrix-pipe bound; it is six dependent launches (each ~2-3 us of launch boundary + 1.3-3 us to the first dependent
+            operand) whose K loops run at the rate a compute unit takes operands in (~65 GB/s per CU)."""
+            gbs = decoder_step_bytes(Bd, L_, 512) / (us * 1e-6) / 1e9 if us > 0 else 0.0
+            tfs = decoder_step_flops(Bd, L_, 512) / (us * 1e-6) / 1e12 if us > 0 else 0.0
+            return dict(bound="latency: 6 dependent launches per frame + per-CU operand ingest (not the matrix pipe: "
+                              "profiles/r04_ab_cell_mfma_ablation.txt)",
+                        kernel=f"autoregressive decoder step, {Bd} utterance(s) (6 launches / frame)",
+                        mfma_achieved_TFLOPs=tfs, mfma_peak_TFLOPs=MFMA_F32_PEAK_TFLOPS, mfma_frac=tfs / MFMA_F32_PEAK_TFLOPS,
+                        hbm_achieved_GBs=gbs, hbm_peak_GBs=HBM_PEAK_GBS, hbm_frac=gbs / HBM_PEAK_GBS,
+                        launch_floor_us=6 * 1.7, launch_floor_frac=6 * 1.7 / us if us > 0 else None,
+                        algorithmic_bytes_per_step=decoder_step_bytes(Bd, L_, 512),
+                        algorithmic_flops_per_step=decoder_step_flops(Bd, L_, 512))
         decode = dict(decode_steps_per_s=n_dec / ddt, utterance_frames_per_s=64 * n_dec / ddt, batch=64, frames=n_dec,
                       L=Ld, launches_per_frame=6, note="decode_steps_per_s includes encoder, conditioning and postnet of the call",
                       frame_loop_us_per_step=us_step, frame_loop_steps_per_s=1e6 / us_step if us_step > 0 else None,
-                      roofline=dict(bound="mfma", kernel="autoregressive decoder step, 64 utterances (6 launches / frame)",
-                                    achieved=tfs, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=tfs / MFMA_F32_PEAK_TFLOPS,
-                                    hbm_achieved_GBs=gbs, hbm_frac=gbs / HBM_PEAK_GBS,
-                                    algorithmic_bytes_per_step=decoder_step_bytes(64, Ld, 512),
-                                    algorithmic_flops_per_step=decoder_step_flops(64, Ld, 512)))
+                      roofline=decode_roofline(64, Ld, us_step))
+        # the reference's own `say` shape (run/say.py:139-149): ONE utterance, the same 860 frames.  At one row the frame is pure
+        # weight streaming (72.4 MB) - and six launch latencies.
+        c1, l1_, s1 = ci[:1].contiguous(), cl[:1].contiguous(), spk[:1].contiguous()
+        L1 = int(l1_[0]); c1 = c1[:, :L1].contiguous()
+        eng.infer(c1, l1_, 32, speaker_id=s1, training=False, seed=1)
+        torch.cuda.synchronize()
+        eng.profile = True; eng.marks = []; eng.spans = []
+        eng.mark("inf.start")
+        tb1 = time.perf_counter()
+        eng.infer(c1, l1_, n_dec, speaker_id=s1, training=False, seed=2, check_every=64)
+        torch.cuda.synchronize()
+        db1 = time.perf_counter() - tb1
+        eng.profile = False
+        us_b1 = eng.segment_times_ms().get("inf.frame_loop", 0.0) * 1e3 / n_dec
+        decode_b1 = dict(batch=1, frames=n_dec, L=L1, decode_steps_per_s=n_dec / db1, frame_loop_us_per_step=us_b1,
+                         frame_loop_steps_per_s=1e6 / us_b1 if us_b1 > 0 else None,
+                         realtime_factor=(n_dec * 256 / 22050) / db1, roofline=decode_roofline(1, L1, us_b1),
+                         note="the reference's `say` shape: one utterance, whole call (encoder + 860 frames + postnet); realtime_factor = "
+                              "seconds of audio at 22.05 kHz / hop 256 per second of wall time")
         # SURVEY section 8d also asks for the utterances sorted by length: the same lock-step loop, reported beside.  (Runs in which
         # utterances stop at different frames are the parity tests' job: tests/test_gpu_fullsize.py, 64 utterances against the oracle.)
         order = torch.argsort(cl, descending=True)
@@ -419,7 +449,7 @@ def main():
                                  us_per_decoder_step=dec_fwd_ms * 1e3 / T if T else None),
                    segments_ms={k: round(v, 3) for k, v in seg.items()},
                    per_rank=[{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in per_rank],
-                   decode=decode, matmul_precision_high=high)
+                   decode=decode, decode_b1=decode_b1, matmul_precision_high=high)
         # HBM-side bytes of the same kernels from rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE, profiles/):
         # recorded offline because counters cannot be collected inside this process
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")

@@ -58,7 +58,7 @@ def train(ctx, speech_dir, results_dir=None, resume_ckpt=None, prosody_model_che
 @click.option("--random-seed", required=False, type=int, default=None, help="A random seed to use in generation.")
 @click.option("--speaker-id", required=False, type=int, default=None, help="Speaker ID for a multi-speaker model")
 @click.option("--controls", required=False, type=str, default=None, help="If controls are enabled, a comma-separated list of values to pass into the model. Defaults to all 0 values.")
-@click.option("--description", required=False, type=str, default=None, help="Description text (needs BERT weights; unavailable offline)")
+@click.option("--description", required=False, type=str, default=None, help="Path of a precomputed description embedding (.pt / .npy, pooler_output of bert-base-uncased); raw text needs the BERT weights (unavailable offline)")
 def say(ctx, checkpoint, text, out, speaker_id, hifi_gan_checkpoint, random_seed, controls, description):
     if ctx.obj["config"] is None:
         raise Exception("Configuration required for speech!")

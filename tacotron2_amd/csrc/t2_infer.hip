@@ -115,6 +115,10 @@ __global__ __launch_bounds__(64 * NW, 1) void linear_rows_kernel(LinK p) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int c = c0 + NW * j < NT ? c0 + NW * j : NT - 1;
+#ifdef T2_NT_WEIGHTS_MT1     // diagnostic build: the linear's weights as a non-temporal stream (A/B at B <= 16: one row block reads them once per frame)
+            if (MT == 1) bw[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wb + wcs * c));
+            else
+#endif
             bw[j] = *reinterpret_cast<const f32x4*>(wb + wcs * c);
 #pragma unroll
             for (int m = 0; m < MT; ++m)

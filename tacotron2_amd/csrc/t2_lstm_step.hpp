@@ -123,6 +123,10 @@ __device__ __forceinline__ void t2_lstm_fwd_fast_body(const LstmK& p, const int 
     auto load_chunk = [&](int g, int j, f32x4& bw, f32x4 (&ax)[MT]) {
         const int c = 4 * U * g + 4 * j + w;
         const int cx = c < NT ? c : NT - 1;     // padding chunks: any finite activations x the zero weight chunk
+#ifdef T2_NT_WEIGHTS_MT1     // diagnostic build (A/B, profiles/r05_ab_decode_nt_weights.txt): once-read weight stream of the <= 16-row step
+        if (MT == 1) bw = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wb + (long)c * 256));
+        else
+#endif
         bw = *reinterpret_cast<const f32x4*>(wb + (long)c * 256);
 #pragma unroll
         for (int m = 0; m < MT; ++m) ax[m] = *reinterpret_cast<const f32x4*>(xb[m] + xcs * cx);

@@ -15,6 +15,28 @@ from ..model.tts_model import TTSModel
 from .common import model_kwargs
 
 
+def load_description(description: Optional[str], dim: int, n: int, dev) -> torch.Tensor:
+    """--description of `say`.  The reference encodes the description TEXT with google-bert/bert-base-uncased (run/say.py:93-116:
+    tokenizer + BertModel -> pooler_output, (1, 768)) - remote weights, unavailable offline.  What the model consumes is only that
+    vector, and the dataset path already feeds it from precomputed files (datasets/tts_dataset.py:277-287: torch.load of a `.pt`
+    per utterance, zeros when absent).  So: a PATH to a precomputed embedding - `.pt` (weights-only load) or `.npy`, (dim,) or
+    (1, dim) - is used as the dataset uses it; no description = zeros; raw text still needs BERT and is refused with that message."""
+    import os
+    if description is None:
+        return torch.zeros(n, dim, device=dev)
+    if not (os.path.isfile(description) and description.endswith((".pt", ".npy"))):
+        raise NotImplementedError("--description with raw text needs the remote google-bert/bert-base-uncased weights (unavailable "
+                                  "offline); pass the path of a precomputed pooler_output embedding (.pt or .npy, shape "
+                                  f"({dim},)) instead, as the dataset manifests do")
+    if description.endswith(".npy"):
+        v = torch.from_numpy(np.load(description, allow_pickle=False))
+    else:
+        v = torch.load(description, map_location="cpu", weights_only=True)
+    v = torch.as_tensor(v).float().reshape(-1)
+    assert v.numel() == dim, f"--description embedding has {v.numel()} values, the model expects {dim}"
+    return v.to(dev).unsqueeze(0).repeat(n, 1).contiguous()
+
+
 def do_say(dataset_config: dict, training_config: dict, model_config: dict, extensions_config: dict, device: int,
            checkpoint: str, text: Union[str, List[str]], output: str, hifi_gan_checkpoint: Optional[str] = None,
            random_seed: Optional[int] = None, speaker_id: Optional[int] = None, controls: Optional[str] = None,
@@ -37,10 +59,7 @@ def do_say(dataset_config: dict, training_config: dict, model_config: dict, exte
         kw["speaker_id"] = torch.full((len(texts),), int(speaker_id or 0), dtype=torch.int32, device=dev)
     if model.description_embeddings:
         dim = model.hparams["description_embeddings_dim"]
-        if description is not None:
-            raise NotImplementedError("BERT description encoding needs the remote google-bert weights (unavailable offline); "
-                                      "pass precomputed embeddings through the Python API instead")
-        kw["description_embeddings"] = torch.zeros(len(texts), dim, device=dev)
+        kw["description_embeddings"] = load_description(description, dim, len(texts), dev)
     if model.controls:      # run/say.py:113-118: comma-separated values; the CLI help promises zeros by default
         n_ctl = int(model.hparams["controls_dim"])
         vals = [float(x) for x in controls.split(",")] if controls else [0.0] * n_ctl

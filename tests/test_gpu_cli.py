@@ -417,3 +417,43 @@ def test_device_prefetcher_yields_the_loader_batches_in_order():
     it = iter(pf)
     assert int(next(it)["n"]) == 0
     it.close()
+
+
+def test_cli_say_description_takes_a_precomputed_embedding(tmp_path):
+    """`say --description PATH` (run/say.py:93-116 feeds BERT's pooler_output of the description text; the weights are remote, so the
+    CLI takes the precomputed vector the way the dataset does, datasets/tts_dataset.py:277-287).  Weights of the reference-generated
+    `tf_train_desc` fixture (7 speaker tokens, description dim 24): the embedding must change the output against the zero vector, the
+    .pt and .npy forms of one vector must give the same output, raw text is refused with the BERT message."""
+    from helpers import SMALL, load_golden, params_from
+    z = load_golden("tf_train_desc")
+    sd = {"tacotron2." + k: v for k, v in params_from(z).items()}
+    hp = dict(lr=1e-3, weight_decay=1e-6, dropout=0.5, speaker_tokens=True, num_speakers=7, description_embeddings=True,
+              description_embeddings_dim=24, **SMALL)
+    ck = tmp_path / "desc.ckpt"
+    torch.save({"state_dict": sd, "hyper_parameters": hp, "global_step": 0, "epoch": 0}, ck)
+    cfg = {"dataset": {"train": "none.csv", "val": "none.csv",
+                       "preprocessing": {"allowed_chars": ALLOWED, "expand_abbreviations": True, "end_token": "^", "num_mels": 16}},
+           "training": {"lr": 1e-3, "batch_size": 4, "weight_decay": 1e-6, "name": "tiny", "args": {"max_steps": 6}},
+           "model": {"scheduler_milestones": [], "args": {"prenet_dim": 16, "att_rnn_dim": 32, "att_dim": 16, "rnn_hidden_dim": 32,
+                                                          "postnet_dim": 32, "dropout": 0.5, "char_embedding_dim": 32}},
+           "extensions": {"speaker_tokens": {"active": True, "num_speakers": 7}, "controls": {"active": False},
+                          "descriptions": {"bert_embeddings": True, "finetuneable": False}}}
+    cfgp = tmp_path / "cfg.json"
+    cfgp.write_text(json.dumps(cfg))
+    v = torch.randn(24, generator=torch.Generator().manual_seed(5)) * 2
+    torch.save(v, tmp_path / "d.pt")
+    np.save(tmp_path / "d.npy", v.view(1, 24).numpy())
+    outs = {}
+    for name, extra in (("zeros", []), ("pt", ["--description", str(tmp_path / "d.pt")]), ("npy", ["--description", str(tmp_path / "d.npy")])):
+        npy = tmp_path / f"say_{name}.npy"
+        _run(["--config", str(cfgp), "--device", "0", "say", "--checkpoint", str(ck), "--text", "Hello there, how are you?", "--out",
+              str(npy), "--random-seed", "3", "--speaker-id", "2"] + extra)
+        outs[name] = np.load(npy)
+        assert outs[name].ndim == 2 and outs[name].shape[1] == 16 and np.isfinite(outs[name]).all()
+    assert outs["pt"].shape == outs["npy"].shape and np.array_equal(outs["pt"], outs["npy"])
+    n = min(len(outs["pt"]), len(outs["zeros"]))
+    assert outs["pt"].shape != outs["zeros"].shape or np.abs(outs["pt"][:n] - outs["zeros"][:n]).max() > 1e-3
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "--config", str(cfgp), "--device", "0", "say", "--checkpoint", str(ck),
+                        "--text", "Hi.", "--out", str(tmp_path / "bad.npy"), "--description", "a calm, low voice"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "bert-base-uncased" in (r.stdout + r.stderr)
