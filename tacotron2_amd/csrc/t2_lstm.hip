@@ -190,8 +190,8 @@ __global__ __launch_bounds__(256, 1) void lstm_step_fwd_sq_kernel(LstmK2 pp) {
     const float* xb[2];
     const long xcs = p.xt_cs;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {       // (tiled rows exist up to Bp = round_up(B, 16): clamp the row tiles past it)
-        const long row = b0 + m * 16 + r, rows = xcs >> 4;
+    for (int m = 0; m < 2; ++m) {       // (tiled rows exist up to round_up(B, 16) of the whole batch: clamp the row tiles past it)
+        const long row = b0 + m * 16 + r, rows = p.xt_rows;
         xb[m] = p.xt + (row < rows ? row : rows - 1) * 16 + 4 * q;
     }
     f32x4 acc[2][2];

@@ -25,6 +25,7 @@ struct LstmK {
     float* gates_out; long ldg;
     const int32_t* len; int t;
     const float* xt; long xt_cs;        // x16-tiled input (chunk stride Bp*16 floats) or null
+    int xt_rows;                        // tiled rows that exist from this row block's first row (round_up(B_total, 16) - b0)
     float* ht_out; int ht_col0;
 };
 struct LstmK2 { LstmK s[2]; };
@@ -62,6 +63,7 @@ inline void t2_lstm_to_k(const T2LstmStep& s, LstmK& k, int b0, int bn) {
     k.gates_out = s.gates_out ? s.gates_out + (long)b0 * s.ldg : nullptr; k.ldg = s.ldg;
     k.len = s.len ? s.len + b0 : nullptr; k.t = s.t;
     k.xt_cs = (long)((s.B + 15) / 16 * 16) * 16;
+    k.xt_rows = (s.B + 15) / 16 * 16 - b0;         // tiled rows that exist from this row block's first row on
     k.xt = s.xt ? s.xt + (long)b0 * 16 : nullptr;
     k.ht_out = s.ht_out ? s.ht_out + (long)b0 * 16 : nullptr; k.ht_col0 = s.ht_col0;
 }
@@ -91,7 +93,10 @@ __device__ __forceinline__ void t2_lstm_fwd_fast_body(const LstmK& p, const int 
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int row = m * 16 + r;
-        xb[m] = p.xt ? p.xt + (long)row * 16 + 4 * q : p.seg[0].x + (long)(row < p.B ? row : 0) * p.seg[0].ldx + 4 * q;
+        // (tiled rows exist up to round_up(B, 16) of the WHOLE batch: a last row block of 33..48 rows has no fourth tile - its lanes
+        //  re-read the last existing row, and their products land in rows the epilogue drops)
+        xb[m] = p.xt ? p.xt + (long)(row < p.xt_rows ? row : p.xt_rows - 1) * 16 + 4 * q
+                     : p.seg[0].x + (long)(row < p.B ? row : 0) * p.seg[0].ldx + 4 * q;
     }
     f32x4 acc[MT];
 #pragma unroll

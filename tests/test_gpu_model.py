@@ -424,9 +424,13 @@ def test_module_inference_and_eval_mode():
 # ------------------------------------------------------------------------------------------------------
 # edge shapes and full-size properties
 # ------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,L,T,lens,tls", [(1, 1, 1, [1], [1]), (2, 7, 3, [7, 2], [3, 1]), (33, 21, 9, None, None)])
+@pytest.mark.parametrize("B,L,T,lens,tls", [(1, 1, 1, [1], [1]), (2, 7, 3, [7, 2], [3, 1]), (33, 21, 9, None, None),
+                                            (100, 9, 5, None, None)])
 def test_edge_shapes_match_oracle(B, L, T, lens, tls):
-    """single utterance / single character / single frame; ragged lengths down to 1; B = 33 (three 16-row MFMA tiles)."""
+    """single utterance / single character / single frame; ragged lengths down to 1; B = 33 (three 16-row MFMA tiles); B = 100: the
+    step kernels walk a batch above 64 rows as blocks of 64, and the last block here has 36 rows - three existing 16-row tiles
+    where the four-tile / square-tile kernels address four (the fourth tile's lanes must stay inside the tiled
+    activations of this block, not read the next frame's)."""
     dev = _dev()
     d = R.default_dims(num_chars=39, encoded_dim=64, prenet_dim=32, att_rnn_dim=64, att_dim=32, rnn_hidden_dim=64,
                        postnet_dim=64, num_mels=80, dropout=0.5)
