@@ -143,8 +143,22 @@ def restore_trainer(ck: dict, trainer) -> bool:
         found = True
     sch = (ck.get("lr_schedulers") or [None])[0]
     if sch:
-        trainer.milestones = sorted(int(m) for m, c in dict(sch["milestones"]).items() for _ in range(int(c)))
-        trainer.base_lr = float(sch["base_lrs"][0])
+        ms = sorted(int(m) for m, c in dict(sch["milestones"]).items() for _ in range(int(c)))
+        # MultiStepLR counts in ITS epochs.  Normally last_epoch == global_step.  A checkpoint the reference wrote after a resume
+        # from a scheduler-less checkpoint (the case below) carries a scheduler that was created at that resume: last_epoch counts
+        # from there, its milestones are relative to it, and its base_lrs hold the lr that was configured then - while the lr it
+        # actually steps is the optimizer's restored one (MultiStepLR multiplies param_groups[i]["lr"], it does not re-derive it from
+        # base_lrs).  Both are brought back to this trainer's absolute step axis: milestones shifted by global_step - last_epoch,
+        # the lr level from _last_lr and the milestones already passed.
+        last = int(sch.get("last_epoch", trainer.global_step))
+        off = trainer.global_step - last
+        trainer.milestones = [m + off for m in ms]
+        gamma = float(sch.get("gamma", 0.1))
+        if off != 0 and sch.get("_last_lr"):
+            passed = sum(1 for m in ms if m <= last)
+            trainer.base_lr = float(sch["_last_lr"][0]) / (gamma ** passed)
+        else:
+            trainer.base_lr = float(sch["base_lrs"][0])
     elif opt and opt.get("param_groups"):
         # no scheduler in the checkpoint (it was written with scheduler_milestones = []): Lightning's optimizer.load_state_dict
         # still restores param_groups[0]["lr"], which replaces the freshly configured lr (and the fine-tune's lr / 10) in the

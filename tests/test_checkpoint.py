@@ -156,6 +156,33 @@ def test_checkpoint_without_scheduler_restores_the_optimizer_lr(tmp_path):
     assert restore_trainer(ck, tr3) and tr3.milestones == [] and tr3.lr_at(100) == pytest.approx(2e-3)
 
 
+def test_scheduler_whose_epochs_do_not_start_at_step_zero_is_mapped_onto_the_step_axis():
+    """The mirror case: a checkpoint written by the reference AFTER such a scheduler-less resume.  Its MultiStepLR was
+    created at the resume (last_epoch counts from there, milestones relative to it, base_lrs = the lr configured then) and steps the
+    optimizer's RESTORED lr.  Example: resumed at global_step 7 with restored lr 1e-4 under a config of lr 1e-3 / milestones [5, 8];
+    saved 3 steps later: global_step 10, last_epoch 3, no milestone passed, _last_lr [1e-4].  Decays are due at steps 12 and 15, from 1e-4."""
+    from collections import Counter
+    from tacotron2_amd.checkpoint import restore_trainer
+    from tacotron2_amd.model.tts_model import TTSModel
+    from tacotron2_amd.trainer import Trainer
+    model = TTSModel(lr=1e-3, weight_decay=1e-6, scheduler_milestones=[5, 8], device="cpu", **_dims())
+    tr = Trainer(model.tacotron2.store, lr=1e-3, weight_decay=1e-6, scheduler_milestones=[5, 8])
+    ck = {"global_step": 10, "optimizer_states": [{"state": {}, "param_groups": [{"lr": 1e-4, "initial_lr": 1e-3}]}],
+          "lr_schedulers": [{"milestones": Counter({5: 1, 8: 1}), "gamma": 0.1, "base_lrs": [1e-3], "last_epoch": 3, "_last_lr": [1e-4],
+                             "_step_count": 4}]}
+    restore_trainer(ck, tr)
+    assert tr.global_step == 10 and tr.milestones == [12, 15] and tr.base_lr == pytest.approx(1e-4)
+    assert tr.lr_at(11) == pytest.approx(1e-4) and tr.lr_at(12) == pytest.approx(1e-5) and tr.lr_at(15) == pytest.approx(1e-6)
+    # ... and one milestone already passed since that resume: last_epoch 6 of [5, 8], _last_lr 1e-5 -> level 1e-4 before it
+    ck["global_step"], ck["lr_schedulers"][0]["last_epoch"], ck["lr_schedulers"][0]["_last_lr"] = 13, 6, [1e-5]
+    restore_trainer(ck, tr)
+    assert tr.milestones == [12, 15] and tr.base_lr == pytest.approx(1e-4) and tr.lr_at(13) == pytest.approx(1e-5)
+    # the ordinary case is untouched: last_epoch == global_step -> absolute milestones, base_lrs
+    ck["global_step"], ck["lr_schedulers"][0]["last_epoch"], ck["lr_schedulers"][0]["_last_lr"] = 6, 6, [1e-4]
+    restore_trainer(ck, tr)
+    assert tr.milestones == [5, 8] and tr.base_lr == pytest.approx(1e-3) and tr.lr_at(6) == pytest.approx(1e-4)
+
+
 def test_trainable_ranges_exclude_frozen_tensors():
     from tacotron2_amd.model.tts_model import TTSModel
     from tacotron2_amd.trainer import Trainer
