@@ -74,6 +74,12 @@ typedef struct {
                                         0 = "highest" (default): six bf16 products per element pair, fp32-exact operands;
                                         1 = "high": three products (a1b1 + a1b2 + a2b1, "bf16x3" in torch's terms, ~16
                                             significand bits); 2 = "medium": one bf16 product */
+    float* stat_out; int stat_Lp, stat_L;  /* optional (split kernel, plain store): per-tile column statistics of the stored values for
+                                        the BatchNorm that follows a conv-as-GEMM (model/encoder.py:33-41, model/postnet.py:9-16):
+                                        stat_out[ceil(M/128)][3][N] = {shift, sum (v - shift), sum (v - shift)^2} over the tile's rows
+                                        with row % stat_Lp < stat_L (real positions of the padded row layout); shift = the column's
+                                        value at the tile's first such row.  t2_bn_fwd(tile_stats = ...) merges them (no atomics, no
+                                        extra pass over the activations).  NULL = off */
 } T2Gemm;
 int t2_gemm(const T2Gemm* g, void* stream);
 
@@ -353,6 +359,9 @@ typedef struct {
     float* dgamma; float* dbeta;
     int phase; const float* shift; float grad_share;
     int sums_prezeroed;          /* 1: the caller has cleared `sums` on this stream (e.g. as one region of t2_zero_regions) */
+    const float* tile_stats; int tile_M;   /* forward, training: the producing GEMM's T2Gemm.stat_out and its M (rows of the GEMM):
+                                    the batch statistics come from these per-tile partials (merged in double) instead of a pass
+                                    over x; NULL = the statistics kernel */
 } T2Bn;
 int t2_bn_fwd(const T2Bn* s, void* stream);
 int t2_bn_bwd(const T2Bn* s, void* stream);

@@ -113,6 +113,35 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(BnK p, int rows_per_block
     }
 }
 
+// Batch statistics from the producing GEMM's per-tile partials (T2Gemm.stat_out): per channel, the tiles' (shift, sum d, sum d^2, n)
+// are merged in double with Chan's update and written to `sums` in the representation bn_finalize_kernel (and the sync-BN
+// all-reduce) expect: sums of (x - s) and (x - s)^2 about the layer's common shift s, then the row count.
+__global__ void bn_merge_tiles_kernel(BnK p, const float* ts, int tile_M) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= p.C) return;
+    const int ntile = (tile_M + 127) / 128;
+    const long Lp = p.Lp_x, L = p.L;
+    auto upto = [&](long x) { return (x / Lp) * L + ((x % Lp) < L ? (x % Lp) : L); };     // valid rows among GEMM rows [0, x)
+    double n = 0, mean = 0, M2 = 0;
+    for (int t = 0; t < ntile; ++t) {
+        const long r0 = (long)t * 128, r1 = r0 + 128 < tile_M ? r0 + 128 : tile_M;
+        const double nt = (double)(upto(r1) - upto(r0));
+        if (nt <= 0) continue;
+        const float* o = ts + (long)t * 3 * p.C + c;
+        const double s1 = o[p.C], s2 = o[2 * (long)p.C];
+        const double mt = (double)o[0] + s1 / nt, m2t = s2 - s1 * s1 / nt;
+        const double tot = n + nt, delta = mt - mean;
+        mean += delta * nt / tot;
+        M2 += m2t + delta * delta * n * nt / tot;
+        n = tot;
+    }
+    const double s = (double)(p.shift ? p.shift[c] : p.x[c]);
+    const double dm = mean - s;
+    p.sums[c] = n * dm;
+    p.sums[p.C + c] = (M2 > 0 ? M2 : 0) + n * dm * dm;
+    if (c == 0) p.sums[2 * p.C] = n;
+}
+
 __global__ void bn_finalize_kernel(BnK p) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= p.C) return;
@@ -639,10 +668,15 @@ extern "C" int t2_bn_fwd(const T2Bn* s, void* stream) {
                "t2_bn_fwd: phases 1/2 (sync-BN) need training statistics and a rank-independent shift");
     BnK k; to_bnk(s, k);
     if (s->training && s->phase != 2) {
-        if (!s->sums_prezeroed) (void)hipMemsetAsync(s->sums, 0, sizeof(double) * (2 * s->C + 2), ST);
-        const long R = (long)s->B * s->L;
-        const int rpb = 128;
-        hipLaunchKernelGGL(bn_stats_kernel, dim3(t2_cdiv(s->C, 64), t2_cdiv(R, rpb)), dim3(256), 0, ST, k, rpb);
+        if (s->tile_stats) {     // statistics from the producing GEMM's epilogue: merged per channel, `sums` is written, not added to
+            T2_REQUIRE(s->tile_M > 0 && (long)s->tile_M <= (long)s->B * s->Lp_x, "t2_bn_fwd: tile_M is the producing GEMM's row count");
+            hipLaunchKernelGGL(bn_merge_tiles_kernel, dim3(t2_cdiv(s->C, 64)), dim3(64), 0, ST, k, s->tile_stats, s->tile_M);
+        } else {
+            if (!s->sums_prezeroed) (void)hipMemsetAsync(s->sums, 0, sizeof(double) * (2 * s->C + 2), ST);
+            const long R = (long)s->B * s->L;
+            const int rpb = 128;
+            hipLaunchKernelGGL(bn_stats_kernel, dim3(t2_cdiv(s->C, 64), t2_cdiv(R, rpb)), dim3(256), 0, ST, k, rpb);
+        }
     }
     if (s->phase != 1) {
         hipLaunchKernelGGL(bn_finalize_kernel, dim3(t2_cdiv(s->C, 256)), dim3(256), 0, ST, k);

@@ -36,6 +36,7 @@ struct GemmK {
     int a_vec, b_vec;
     int ntm, ntn;
     int a_tap_len; long a_tap_stride;     // T2Gemm.a_tap_len / a_tap_stride (0: plain rows)
+    float* stat_out; int stat_Lp, stat_L; // T2Gemm.stat_out: per-tile column statistics of the stored values (split kernel, plain store)
 };
 
 // physical element offset of logical k0 (a multiple of the tile depth, which divides a_tap_len) on A's K axis
@@ -482,6 +483,78 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16(GemmK p) {
             }
         }
     }
+    // ---- optional: column statistics of this tile's stored values over its VALID rows (row % stat_Lp < stat_L: the rows of a
+    // conv-as-GEMM output that are real positions, not the junk rows that straddle two samples), for the BatchNorm that follows:
+    // stat_out[tile_m][0][col] = shift (the column's value at the tile's first valid row), [1] = sum (v - shift), [2] = sum (v - shift)^2.
+    // The tile-local shift keeps the sums free of cancellation whatever the channel mean is; t2_bn_fwd merges the tiles in double
+    // (Chan's update).  No atomics: every (tile, column) has one writer.
+    if (p.stat_out) {
+        __syncthreads();                                         // (the staging buffers are free: every wave is past its last read)
+        float* sh = reinterpret_cast<float*>(smem);              // [128] shift, then [2 sums][2 wm][128]
+        float* red = sh + 128;
+        const int Lp = p.stat_Lp, Lv = p.stat_L;
+        auto valid = [&](int row) { return row < p.M && (row % Lp) < Lv; };
+        int rv = 0;                                              // first valid row of the tile (junk runs are Lp - L rows long)
+        while (rv < 127 && !valid(m0 + rv)) ++rv;
+        auto value = [&](int i, int j, int r) {
+            const int col = n0 + wn * 64 + j * 32 + li;
+            float badd = 0.f;
+            if (col < p.N) { if (p.bias) badd += p.bias[col]; if (p.bias2) badd += p.bias2[col]; }
+            return p.alpha * (NP == 1 ? hi[i][j][r] : hi[i][j][r] + lo[i][j][r]) + badd;
+        };
+        {   // owner of row rv: wave row wm = rv / 64, block i = (rv % 64) / 32, lane half lh = ((rv % 32) / 4) & 1, reg from the rest
+            const int rr = rv & 31, own_wm = rv >> 6, own_i = (rv & 63) >> 5, own_lh = (rr >> 2) & 1, own_reg = (rr & 3) + 4 * (rr >> 3);
+            if (wm == own_wm && lh == own_lh) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (i == own_i && r == own_reg) v = value(i, j, r);
+                    sh[wn * 64 + j * 32 + li] = v;
+                }
+            }
+        }
+        __syncthreads();
+        // validity of this lane's 32 rows, once: one division for the lane's first row, then offsets < 64 with a single wrap
+        // (Lp >= 64; shorter padded rows take the plain modulo)
+        unsigned vmask = 0u;
+        {
+            const int rbase = m0 + wm * 64 + 4 * lh, rem0 = rbase % Lp;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int off = i * 32 + (r & 3) + 8 * (r >> 2);
+                    int rem = rem0 + off;
+                    if (Lp >= 64) rem = rem >= Lp ? rem - Lp : rem; else rem %= Lp;
+                    if (rbase + off < p.M && rem < Lv) vmask |= 1u << (i * 16 + r);
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float sft = sh[wn * 64 + j * 32 + li];
+            float a = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float dv = ((vmask >> (i * 16 + r)) & 1u) ? value(i, j, r) - sft : 0.f;
+                    a += dv; q = fmaf(dv, dv, q);
+                }
+            a += __shfl_xor(a, 32); q += __shfl_xor(q, 32);       // the two lane halves hold the other rows of the column
+            if (lh == 0) { red[(0 * 2 + wm) * 128 + wn * 64 + j * 32 + li] = a; red[(1 * 2 + wm) * 128 + wn * 64 + j * 32 + li] = q; }
+        }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N) {
+            float* o = p.stat_out + (long)tm * 3 * p.N + n0 + tid;
+            o[0] = sh[tid];
+            o[p.N] = red[(0 * 2 + 0) * 128 + tid] + red[(0 * 2 + 1) * 128 + tid];
+            o[2 * (long)p.N] = red[(1 * 2 + 0) * 128 + tid] + red[(1 * 2 + 1) * 128 + tid];
+        }
+    }
 }
 
 }  // namespace
@@ -510,6 +583,10 @@ extern "C" int t2_gemm(const T2Gemm* g, void* stream) {
                "t2_gemm: a_tap_len needs a k-major A, a multiple of 32 and K a whole number of taps");
     p.a_tap_len = g->a_tap_len; p.a_tap_stride = (long)g->a_tap_stride;
     if (g->a_tap_len) p.a_vec = p.a_vec && (g->a_tap_stride % 4 == 0);
+    T2_REQUIRE(!g->stat_out || (!g->native_fp32 && splitk == 1 && batch == 1 && g->accumulate == 0 && !g->relu && !g->mulmask &&
+                                g->stat_Lp >= g->stat_L && g->stat_L >= 1 && g->stat_Lp - g->stat_L < 64),
+               "t2_gemm: stat_out needs the split kernel, a plain store (no split-K, batch, accumulate, relu, mask) and 1 <= stat_L <= stat_Lp");
+    p.stat_out = g->stat_out; p.stat_Lp = g->stat_Lp; p.stat_L = g->stat_L;
     dim3 grid(p.ntm * p.ntn, 1, batch * splitk), block(256);
     hipStream_t s = (hipStream_t)stream;
     // share_cu: 24 KB of (unused) dynamic LDS on top of the 73.7 KB static tile buffers -> a second workgroup no longer fits

@@ -46,12 +46,12 @@ def set_float32_matmul_precision(name: str) -> None:
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_k=1, b_k=1, alpha=1.0, bias=None, bias2=None, mulmask=None, ldmask=0,
-         relu=0, accumulate=0, splitk=1, batch=1, sA=0, sB=0, sC=0, a_tap_len=0, a_tap_stride=0):
+         relu=0, accumulate=0, splitk=1, batch=1, sA=0, sB=0, sC=0, a_tap_len=0, a_tap_stride=0, stat_out=None, stat_Lp=0, stat_L=0):
     """C-ABI t2_gemm on raw pointers (ints) or tensors."""
     g = make("T2Gemm", A=A, B=B, C=C, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, a_kmajor=a_k, b_kmajor=b_k,
              alpha=alpha, bias=bias, bias2=bias2, mulmask=mulmask, ldmask=ldmask, relu=relu, accumulate=accumulate,
              splitk=splitk, batch=batch, sA=sA, sB=sB, sC=sC, share_cu=SHARE_CU[0], native_fp32=GEMM_NATIVE_FP32[0], precision=GEMM_PRECISION[0],
-             a_tap_len=a_tap_len, a_tap_stride=a_tap_stride)
+             a_tap_len=a_tap_len, a_tap_stride=a_tap_stride, stat_out=stat_out, stat_Lp=stat_Lp, stat_L=stat_L)
     call("t2_gemm", g, _stream())
 
 
@@ -188,6 +188,7 @@ class Engine:
         self.splitk_small_chunks = True  # forward pipeline: the hoisted decoder-LSTM input GEMM of short chunks runs split-K
         self.enc_chain = "persistent"    # encoder BiLSTM recurrence: "persistent" (one launch, both directions) | "steps" (S launches)
         self.enc_persist_max_rows = 32   # (the launch itself takes up to 64 rows, as two consecutive blocks)
+        self.bn_epilogue_stats = True # BatchNorm statistics from the producing GEMM's epilogue where it is one plain pass (postnet)
         self.bptt_off_chain = True    # the decoder-LSTM BPTT launches (side stream, a chunk ahead) keep the default wave priority
         self.sync_bn_group = None     # torch.distributed group: BatchNorm statistics over all ranks' shards (Trainer(sync_bn=True))
         self.grad_tail_hook = None    # called on the side stream once the gradients from prenet.0.weight onwards are enqueued
@@ -416,7 +417,16 @@ class Engine:
         wp = self.buf(f"{tag}.wp", Co, 5 * Ci)
         call("t2_pack_conv_weight", w, wp, Co, Ci, 5, 0, _stream())
         raw = self.buf(f"{tag}.raw", B * Lp, Co)
-        gemm_fill(x_pad, wp, raw, B * Lp - 4, Co, 5 * Ci, Ci, 5 * Ci, Co, bias=bias)
+        Mg = B * Lp - 4
+        # BatchNorm batch statistics as per-tile partial sums in the convolution GEMM's epilogue (no extra pass over `raw`, no
+        # atomics; merged by t2_bn_fwd) - wherever the GEMM is ONE plain pass over K (the under-filled encoder convolutions run
+        # split-K with atomics instead, their statistics stay a kernel of their own)
+        tstats = None
+        if training and self.bn_epilogue_stats and not fill_splits(Mg, Co, 5 * Ci) and not GEMM_NATIVE_FP32[0]:
+            tstats = self.buf(f"{tag}.tstats", (Mg + 127) // 128, 3, Co)
+            gemm(x_pad, wp, raw, Mg, Co, 5 * Ci, Ci, 5 * Ci, Co, bias=bias, stat_out=tstats, stat_Lp=Lp, stat_L=L)
+        else:
+            gemm_fill(x_pad, wp, raw, Mg, Co, 5 * Ci, Ci, 5 * Ci, Co, bias=bias)
         mean = self.buf(f"{tag}.mean", Co)
         invstd = self.buf(f"{tag}.invstd", Co)
         sums = self.bn_sums(tag, backward=False)
@@ -428,7 +438,7 @@ class Engine:
                   running_mean=Bf[bn_prefix + ".running_mean"], running_var=Bf[bn_prefix + ".running_var"],
                   training=1 if training else 0, momentum=0.1, eps=1e-5, sums=sums, mean=mean, invstd=invstd, act=act,
                   drop=drop, res=res, Lp_res=Lp_res, pad_res=pad_res, len=length, fill=fill, y=y, Lp_y=Lp_y, pad_y=pad_y,
-                  sums_prezeroed=1)
+                  sums_prezeroed=1, tile_stats=tstats, tile_M=Mg if tstats is not None else 0)
         if sync:
             # synchronised batch statistics: every rank sums (x - shift), (x - shift)^2 and its row count, ONE all-reduce of
             # 2C + 2 doubles per layer, then every rank normalises with the statistics of the global batch (what the

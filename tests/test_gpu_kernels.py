@@ -545,3 +545,60 @@ def test_griffin_lim_converges_and_mel_round_trip():
     lm2 = gl.front(wav)
     loud = lm > (lm.max() - 6.0)
     assert float((lm2 - lm)[loud].abs().mean()) < 0.5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,L,Ci,Co,level", [(32, 872, 80, 512, -5.5), (32, 872, 512, 80, 0.3), (3, 5, 64, 64, 2.0), (7, 61, 32, 200, -1.0)])
+def test_batchnorm_statistics_from_the_gemm_epilogue_match_float64(B, L, Ci, Co, level):
+    """T2Gemm.stat_out + T2Bn.tile_stats (round 5): the conv-as-GEMM of a postnet layer writes, per 128-row tile and column,
+    {shift, sum (v - shift), sum (v - shift)^2} over the tile's real positions (rows of the padded layout with row % (L + 4) < L;
+    the junk rows that straddle two samples are excluded), and t2_bn_fwd merges the tiles in double.  Against float64 statistics
+    of the SAME fp32 convolution output: mean, 1/std and the running statistics, at the bench's postnet shapes (27,904 positions,
+    first layer on a -5.5 log-mel level, last layer with N = 80 < one tile), a tiny padded length (L + 4 < 64: the modulo path) and a
+    ragged tile count; and bit-identical normalised outputs to the statistics-kernel path within fp32 rounding of the statistics."""
+    from tacotron2_amd import _lib
+    from tacotron2_amd._lib import call, make
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    Lp = L + 4
+    x_pad = torch.zeros(B, Lp, Ci)
+    x_pad[:, 2:2 + L] = torch.randn(B, L, Ci, generator=g) * 0.25 + level
+    w = torch.randn(Co, 5 * Ci, generator=g) / (5 * Ci) ** 0.5
+    bias = torch.randn(Co, generator=g)
+    xd, wd, bd = x_pad.to(dev), w.to(dev).contiguous(), bias.to(dev)
+    M = B * Lp - 4
+    raw = torch.zeros(B * Lp, Co, device=dev)
+    ts = torch.full(((M + 127) // 128, 3, Co), float("nan"), device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    gm = make("T2Gemm", A=xd, B=wd, C=raw, M=M, N=Co, K=5 * Ci, lda=Ci, ldb=5 * Ci, ldc=Co, a_kmajor=1, b_kmajor=1, alpha=1.0, bias=bd,
+              splitk=1, batch=1, stat_out=ts, stat_Lp=Lp, stat_L=L)
+    call("t2_gemm", gm, st)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ts).all())
+    valid = (torch.arange(B * Lp, device=dev) % Lp < L) & (torch.arange(B * Lp, device=dev) < M)
+    v64 = raw[valid].double()
+    n = v64.shape[0]
+    assert n == B * L
+    mean64, var64 = v64.mean(0), v64.var(0, unbiased=False)
+    outs = {}
+    for name, use_tiles in (("tiles", True), ("kernel", False)):
+        y = torch.empty(B, Lp, Co, device=dev)
+        mean, invstd = torch.empty(Co, device=dev), torch.empty(Co, device=dev)
+        sums = torch.zeros(2 * Co + 2, dtype=torch.float64, device=dev)
+        rm, rv = torch.zeros(Co, device=dev), torch.ones(Co, device=dev)
+        bn = make("T2Bn", B=B, L=L, C=Co, x=raw, Lp_x=Lp, gamma=torch.ones(Co, device=dev), beta=torch.zeros(Co, device=dev),
+                  running_mean=rm, running_var=rv, training=1, momentum=0.1, eps=1e-5, sums=sums, mean=mean, invstd=invstd, act=2,
+                  y=y, Lp_y=Lp, pad_y=2, tile_stats=ts if use_tiles else None, tile_M=M if use_tiles else 0)
+        call("t2_bn_fwd", bn, st)
+        torch.cuda.synchronize()
+        assert float(sums[2 * Co]) == n
+        assert float((mean.double() - mean64).abs().max()) < 2e-6 * max(1.0, abs(level) + 1), name
+        rel = ((invstd.double() - 1 / torch.sqrt(var64 + 1e-5)).abs() * torch.sqrt(var64 + 1e-5)).max()
+        assert float(rel) < 3e-6, (name, float(rel))
+        assert float((rv.double() - (0.9 + 0.1 * var64 * n / max(n - 1, 1))).abs().max()) < 1e-5
+        outs[name] = (y, mean, invstd)
+    assert float((outs["tiles"][0] - outs["kernel"][0]).abs().max()) < 2e-5      # same statistics to rounding -> same outputs
+    # the epilogue is refused where partial sums of partial products would be meaningless
+    gm.splitk = 2; gm.accumulate = 2
+    with pytest.raises(_lib.T2Error):
+        call("t2_gemm", gm, st)
