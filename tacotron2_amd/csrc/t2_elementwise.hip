@@ -116,30 +116,61 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(BnK p, int rows_per_block
 // Batch statistics from the producing GEMM's per-tile partials (T2Gemm.stat_out): per channel, the tiles' (shift, sum d, sum d^2, n)
 // are merged in double with Chan's update and written to `sums` in the representation bn_finalize_kernel (and the sync-BN
 // all-reduce) expect: sums of (x - s) and (x - s)^2 about the layer's common shift s, then the row count.
-__global__ void bn_merge_tiles_kernel(BnK p, const float* ts, int tile_M) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= p.C) return;
+__global__ __launch_bounds__(1024) void bn_merge_tiles_kernel(BnK p, const float* ts, int tile_M) {
+    // block = 64 channels x 16 tile lanes: a lane merges every 16th tile (its loads are independent of each other - the whole
+    // table is a few hundred KB, the cost is latency), then the 16 partial results are merged pairwise through LDS
+    __shared__ double sn[16][64], sm[16][64], sq[16][64];
+    const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     const int ntile = (tile_M + 127) / 128;
-    const long Lp = p.Lp_x, L = p.L;
-    auto upto = [&](long x) { return (x / Lp) * L + ((x % Lp) < L ? (x % Lp) : L); };     // valid rows among GEMM rows [0, x)
-    double n = 0, mean = 0, M2 = 0;
-    for (int t = 0; t < ntile; ++t) {
-        const long r0 = (long)t * 128, r1 = r0 + 128 < tile_M ? r0 + 128 : tile_M;
-        const double nt = (double)(upto(r1) - upto(r0));
-        if (nt <= 0) continue;
-        const float* o = ts + (long)t * 3 * p.C + c;
-        const double s1 = o[p.C], s2 = o[2 * (long)p.C];
-        const double mt = (double)o[0] + s1 / nt, m2t = s2 - s1 * s1 / nt;
+    const int Lp = p.Lp_x, L = p.L;
+    auto upto = [&](int x) { const int r = x % Lp; return (x / Lp) * L + (r < L ? r : L); };     // valid rows among GEMM rows [0, x)
+    auto merge = [](double& n, double& mean, double& M2, double nt, double mt, double m2t) {
+        if (nt <= 0) return;
         const double tot = n + nt, delta = mt - mean;
         mean += delta * nt / tot;
         M2 += m2t + delta * delta * n * nt / tot;
         n = tot;
+    };
+    double n = 0, mean = 0, M2 = 0;
+    if (c < p.C) {
+        for (int t0 = tl; t0 < ntile; t0 += 64) {
+            float sh[4], s1[4], s2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + 16 * u;
+                const float* o = ts + (long)(t < ntile ? t : 0) * 3 * p.C + c;
+                sh[u] = o[0]; s1[u] = o[p.C]; s2[u] = o[2 * (long)p.C];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + 16 * u;
+                if (t >= ntile) continue;
+                const int r0 = t * 128, r1 = r0 + 128 < tile_M ? r0 + 128 : tile_M;
+                const double nt = (double)(upto(r1) - upto(r0));
+                if (nt <= 0) continue;
+                merge(n, mean, M2, nt, (double)sh[u] + (double)s1[u] / nt, (double)s2[u] - (double)s1[u] * s1[u] / nt);
+            }
+        }
     }
-    const double s = (double)(p.shift ? p.shift[c] : p.x[c]);
-    const double dm = mean - s;
-    p.sums[c] = n * dm;
-    p.sums[p.C + c] = (M2 > 0 ? M2 : 0) + n * dm * dm;
-    if (c == 0) p.sums[2 * p.C] = n;
+    sn[tl][cl] = n; sm[tl][cl] = mean; sq[tl][cl] = M2;
+    __syncthreads();
+    for (int s_ = 8; s_ >= 1; s_ >>= 1) {
+        if (tl < s_) {
+            double a = sn[tl][cl], b = sm[tl][cl], d = sq[tl][cl];
+            merge(a, b, d, sn[tl + s_][cl], sm[tl + s_][cl], sq[tl + s_][cl]);
+            sn[tl][cl] = a; sm[tl][cl] = b; sq[tl][cl] = d;
+        }
+        __syncthreads();
+    }
+    if (tl == 0 && c < p.C) {
+        n = sn[0][cl]; mean = sm[0][cl]; M2 = sq[0][cl];
+        const double s = (double)(p.shift ? p.shift[c] : p.x[c]);
+        const double dm = mean - s;
+        p.sums[c] = n * dm;
+        p.sums[p.C + c] = (M2 > 0 ? M2 : 0) + n * dm * dm;
+        if (c == 0) p.sums[2 * p.C] = n;
+    }
 }
 
 __global__ void bn_finalize_kernel(BnK p) {
@@ -670,7 +701,7 @@ extern "C" int t2_bn_fwd(const T2Bn* s, void* stream) {
     if (s->training && s->phase != 2) {
         if (s->tile_stats) {     // statistics from the producing GEMM's epilogue: merged per channel, `sums` is written, not added to
             T2_REQUIRE(s->tile_M > 0 && (long)s->tile_M <= (long)s->B * s->Lp_x, "t2_bn_fwd: tile_M is the producing GEMM's row count");
-            hipLaunchKernelGGL(bn_merge_tiles_kernel, dim3(t2_cdiv(s->C, 64)), dim3(64), 0, ST, k, s->tile_stats, s->tile_M);
+            hipLaunchKernelGGL(bn_merge_tiles_kernel, dim3(t2_cdiv(s->C, 64)), dim3(1024), 0, ST, k, s->tile_stats, s->tile_M);
         } else {
             if (!s->sums_prezeroed) (void)hipMemsetAsync(s->sums, 0, sizeof(double) * (2 * s->C + 2), ST);
             const long R = (long)s->B * s->L;

@@ -594,7 +594,9 @@ def test_batchnorm_statistics_from_the_gemm_epilogue_match_float64(B, L, Ci, Co,
         assert float(sums[2 * Co]) == n
         assert float((mean.double() - mean64).abs().max()) < 2e-6 * max(1.0, abs(level) + 1), name
         rel = ((invstd.double() - 1 / torch.sqrt(var64 + 1e-5)).abs() * torch.sqrt(var64 + 1e-5)).max()
-        assert float(rel) < 3e-6, (name, float(rel))
+        # (the tile path shifts every tile by a value of its own; the statistics kernel shifts the whole layer by the channel's first
+        #  value and sums 27,904 terms in fp32 per partial - it is the LESS accurate of the two)
+        assert float(rel) < (3e-6 if use_tiles else 2e-5), (name, float(rel))
         assert float((rv.double() - (0.9 + 0.1 * var64 * n / max(n - 1, 1))).abs().max()) < 1e-5
         outs[name] = (y, mean, invstd)
     assert float((outs["tiles"][0] - outs["kernel"][0]).abs().max()) < 2e-5      # same statistics to rounding -> same outputs
