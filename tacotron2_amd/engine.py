@@ -188,7 +188,9 @@ class Engine:
         self.splitk_small_chunks = True  # forward pipeline: the hoisted decoder-LSTM input GEMM of short chunks runs split-K
         self.enc_chain = "persistent"    # encoder BiLSTM recurrence: "persistent" (one launch, both directions) | "steps" (S launches)
         self.enc_persist_max_rows = 32   # (the launch itself takes up to 64 rows, as two consecutive blocks)
-        self.bn_epilogue_stats = True # BatchNorm statistics from the producing GEMM's epilogue where it is one plain pass (postnet)
+        self.bn_epilogue_stats = False  # BatchNorm statistics from the producing GEMM's epilogue (T2Gemm.stat_out) instead of their own pass:
+                                        # built and measured in round 5 - more accurate (per-tile shifts), but the GEMM is VALU-bound and
+                                        # its epilogue costs more than the 22 us statistics pass it saves (profiles/r05_ab_bn_epilogue_stats.txt)
         self.bptt_off_chain = True    # the decoder-LSTM BPTT launches (side stream, a chunk ahead) keep the default wave priority
         self.sync_bn_group = None     # torch.distributed group: BatchNorm statistics over all ranks' shards (Trainer(sync_bn=True))
         self.grad_tail_hook = None    # called on the side stream once the gradients from prenet.0.weight onwards are enqueued
@@ -370,7 +372,8 @@ class Engine:
         arena = self.buf("bn.sums", 16, 2 * C + 2, dtype=torch.float64)
         zero_later(arena[8:] if backward else arena[:8])
         if not backward:
-            zero_later(self.persist_sync()[self.PERSIST_RING0:])
+            if self._persist_sync is not None:      # (created - zero-filled - by the first persistent launch of this engine)
+                zero_later(self._persist_sync[self.PERSIST_RING0:])
             self._persist_next = 0
 
     PERSIST_RING0 = 320              # words 0..255 legacy counters, 256 sticky flag; from 320: ring of 256-word counter blocks
