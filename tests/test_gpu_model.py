@@ -133,6 +133,19 @@ def test_forward_train_midsize_matches_oracle():
     assert l1(mels, ref[0]) < MEL_L1_TOL and l1(post, ref[1]) < MEL_L1_TOL
     assert mx(al, ref[3]) < 2e-5
     assert mx(mels, ref[0]) < 1e-3 and mx(post, ref[1]) < 1e-3
+    # The same forward with the BatchNorm statistics taken from the convolution GEMMs' epilogues (Engine.bn_epilogue_stats, off by
+    # default: profiles/r05_ab_bn_epilogue_stats.txt) - every encoder and postnet layer here is one plain GEMM pass (K = 640), so all
+    # eight layers take that path: same outputs and running statistics against the oracle
+    eng2, ps2 = build_engine(d, P, dev)
+    eng2.bn_epilogue_stats = True
+    (mels2, post2, _, al2), ctx2 = eng2.forward_tf(ci.to(dev), lens.to(dev), mel.to(dev), tl.to(dev), training=True,
+                                                   masks=masks_to_device(masks, dev))
+    torch.cuda.synchronize()
+    assert "post.conv0.tstats" in eng2._ws and "enc.conv0.tstats" in eng2._ws and "post.conv0.tstats" not in eng._ws
+    assert l1(mels2, ref[0]) < MEL_L1_TOL and l1(post2, ref[1]) < MEL_L1_TOL and mx(al2, ref[3]) < 2e-5
+    assert mx(post2, ref[1]) < 1e-3 and mx(post2, post) < 1e-4
+    for k in ps.Bf:
+        assert mx(ps2.Bf[k], ps.Bf[k].cpu()) < 1e-5, k
 
 
 # ------------------------------------------------------------------------------------------------------
