@@ -168,6 +168,7 @@ class Engine:
         self.dev = ps.device
         self._ws: Dict[str, torch.Tensor] = {}
         self._prez: Dict[str, bool] = {}
+        self._bn_clean: set = set()   # BatchNorm workspace slots cleared by begin_phase and not used since
         self._persist_next = 0
         self._side = None
         self.chunk = 64               # frames per pipeline chunk of the forward frame loop
@@ -357,13 +358,20 @@ class Engine:
                 "post.conv4": 7}
 
     def bn_sums(self, tag: str, backward: bool) -> torch.Tensor:
-        """The statistics workspace (2C + 2 doubles) of one BatchNorm layer: a slot of ONE arena, cleared per phase by
-        begin_phase (T2Bn.sums_prezeroed) instead of one memset per layer."""
+        """The statistics workspace (2C + 2 doubles) of one BatchNorm layer: a slot of ONE arena that begin_phase clears for the
+        phase's 8 layers at once (T2Bn.sums_prezeroed) instead of one memset per layer.  A slot is good for ONE use per clear: a
+        layer driven without begin_phase (encoder_fwd / conv_bn_fwd called on their own), or twice in a phase, gets its slot put on
+        the zero list right here."""
         C = max(self.d["encoded_dim"], self.d["postnet_dim"], self.d["num_mels"])
         arena = self.buf("bn.sums", 16, 2 * C + 2, dtype=torch.float64)
         if tag not in self.BN_SLOTS:      # a layer driven from outside the engine's phases (model/submodules.py): its own workspace
             return zero_later(self.buf(f"{tag}.sums", 2 * C + 2, dtype=torch.float64))
-        return arena[self.BN_SLOTS[tag] + (8 if backward else 0)]
+        slot = self.BN_SLOTS[tag] + (8 if backward else 0)
+        if slot in self._bn_clean:
+            self._bn_clean.discard(slot)
+        else:
+            zero_later(arena[slot])
+        return arena[slot]
 
     def begin_phase(self, backward: bool):
         """Start of a forward (teacher-forced or inference) / of a backward: the BatchNorm sums of the phase's 8 layers and - forward
@@ -371,6 +379,7 @@ class Engine:
         C = max(self.d["encoded_dim"], self.d["postnet_dim"], self.d["num_mels"])
         arena = self.buf("bn.sums", 16, 2 * C + 2, dtype=torch.float64)
         zero_later(arena[8:] if backward else arena[:8])
+        self._bn_clean = (self._bn_clean - set(range(0, 16))) | set(range(8, 16) if backward else range(0, 8))
         if not backward:
             if self._persist_sync is not None:      # (created - zero-filled - by the first persistent launch of this engine)
                 zero_later(self._persist_sync[self.PERSIST_RING0:])
