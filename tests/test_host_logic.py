@@ -188,3 +188,78 @@ def test_length_bucket_sampler_shards_similar_lengths_across_ranks():
     # one rank: unchanged behaviour (every utterance once, drop_last)
     one = list(LengthBucketBatchSampler(lengths, bs, window=16, seed=0))
     assert len(one) == 13100 // bs and len({i for b in one for i in b}) == len(one) * bs
+
+
+def _wav_files(tmp_path, lengths, sr=22050):
+    import wave
+    rng = np.random.default_rng(3)
+    names = []
+    for i, n in enumerate(lengths):
+        x = (rng.standard_normal(n) * 0.1).astype(np.float32)
+        x = np.concatenate([np.zeros(2500, np.float32), x, np.zeros(1800, np.float32)])
+        with wave.open(str(tmp_path / f"u{i}.wav"), "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(sr); w.writeframes((x * 32767).astype("<i2").tobytes())
+        names.append(f"u{i}.wav")
+    return names
+
+
+def test_trim_silence_running_sum_equals_the_framed_definition():
+    """librosa.effects.trim semantics (datasets/tts_dataset.py:197-199 of the reference; parity unpinned - librosa is absent): the O(n)
+    running-sum form against the literal (frames x 2048) gather it replaced, on signals with silent heads and tails."""
+    from tacotron2_amd.datasets.tts_dataset import trim_silence
+
+    def framed(x, top_db=60, frame_length=2048, hop_length=512):
+        if len(x) < frame_length:
+            return x
+        xp = np.pad(x, (frame_length // 2, frame_length // 2))
+        nfr = 1 + (len(xp) - frame_length) // hop_length
+        idx = np.arange(frame_length)[None, :] + hop_length * np.arange(nfr)[:, None]
+        rms = np.sqrt(np.mean(xp[idx] ** 2, axis=1))
+        db = 20 * np.log10(np.maximum(rms, 1e-10)) - 20 * np.log10(max(rms.max(), 1e-10))
+        nz = np.nonzero(db > -top_db)[0]
+        return x[:0] if len(nz) == 0 else x[nz[0] * hop_length:min(len(x), (nz[-1] + 1) * hop_length)]
+    rng = np.random.default_rng(0)
+    for k in range(25):
+        n = int(rng.integers(2048, 120000))
+        x = (rng.standard_normal(n) * 0.1).astype(np.float32)
+        a, b = int(rng.integers(0, n // 3)), int(rng.integers(0, n // 3))
+        x[:a] *= 1e-5; x[n - b:] *= 1e-5
+        want, got = framed(x), trim_silence(x)
+        assert len(want) == len(got) and (len(got) == 0 or (got[0] == want[0] and got[-1] == want[-1])), k
+    # digital silence has no peak to be 60 dB below: every frame is at 0 dB of the floor and the signal is kept whole (as librosa does)
+    assert len(trim_silence(np.zeros(5000, np.float32))) == 5000 and len(trim_silence(np.ones(100, np.float32))) == 100
+
+
+def test_device_batch_loader_host_side_packs_one_buffer_and_knows_the_shape(tmp_path):
+    """The host half of the training input pipeline (DeviceBatchLoader.host_batch -> HostWavBatch; no GPU needed): the batch's WAVs
+    decoded by the thread pool, trimmed, silence-padded and packed into ONE zero-filled buffer; the padded lengths (L, T) as host
+    integers - frames = 1 + samples // 256, what the device pass will produce - so a data-parallel step's shape can be agreed
+    before anything is on the device (Trainer.negotiate_collated -> set_global_shape)."""
+    from tacotron2_amd.datasets.tts_dataset import DeviceBatchLoader, TTSDataset
+    lengths = [9000, 15000, 12345, 30000, 7000]
+    files = _wav_files(tmp_path, lengths)
+    texts = ["short.", "a somewhat longer sentence.", "mid one", "the longest utterance of them all, by far.", "x"]
+    ds = TTSDataset(filenames=files, texts=texts, base_dir=str(tmp_path), speaker_ids=[0, 1, 2, 3, 0], silence=512, trim=True, cache=False,
+                    device="cpu")
+    ld = DeviceBatchLoader(ds, batch_size=2, shuffle=False, drop_last=True, decode_threads=2)
+    assert len(ld) == 2
+    got = list(ld)
+    assert [hb.idxs for hb in got] == [[0, 1], [2, 3]]
+    hb = got[1]
+    for r, i in enumerate(hb.idxs):
+        one = ds.load_audio(i)                                  # the per-utterance host path: the same samples, then zeros
+        assert hb.n[r] == len(one) and abs(len(one) - (lengths[i] + 512)) <= 1536      # trimmed to the signal (+- three hops), + silence
+        assert np.array_equal(hb.wav[r, :len(one)].numpy(), one) and float(hb.wav[r, len(one):].abs().max()) == 0.0
+    assert hb.wav.shape[0] == 2 and hb.wav.shape[1] % 64 == 0 and hb.wav.shape[1] >= max(hb.n)
+    assert hb.frames == [1 + n // 256 for n in hb.n] and hb.T == max(hb.frames)
+    assert hb.L == max(len(ds.ids[i]) for i in hb.idxs) and (hb.Lg, hb.Tg) == (hb.L, hb.T) and not hb.hit_mels
+    hb.set_global_shape(hb.L + 4, hb.T + 9)
+    assert (hb.Lg, hb.Tg) == (hb.L + 4, hb.T + 9)
+    assert ld.batches == 2 and ld.decode_s > 0
+    # the same through the data-parallel hook on one rank: a no-op
+    from tacotron2_amd.params import ParamStore
+    from tacotron2_amd.trainer import Trainer
+    from oracle import tacotron2_ref as R
+    from tests.helpers import SMALL
+    tr = Trainer(ParamStore(R.default_dims(**SMALL), "cpu"), lr=1e-3, weight_decay=0.0)
+    assert tr.negotiate_collated(got[0]) is got[0]
