@@ -249,7 +249,7 @@ def test_device_batch_loader_host_side_packs_one_buffer_and_knows_the_shape(tmp_
     for r, i in enumerate(hb.idxs):
         one = ds.load_audio(i)                                  # the per-utterance host path: the same samples, then zeros
         assert hb.n[r] == len(one) and abs(len(one) - (lengths[i] + 512)) <= 3072      # trimmed to the signal (within a 2048-window + two hops), + silence
-        assert np.array_equal(hb.wav[r, :len(one)].numpy(), one) and float(hb.wav[r, len(one):].abs().max()) == 0.0
+        assert np.array_equal(hb.wav[r, :len(one)].numpy(), one) and float(hb.wav[r, len(one):].abs().sum()) == 0.0
     assert hb.wav.shape[0] == 2 and hb.wav.shape[1] % 64 == 0 and hb.wav.shape[1] >= max(hb.n)
     assert hb.frames == [1 + n // 256 for n in hb.n] and hb.T == max(hb.frames)
     assert hb.L == max(len(ds.ids[i]) for i in hb.idxs) and (hb.Lg, hb.Tg) == (hb.L, hb.T) and not hb.hit_mels
