@@ -436,6 +436,9 @@ def main():
                                allreduce=("none" if not tr.dp else "2 buckets, tail overlapped with the encoder backward"
                                           if tr.overlap_allreduce else "1 call after the backward"),
                                queue_check=qc,
+                               hbm_footprint=dict(engine_workspaces=tr.engine.workspace_report(top=4),
+                                                  parameters_grads_adam_bytes=4 * 4 * ps.numel,
+                                                  torch_allocated_bytes=int(torch.cuda.max_memory_allocated(dev))),
                                shape_negotiation="none inside the timed region: one fixed batch, padded to the global shape before "
                                                  "it (main.py train agrees the shape of step k+1 on the host, in the loader thread, "
                                                  "over its own gloo group while step k runs: nothing on the step path either)",

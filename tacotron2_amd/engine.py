@@ -346,6 +346,12 @@ class Engine:
             zero_later(v)       # cleared by the next t2_zero_regions launch, in front of the next library call
         return v
 
+    def workspace_report(self, top: int = 8) -> dict:
+        """Device memory of the named workspaces as allocated so far (after a step at the largest shape seen): total bytes, count
+        and the largest ones - the engine's part of the HBM footprint (the tanh stash of the attention backward dominates)."""
+        sizes = sorted(((t.numel() * t.element_size(), n) for n, t in self._ws.items()), reverse=True)
+        return dict(total_bytes=sum(b for b, _ in sizes), buffers=len(sizes), largest={n: b for b, n in sizes[:top]})
+
     def prezero(self, name: str, *shape, dtype=torch.float32) -> torch.Tensor:
         """Allocate the named workspace and put it on the zero list NOW (a phase's prologue: one launch clears everything the phase
         accumulates into); the later `buf(name, ..., zero=True)` of the code that uses it is then a plain lookup."""
