@@ -1356,6 +1356,15 @@ class Engine:
         p = float(d["dropout"])
         t0 = 0
         self.mark("inf.encoder")
+        # The host looks at the groups' "everyone has stopped" words once per chunk of `check_every` frames - and ONE CHUNK LATE:
+        # the words of chunk k travel to pinned host memory behind the chunk (asynchronous copy + event) while chunk k+1 is already
+        # enqueued, so the device never waits for the host's round trip (the reference synchronises `done.all()` every frame,
+        # model/tacotron2.py:321).  A loop that has stopped therefore runs at most one chunk longer than it needed to; the exact
+        # break frame and `lengths` come from the stored stop logits afterwards (t2_stop_scan), whatever was computed past it.
+        pend = None
+        pin = torch.empty(len(groups), 2, dtype=torch.int32, pin_memory=True)
+        pins = [pin, pin.clone().pin_memory()]
+        k = 0
         while t0 < Tcap:
             t1 = min(Tcap, t0 + check_every)
             for gi, G in enumerate(groups):
@@ -1365,9 +1374,17 @@ class Engine:
                     call("t2_philox_mask", _ptr(G["pm"], t0 * 2 * Bg * Pd), n, p, seed, 1000 + t0 + 100003 * gi, st)
                 call("t2_decoder_infer", G["a"], t0, t1, st)
             t0 = t1
-            flags = torch.stack([G["state"] for G in groups]).cpu()     # the only host synchronisation: once per chunk
-            if bool((flags[:, 0] != 0).all()):
-                break
+            buf = pins[k & 1]
+            for gi, G in enumerate(groups):
+                buf[gi].copy_(G["state"], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            if pend is not None:
+                pend[0].synchronize()
+                if bool((pend[1][:, 0] != 0).all()):
+                    break
+            pend = (ev, buf)
+            k += 1
         self.mark("inf.frame_loop")
         # exact break frame and lengths from the stored stop logits (model/tacotron2.py:319-322)
         lengths = self.buf("inf.lengths", B, dtype=torch.int64)
