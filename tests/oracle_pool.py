@@ -25,12 +25,24 @@ _results = {}
 waited_s = {}
 
 
+_live = {}          # name -> Popen of a job that is running (ended by exact PID at shutdown)
+_closing = False
+
+
 def _run_child(name, out):
     t0 = time.time()
+    if _closing:
+        raise RuntimeError("oracle pool is shutting down")
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(THREADS))
-    r = subprocess.run([sys.executable, "-m", "tests.oracle_jobs", name, out, str(THREADS)], cwd=ROOT, capture_output=True, text=True, env=env)
-    if r.returncode != 0:
-        raise RuntimeError(f"oracle job {name} failed (rc {r.returncode}):\n{r.stderr[-3000:]}")
+    p = subprocess.Popen([sys.executable, "-m", "tests.oracle_jobs", name, out, str(THREADS)], cwd=ROOT, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, env=env)
+    _live[name] = p
+    try:
+        _, err = p.communicate()
+    finally:
+        _live.pop(name, None)
+    if p.returncode != 0:
+        raise RuntimeError(f"oracle job {name} failed (rc {p.returncode}):\n{err[-3000:]}")
     return out, time.time() - t0
 
 
@@ -71,10 +83,16 @@ def release(name):
 
 
 def shutdown():
-    global _pool
+    """End of the session (also after an early -x stop): queued jobs are cancelled, running ones are ended - by the exact process
+    handles started here - so nothing is left computing behind a finished test run."""
+    global _pool, _closing
+    _closing = True
     if _pool is not None:
         for f in _futures.values():
             f.cancel()
+        for p in list(_live.values()):
+            if p.poll() is None:
+                p.kill()
         _pool.shutdown(wait=True)
         _pool = None
     if _dir and os.path.isdir(_dir):
