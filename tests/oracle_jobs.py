@@ -82,6 +82,38 @@ def _libritts_fwd():
                 kw=dict(speaker_id=b["speaker_id"], description_embeddings=b["description_embeddings"]), kind="fwd")
 
 
+def _judged_fwd_b64():
+    """The shipped config's own batch size (config/vanilla-lj-hifi-stop.json:18) at the judged lengths: 64 utterances of the bench
+    generator - the step kernels' four row tiles / square tiles, the persistent decoder-LSTM launch as two blocks of 32 rows."""
+    from tacotron2_amd.synthetic import ljspeech_batch
+    d = R.default_dims(speaker_tokens=True, num_speakers=4)
+    P = R.init_params(d, seed=64)
+    b = ljspeech_batch(64, seed=1234, num_speakers=4)
+    ci, cl, mel, tl = b["chars_idx"], b["chars_idx_len"], b["mel_spectrogram"], b["mel_spectrogram_len"]
+    masks = scale_masks(d, ci.shape[0], ci.shape[1], mel.shape[1], 6464)
+    return dict(d=d, P=P, case=(ci, cl, mel, tl, b["gate"], masks), kw=dict(speaker_id=b["speaker_id"]), kind="fwd")
+
+
+def _libritts4():
+    """configs[3] (descriptions + 562 speaker tokens, E' = 640) at its per-GPU LENGTHS: the utterances of the LibriTTS-shaped batch with
+    the longest text, the most frames and the two shortest, as one batch of four - a full training step with every gradient."""
+    from tacotron2_amd.synthetic import ljspeech_batch
+    d = R.default_dims(speaker_tokens=True, num_speakers=562, description_embeddings=True, description_embeddings_dim=768)
+    P = R.init_params(d, seed=3)
+    b = ljspeech_batch(32, seed=1234, num_speakers=562, desc_dim=768, shape="libritts")
+    cl, tl = b["chars_idx_len"], b["mel_spectrogram_len"]
+    pick = [int(cl.argmax()), int(tl.argmax())]
+    for i in torch.argsort(tl).tolist():
+        if len(set(pick)) == 4:
+            break
+        pick.append(i)
+    pick = sorted(set(pick))
+    ci, mel, gate = b["chars_idx"][pick], b["mel_spectrogram"][pick], b["gate"][pick]
+    masks = scale_masks(d, 4, ci.shape[1], mel.shape[1], 936)
+    return dict(d=d, P=P, case=(ci, cl[pick], mel, tl[pick], gate, masks),
+                kw=dict(speaker_id=b["speaker_id"][pick], description_embeddings=b["description_embeddings"][pick]), kind="train")
+
+
 def _bench_len_vanilla():
     d = R.default_dims(speaker_tokens=True, num_speakers=4)
     P = R.init_params(d, seed=188)
@@ -135,7 +167,24 @@ def _decode_ragged():
     return dict(d=d, P=P, case=(ci, cl, None, None, None, None), kw=dict(speaker_id=spk), pm=pm, N=DECODE_N, kind="decode_ragged")
 
 
-CASES = dict(judged_fwd=_judged_fwd, judged4=_judged4, libritts_fwd=_libritts_fwd, bench_len_vanilla=_bench_len_vanilla,
+DECODE_FULL_N = 860
+
+
+def _decode_full():
+    """The bench's decode call at its FULL horizon: 64 utterances (L = 167), 860 frames, a stop projection that never stops (bias +50),
+    prenet masks replayed - every frame of the benchmarked length against the oracle (the ragged case above covers the stop logic)."""
+    from tacotron2_amd.synthetic import ljspeech_batch
+    d = R.default_dims(speaker_tokens=True, num_speakers=4)
+    P = R.init_params(d, seed=67)
+    P["decoder.gate.bias"] = torch.full_like(P["decoder.gate.bias"], 50.0)
+    ib = ljspeech_batch(64, seed=4321, num_speakers=4)
+    g = torch.Generator().manual_seed(68)
+    pm = (torch.rand(DECODE_FULL_N + 1, 2, 64, 256, generator=g) >= 0.5).float() * 2
+    return dict(d=d, P=P, case=(ib["chars_idx"], ib["chars_idx_len"], None, None, None, None), kw=dict(speaker_id=ib["speaker_id"]), pm=pm,
+                N=DECODE_FULL_N, kind="decode_full")
+
+
+CASES = dict(judged_fwd=_judged_fwd, judged_fwd_b64=_judged_fwd_b64, libritts4=_libritts4, decode_full=_decode_full, judged4=_judged4, libritts_fwd=_libritts_fwd, bench_len_vanilla=_bench_len_vanilla,
              bench_len_desc=_bench_len_desc, b64_step=_b64_step, long_text=_long_text, tile_edge=_tile_edge,
              decode_ragged=_decode_ragged)
 
@@ -227,6 +276,13 @@ def run(name: str) -> dict:
             ref = R.tacotron2_fwd(P, d, ci, lens, False, speaker_id=spk, max_len_override=N, training=False, masks=dm, trace=trace)
         return dict(w=w, beta=beta, nstar=nstar, first=first, margin=margin, ref=[x.detach() for x in ref],
                     lengths=trace["lengths"])
+    if kind == "decode_full":
+        N, pm, spk = c["N"], c["pm"], kw["speaker_id"]
+        dm = dict(prenet_drop=[[pm[i, 0], pm[i, 1]] for i in range(N + 1)])
+        trace = {}
+        with torch.no_grad():
+            ref = R.tacotron2_fwd(P, d, ci, lens, False, speaker_id=spk, max_len_override=N, training=False, masks=dm, trace=trace)
+        return dict(ref=[x.detach() for x in ref], lengths=trace["lengths"])
     raise KeyError(name)
 
 

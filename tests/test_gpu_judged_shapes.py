@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import tacotron2_ref as R  # noqa: E402
 from tacotron2_amd.synthetic import ljspeech_batch  # noqa: E402
-from tests.oracle_jobs import DECODE_N, case as job_case  # noqa: E402
+from tests.oracle_jobs import DECODE_FULL_N, DECODE_N, case as job_case  # noqa: E402
 from tests.oracle_pool import oracle, release  # noqa: E402
 from tests.test_gpu_fullsize import _hip_train_and_compare  # noqa: E402
 from tests.test_gpu_model import MEL_L1_TOL, _dev, build_engine, l1, masks_to_device, mx  # noqa: E402
@@ -136,6 +136,34 @@ def test_judged_decode_shape_161_to_221_frames_default_check_every_matches_oracl
     assert torch.equal(mels, mels2) and torch.equal(gates, gates2) and torch.equal(lengths, lengths2)
 
 
+@pytest.mark.oracle("decode_full")
+def test_judged_decode_shape_full_860_frame_horizon_matches_oracle():
+    """Every frame of the benchmarked decode length against the oracle: the bench's 64 utterances (L = 167), 860 frames, a stop
+    projection that cannot stop (bias +50; the stop logic and ragged stops are the test above), prenet masks replayed, the default
+    host-check period.  The autoregressive loop feeds its own fp32 output back through the prenet for 860 frames: the error against
+    the oracle must stay inside the north-star tolerance and must not grow along the horizon (model/tacotron2.py:262-329)."""
+    dev = _dev()
+    c = job_case("decode_full")
+    d, P, (ci, cl, *_), spk, pm, N = c["d"], c["P"], c["case"], c["kw"]["speaker_id"], c["pm"], c["N"]
+    assert ci.shape == (64, 167) and N == DECODE_FULL_N == 860
+    o = oracle("decode_full")
+    ref, ref_lengths = o["ref"], o["lengths"]
+    assert ref[0].shape == (64, N, 80) and bool((ref_lengths == N).all())          # nobody stops: the loop runs to the cap
+    eng, ps = build_engine(d, P, dev)
+    mels, post, gates, al, lengths = eng.infer(ci.to(dev), cl.to(dev), N, speaker_id=spk.to(dev), prenet_masks=pm.to(dev).contiguous())
+    torch.cuda.synchronize()
+    assert mels.shape == ref[0].shape and (lengths.cpu() == ref_lengths).all()
+    em = (mels.double().cpu() - ref[0].double()).abs().mean((0, 2))
+    ea = (al.double().cpu() - ref[3].double()).abs().amax((0, 2))
+    marks = [0, 31, 63, 127, 255, 383, 511, 639, 767, 859]
+    print("decode drift vs oracle over the bench horizon (B=64, L=167, 860 frames): frame: mel L1 / alignment max-abs")
+    print("  " + "  ".join(f"{t + 1}: {float(em[t]):.1e}/{float(ea[t]):.1e}" for t in marks))
+    assert l1(mels, ref[0]) < MEL_L1_TOL and l1(post, ref[1]) < MEL_L1_TOL, (l1(mels, ref[0]), l1(post, ref[1]))
+    assert float(em.max()) < MEL_L1_TOL and mx(al, ref[3]) < 1e-4
+    assert float(em[-100:].mean()) < 4 * float(em[:100].mean()) + 1e-7           # no growth along the horizon
+    release("decode_full")
+
+
 def test_bench_decode_call_properties():
     """The call bench.py times for `decode`: 64 utterances, 860 frames, device Philox prenet masks, check_every = 64, random-init
     weights.  Under random weights the stop logit of an utterance is nearly constant in time (a per-speaker value): some utterances
@@ -199,6 +227,45 @@ def test_descriptions_libritts_per_gpu_shape_forward_matches_oracle():
     assert e0 < MEL_L1_TOL and e1 < MEL_L1_TOL and ea < 2e-5, (e0, e1, ea)
     assert ((outs[2].cpu() == -1000.0) == (ref[2] == -1000.0)).all()
     release("libritts_fwd")
+
+
+@pytest.mark.oracle("judged_fwd_b64")
+def test_shipped_batch_size_64_at_the_judged_lengths_forward_matches_oracle():
+    """config/vanilla-lj-hifi-stop.json's own batch size, 64, at the judged LENGTHS (L = 188, T = 872; the benchmark overrides the
+    batch to 32): 64 utterances of the bench generator, teacher-forced forward in training mode with replayed masks against the oracle -
+    four row tiles / 32 x 32 tiles in the cell steps over 872 frames, the persistent decoder-LSTM launch as two blocks of 32 rows, the
+    encoder recurrence as step launches."""
+    dev = _dev()
+    c = job_case("judged_fwd_b64")
+    d, P, (ci, cl, mel, tl, _, masks), spk = c["d"], c["P"], c["case"], c["kw"]["speaker_id"]
+    B, L = ci.shape
+    T = mel.shape[1]
+    assert B == 64 and L == 188 and T == 872
+    ref = oracle("judged_fwd_b64")["ref"]
+    eng, ps = build_engine(d, P, dev)
+    outs, ctx = eng.forward_tf(ci.to(dev), cl.to(dev), mel.to(dev), tl.to(dev), speaker_id=spk.to(dev), training=True,
+                               masks=masks_to_device(masks, dev))
+    torch.cuda.synchronize()
+    eng.check_persistent_kernels()
+    assert ctx["persist"] and not ctx["enc_persist"]
+    e0, e1, ea = l1(outs[0], ref[0]), l1(outs[1], ref[1]), mx(outs[3], ref[3])
+    print(f"b = 64 at the judged lengths: mel L1 {e0:.2e} / post {e1:.2e}, alignments max-abs {ea:.2e}")
+    assert e0 < MEL_L1_TOL and e1 < MEL_L1_TOL and ea < 2e-5, (e0, e1, ea)
+    assert ((outs[2].cpu() == -1000.0) == (ref[2] == -1000.0)).all()
+    release("judged_fwd_b64")
+
+
+@pytest.mark.oracle("libritts4")
+def test_descriptions_libritts_lengths_four_utterance_step_matches_oracle():
+    """configs[3] gradients at its per-GPU LENGTHS (the forward at the full per-GPU shape is the test above): four utterances of the
+    LibriTTS-shaped batch that keep its longest text and its largest frame count (T > 872: one more pipeline chunk than the LJSpeech
+    batch), E' = 640, 562 speaker tokens, description embeddings - outputs, loss, EVERY parameter gradient, BN statistics."""
+    dev = _dev()
+    c = job_case("libritts4")
+    ci, cl, mel, tl, gate, masks = c["case"]
+    assert ci.shape[0] == 4 and 872 < mel.shape[1] <= 938 and c["d"]["num_speakers"] == 562
+    _hip_train_and_compare(c["d"], c["P"], c["case"], dev, kw_cpu=c["kw"], kw_dev={k: v.to(dev) for k, v in c["kw"].items()},
+                           job="libritts4")
 
 
 @pytest.mark.oracle("b64_step")
