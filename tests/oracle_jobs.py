@@ -52,6 +52,14 @@ def _judged_fwd():
     return dict(d=d, P=P, case=(ci, cl, mel, tl, b["gate"], masks), kw=dict(speaker_id=b["speaker_id"]), kind="fwd")
 
 
+def _judged_step():
+    """The judged configuration ITSELF as a training step: the bench batch (B = 32, L = 188, T = 872, 18,279 valid frames), every
+    parameter gradient.  ~40 s and 15 GB of CPU oracle with 8 threads - affordable only as a background job."""
+    c = _judged_fwd()
+    c["kind"] = "train"
+    return c
+
+
 def _judged4():
     from tacotron2_amd.synthetic import ljspeech_batch
     d = R.default_dims(speaker_tokens=True, num_speakers=4)
@@ -184,7 +192,7 @@ def _decode_full():
                 N=DECODE_FULL_N, kind="decode_full")
 
 
-CASES = dict(judged_fwd=_judged_fwd, judged_fwd_b64=_judged_fwd_b64, libritts4=_libritts4, decode_full=_decode_full, judged4=_judged4, libritts_fwd=_libritts_fwd, bench_len_vanilla=_bench_len_vanilla,
+CASES = dict(judged_fwd=_judged_fwd, judged_step=_judged_step, judged_fwd_b64=_judged_fwd_b64, libritts4=_libritts4, decode_full=_decode_full, judged4=_judged4, libritts_fwd=_libritts_fwd, bench_len_vanilla=_bench_len_vanilla,
              bench_len_desc=_bench_len_desc, b64_step=_b64_step, long_text=_long_text, tile_edge=_tile_edge,
              decode_ragged=_decode_ragged)
 

@@ -17,6 +17,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKERS = int(os.environ.get("T2_ORACLE_WORKERS", "6"))
 THREADS = int(os.environ.get("T2_ORACLE_THREADS", "2"))
+JOB_THREADS = {"judged_step": 8}        # the one job whose autograd graph is big enough to use them (B = 32, T = 872)
 
 _pool = None
 _dir = None
@@ -33,8 +34,9 @@ def _run_child(name, out):
     t0 = time.time()
     if _closing:
         raise RuntimeError("oracle pool is shutting down")
-    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(THREADS))
-    p = subprocess.Popen([sys.executable, "-m", "tests.oracle_jobs", name, out, str(THREADS)], cwd=ROOT, stdout=subprocess.PIPE,
+    nthr = JOB_THREADS.get(name, THREADS)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(nthr))
+    p = subprocess.Popen([sys.executable, "-m", "tests.oracle_jobs", name, out, str(nthr)], cwd=ROOT, stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, text=True, env=env)
     _live[name] = p
     try:

@@ -78,6 +78,20 @@ def test_judged_train_shape_forward_matches_oracle():
     release("judged_fwd")
 
 
+@pytest.mark.oracle("judged_step")
+def test_judged_train_shape_full_step_every_gradient_matches_oracle():
+    """THE judged configuration as a whole training step: the bench batch - B = 32, L = 188, T = 872, 18,279 valid frames, vanilla-lj-hifi
+    dims with 4 speaker tokens - forward, 3-term loss and the complete backward with the bench's schedule untouched, against the
+    oracle's autograd: outputs, loss, EVERY parameter gradient (28 M values), BatchNorm statistics.  (Round 4 could afford this only on
+    four utterances; the oracle side is now a background job: ~40 s of CPU with 8 threads while other GPU tests run.)"""
+    dev = _dev()
+    c = job_case("judged_step")
+    ci, cl, mel, tl, gate, masks = c["case"]
+    assert (ci.shape[0], ci.shape[1], mel.shape[1]) == (32, 188, 872) and int(tl.sum()) == 18279
+    _hip_train_and_compare(c["d"], c["P"], c["case"], dev, kw_cpu=c["kw"], kw_dev={k: v.to(dev) for k, v in c["kw"].items()},
+                           check_engine=lambda e: _bench_schedule(e, 872), job="judged_step")
+
+
 @pytest.mark.oracle("judged4")
 def test_judged_train_lengths_four_utterance_step_matches_oracle():
     """Gradients at the judged LENGTHS: the utterances of the bench batch with the longest text (188), the most frames (872) and
