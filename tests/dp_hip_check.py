@@ -28,18 +28,31 @@ def main():
     from tacotron2_amd.trainer import Trainer
     from tests.test_gpu_model import masks_to_device, random_case
     sync_bn = "--per-shard-bn" not in sys.argv
-    d = R.default_dims(num_chars=39, encoded_dim=128, prenet_dim=64, att_rnn_dim=256, att_dim=64, rnn_hidden_dim=256,
-                       postnet_dim=128, num_mels=80, dropout=0.5, speaker_tokens=True, num_speakers=4)
-    P = R.init_params(d, seed=12)
-    Bt, L, T = 6, 27, 22
-    ci, lens, mel, tl, gate, masks = random_case(d, Bt, L, T, 41, dev)
-    spk = torch.tensor([0, 3, 1, 1, 2, 0], dtype=torch.int32)
+    judged = "--judged" in sys.argv
+    if judged:
+        # BASELINE configs[1]/[2] dims and data: vanilla-lj-hifi dims, the bench batch (32 utterances, L = 188, T = 872) sharded over
+        # the ranks by utterance - what every GPU of the data-parallel job runs, against the single-process step on the whole batch
+        from tests.oracle_jobs import case as job_case
+        c = job_case("judged_fwd")
+        d, P = c["d"], c["P"]
+        ci, lens, mel, tl, gate, masks = c["case"]
+        spk = c["kw"]["speaker_id"]
+        Bt = ci.shape[0]
+    else:
+        d = R.default_dims(num_chars=39, encoded_dim=128, prenet_dim=64, att_rnn_dim=256, att_dim=64, rnn_hidden_dim=256,
+                           postnet_dim=128, num_mels=80, dropout=0.5, speaker_tokens=True, num_speakers=4)
+        P = R.init_params(d, seed=12)
+        Bt, L, T = 6, 27, 22
+        ci, lens, mel, tl, gate, masks = random_case(d, Bt, L, T, 41, dev)
+        spk = torch.tensor([0, 3, 1, 1, 2, 0], dtype=torch.int32)
     ps = ParamStore(d, dev); ps.load_state_dict(P)
     overlap = "--one-allreduce" not in sys.argv
     tr = Trainer(ps, lr=1e-3, weight_decay=1e-6, max_norm=1.0, sync_bn=sync_bn, overlap_allreduce=overlap)
     # (with synchronised BatchNorm the gradient goes as one call: the small statistics reduces of the encoder backward would queue
     #  behind an overlapped tail bucket on the communicator's stream - Trainer.__init__)
     assert tr.world == world and tr.sync_bn == sync_bn and tr.overlap_allreduce == (overlap and not sync_bn)
+    if judged:      # two processes on ONE card: their 256-workgroup persistent launches cannot promise each other co-residency
+        tr.engine.dec_chain = "steps"; tr.engine.enc_chain = "steps"
     tail0 = ps.offsets["prenet.0.weight"]
     hook_tail = []
     if tr.overlap_allreduce:       # what the tail bucket held when its all-reduce was started (side stream, inside the hook)
