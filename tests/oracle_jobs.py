@@ -178,18 +178,23 @@ def _decode_ragged():
 DECODE_FULL_N = 860
 
 
-def _decode_full():
+def _decode_full(spec=""):
     """The bench's decode call at its FULL horizon: 64 utterances (L = 167), 860 frames, a stop projection that never stops (bias +50),
-    prenet masks replayed - every frame of the benchmarked length against the oracle (the ragged case above covers the stop logic)."""
+    prenet masks replayed - every frame of the benchmarked length against the oracle (the ragged case above covers the stop logic).
+    spec "B-N": the first B of those utterances for N frames (B = 1: the reference's own `say` shape, run/say.py:139-149; the
+    <= 16-row and 17-32-row instantiations of the step kernels over a long horizon)."""
     from tacotron2_amd.synthetic import ljspeech_batch
+    B, N = (int(x) for x in spec.split("-")) if spec else (64, DECODE_FULL_N)
     d = R.default_dims(speaker_tokens=True, num_speakers=4)
     P = R.init_params(d, seed=67)
     P["decoder.gate.bias"] = torch.full_like(P["decoder.gate.bias"], 50.0)
     ib = ljspeech_batch(64, seed=4321, num_speakers=4)
+    cl = ib["chars_idx_len"][:B].clone()
+    ci = ib["chars_idx"][:B, :int(cl.max())].contiguous()
     g = torch.Generator().manual_seed(68)
-    pm = (torch.rand(DECODE_FULL_N + 1, 2, 64, 256, generator=g) >= 0.5).float() * 2
-    return dict(d=d, P=P, case=(ib["chars_idx"], ib["chars_idx_len"], None, None, None, None), kw=dict(speaker_id=ib["speaker_id"]), pm=pm,
-                N=DECODE_FULL_N, kind="decode_full")
+    pm = (torch.rand(N + 1, 2, 64, 256, generator=g) >= 0.5).float()[:, :, :B].contiguous() * 2
+    return dict(d=d, P=P, case=(ci, cl, None, None, None, None), kw=dict(speaker_id=ib["speaker_id"][:B].clone()), pm=pm, N=N,
+                kind="decode_full")
 
 
 CASES = dict(judged_fwd=_judged_fwd, judged_step=_judged_step, judged_fwd_b64=_judged_fwd_b64, libritts4=_libritts4, decode_full=_decode_full, judged4=_judged4, libritts_fwd=_libritts_fwd, bench_len_vanilla=_bench_len_vanilla,

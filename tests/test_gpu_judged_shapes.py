@@ -178,6 +178,29 @@ def test_judged_decode_shape_full_860_frame_horizon_matches_oracle():
     release("decode_full")
 
 
+@pytest.mark.oracle("decode_full:{B}-{N}")
+@pytest.mark.parametrize("B,N", [(1, 860), (32, 300)])
+def test_decode_long_horizon_at_one_and_32_utterances_matches_oracle(B, N):
+    """The same long-horizon check for the other instantiations of the decode loop's kernels: ONE utterance for 860 frames - the
+    reference's own `say` shape (run/say.py:139-149: batch 1; the <= 16-row step kernels, one 16-row MFMA tile with a single live row) -
+    and 32 utterances for 300 frames (the two-tile step kernels), vanilla dims, against the oracle frame by frame."""
+    dev = _dev()
+    c = job_case(f"decode_full:{B}-{N}")
+    d, P, (ci, cl, *_), spk, pm = c["d"], c["P"], c["case"], c["kw"]["speaker_id"], c["pm"]
+    assert ci.shape[0] == B and c["N"] == N and pm.shape == (N + 1, 2, B, 256)
+    o = oracle(f"decode_full:{B}-{N}")
+    ref, ref_lengths = o["ref"], o["lengths"]
+    assert ref[0].shape == (B, N, 80)
+    eng, ps = build_engine(d, P, dev)
+    mels, post, gates, al, lengths = eng.infer(ci.to(dev), cl.to(dev), N, speaker_id=spk.to(dev), prenet_masks=pm.to(dev).contiguous())
+    torch.cuda.synchronize()
+    assert mels.shape == ref[0].shape and (lengths.cpu() == ref_lengths).all()
+    em = (mels.double().cpu() - ref[0].double()).abs().mean((0, 2))
+    print(f"decode drift vs oracle, B={B}, {N} frames: mel L1 at frame 1 / {N // 2} / {N}: {float(em[0]):.1e} / {float(em[N // 2 - 1]):.1e} / {float(em[-1]):.1e}")
+    assert l1(mels, ref[0]) < MEL_L1_TOL and l1(post, ref[1]) < MEL_L1_TOL and float(em.max()) < MEL_L1_TOL and mx(al, ref[3]) < 1e-4
+    assert float(em[-50:].mean()) < 4 * float(em[:50].mean()) + 1e-7
+
+
 def test_bench_decode_call_properties():
     """The call bench.py times for `decode`: 64 utterances, 860 frames, device Philox prenet masks, check_every = 64, random-init
     weights.  Under random weights the stop logit of an utterance is nearly constant in time (a per-speaker value): some utterances
