@@ -89,9 +89,13 @@ def test_cli_train_on_wav_manifest_resume(tmp_path):
     res = tmp_path / "res"
     _run(["--config", str(cfg), "train", "--speech-dir", str(speech), "--results-dir", str(res), "--max-steps", "2"])
     assert os.path.exists(res / "final.ckpt") and len(os.listdir(res / "mel_cache")) >= 3
+    # the resumed run takes the item-at-a-time loader (training.loader = "items": TTSDataset.__getitem__ + collate, the reference's
+    # own structure, kept for A/B runs; the first run used the default batched device loader) - and finds the first run's cache
+    c = json.loads(cfg.read_text()); c["training"]["loader"] = "items"; cfg.write_text(json.dumps(c))
     out = _run(["--config", str(cfg), "train", "--speech-dir", str(speech), "--results-dir", str(res), "--max-steps", "4",
                 "--resume-ckpt", str(res / "final.ckpt")])
     assert "step 3/4" in out or "step 4/4" in out
+    assert "input pipeline:" not in out                    # (that line is the batched loader's; the first run printed it)
     # train-mel-export (run/train_mel_export.py): teacher-forced post-net mels of train + val manifests, one file per wav
     exp = tmp_path / "export"
     _run(["--config", str(cfg), "train-mel-export", "--speech-dir", str(speech), "--checkpoint", str(res / "final.ckpt"),
