@@ -156,7 +156,10 @@ def launch_ranks(args, argv) -> int:
                    GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES", "16"),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
                    OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", str(max(1, cores // n))))
-        plan.append(dict(cmd=[sys.executable, os.path.abspath(__file__)] + child_argv, env=env))
+        cmd = [sys.executable, os.path.abspath(__file__)] + child_argv
+        if os.environ.get("T2_BENCH_CHILD_CMD"):        # test hook (tests/test_bench_launcher.py): stand-in ranks
+            cmd = os.environ["T2_BENCH_CHILD_CMD"].split()
+        plan.append(dict(cmd=cmd, env=env))
     if args.dry_run_launch:
         print(json.dumps(dict(launch=plan, note="dry run: nothing started, no GPU call made")), flush=True)
         return 0
@@ -174,11 +177,22 @@ def launch_ranks(args, argv) -> int:
                                       stdout=None if r == 0 else sys.stderr))
     print(f"[bench] launcher: started {n} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}", file=sys.stderr, flush=True)
     deadline, first_fail, grace = (time.time() + args.launch_timeout if args.launch_timeout > 0 else None), None, 20.0
+    # a launcher that is told to stop (the driver's time limit, Ctrl-C) takes its ranks with it - nothing is left running on the GPUs
+    import signal
+    stop = {"sig": None}
+
+    def on_signal(signum, frame):
+        stop["sig"] = signum
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sg, on_signal)
     while True:
         rcs = [p.poll() for p in procs]
         if all(rc is not None for rc in rcs):
             break
         now = time.time()
+        if stop["sig"] is not None and deadline is None:
+            print(f"[bench] launcher: signal {stop['sig']}: ending the ranks", file=sys.stderr, flush=True)
+            deadline = now - 1
         if first_fail is None and any(rc not in (None, 0) for rc in rcs):
             first_fail = now
             bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]

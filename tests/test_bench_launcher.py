@@ -59,3 +59,33 @@ def test_launcher_relays_the_worst_return_code_and_leaves_no_child_behind():
     # without --share-gpu the launcher itself refuses: fewer devices than ranks
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2"], cwd=ROOT, capture_output=True, text=True, timeout=300, env=_env())
     assert r.returncode == 2 and "shows 0 GPU" in r.stderr
+
+
+def test_a_terminated_launcher_takes_its_ranks_with_it(tmp_path):
+    """SIGTERM to the launcher (the driver's time limit) must end the child ranks too.  The children here are stand-ins that sleep:
+    the launcher is pointed at them through T2_BENCH_CHILD_CMD (test hook), writes their PIDs to stderr, gets SIGTERM after they
+    have started, and must come back within seconds with every child gone."""
+    import re
+    import signal
+    child = tmp_path / "sleeper.py"
+    child.write_text("import time, sys\nprint('up', flush=True)\ntime.sleep(600)\n")
+    p = subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--share-gpu", "--backend", "gloo"], cwd=ROOT, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, env=dict(_env(), T2_BENCH_CHILD_CMD=f"{sys.executable} {child}"))
+    line = ""
+    t0 = time.time()
+    while "started 2 ranks" not in line and time.time() - t0 < 120:
+        line = p.stderr.readline()
+    pids = [int(x) for x in re.search(r"pids \[([0-9, ]+)\]", line).group(1).split(",")]
+    assert len(pids) == 2
+    time.sleep(1.0)
+    p.send_signal(signal.SIGTERM)
+    rc = p.wait(timeout=60)
+    assert rc != 0
+    time.sleep(0.5)
+    for pid in pids:
+        try:
+            os.kill(pid, 0)
+            alive = True
+        except ProcessLookupError:
+            alive = False
+        assert not alive, f"child {pid} survived its launcher"
