@@ -12,6 +12,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "gpu_processes(n): the test has n processes on the GPU at once (itself included); more than 2 "
+                                       "reserve their share of the box's limit of 6 from the background oracle jobs")
     config.addinivalue_line("markers", "oracle(name): the test reads the CPU-oracle job `name` of tests/oracle_jobs.py; the jobs of all "
                                        "selected tests are started as background CPU processes when the session starts "
                                        "('{L}' in the name is filled from the test's parameters)")
@@ -42,6 +44,16 @@ def pytest_sessionfinish(session, exitstatus):
             print("\n[oracle pool] job: (seconds the test waited, seconds the job took) " +
                   ", ".join(f"{k}: {v}" for k, v in pool.waited_s.items()))
         pool.shutdown()
+
+
+@pytest.fixture(autouse=True)
+def _gpu_process_share(request):
+    m = request.node.get_closest_marker("gpu_processes")
+    if m is None or "tests.oracle_pool" not in sys.modules:
+        yield
+        return
+    with sys.modules["tests.oracle_pool"].reserve(int(m.args[0])):
+        yield
 
 
 @pytest.fixture(scope="session")

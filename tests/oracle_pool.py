@@ -15,7 +15,12 @@ from concurrent.futures import ThreadPoolExecutor
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-WORKERS = int(os.environ.get("T2_ORACLE_WORKERS", "6"))
+# The GPU box admits 6 processes with the device open at once.  A job is a CPU process, but torch's autograd engine enumerates the
+# devices when its worker threads start and holds /dev/kfd open for ~0.3 s while it does (seen with HIP_VISIBLE_DEVICES empty too) -
+# so a running job may count against that limit at any moment.  4 workers + the test process + one child process of a CLI test = 6;
+# tests that start more GPU processes reserve their share first (`gpu_processes` marker -> reserve()).
+WORKERS = int(os.environ.get("T2_ORACLE_WORKERS", "4"))
+GPU_PROCESS_LIMIT = 6
 THREADS = int(os.environ.get("T2_ORACLE_THREADS", "2"))
 JOB_THREADS = {"judged_step": 8}        # the one job whose autograd graph is big enough to use them (B = 32, T = 872)
 
@@ -28,12 +33,53 @@ waited_s = {}
 
 _live = {}          # name -> Popen of a job that is running (ended by exact PID at shutdown)
 _closing = False
+import threading
+_cv = threading.Condition()
+_running = 0
+_cap = WORKERS      # jobs allowed to run at once right now (lowered while a test with several GPU processes runs)
+
+
+class reserve:
+    """with reserve(n): ...  - a test that will have `n` processes on the GPU (itself included).  Lowers the number of oracle jobs
+    that may run to GPU_PROCESS_LIMIT - n and waits until no more than that many are running."""
+
+    def __init__(self, n: int):
+        self.cap = max(0, GPU_PROCESS_LIMIT - int(n))
+
+    def __enter__(self):
+        global _cap
+        with _cv:
+            _cap = min(WORKERS, self.cap)
+            while _running > _cap and not _closing:
+                _cv.wait(timeout=1.0)
+        return self
+
+    def __exit__(self, *exc):
+        global _cap
+        with _cv:
+            _cap = WORKERS
+            _cv.notify_all()
+        return False
 
 
 def _run_child(name, out):
+    global _running
+    with _cv:
+        while _running >= _cap and not _closing:
+            _cv.wait(timeout=1.0)
+        if _closing:
+            raise RuntimeError("oracle pool is shutting down")
+        _running += 1
+    try:
+        return _run_child_now(name, out)
+    finally:
+        with _cv:
+            _running -= 1
+            _cv.notify_all()
+
+
+def _run_child_now(name, out):
     t0 = time.time()
-    if _closing:
-        raise RuntimeError("oracle pool is shutting down")
     nthr = JOB_THREADS.get(name, THREADS)
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(nthr))
     p = subprocess.Popen([sys.executable, "-m", "tests.oracle_jobs", name, out, str(nthr)], cwd=ROOT, stdout=subprocess.PIPE,
@@ -89,6 +135,8 @@ def shutdown():
     handles started here - so nothing is left computing behind a finished test run."""
     global _pool, _closing
     _closing = True
+    with _cv:
+        _cv.notify_all()
     if _pool is not None:
         for f in _futures.values():
             f.cancel()

@@ -177,6 +177,7 @@ def test_cli_train_data_parallel_step_over_rccl_never_blocks_the_host(tmp_path):
     assert ck["global_step"] == 5
 
 
+@pytest.mark.gpu_processes(3)
 def test_cli_train_two_ranks_on_a_wav_manifest(tmp_path):
     """`main.py train` as two ranks (torch.distributed.run; gloo, both on cuda:0 - RCCL needs a GPU per rank) on a real WAV
     manifest: utterances sharded by rank (3 each, batch 1: an epoch is 3 steps, the 5 steps cross it), every batch padded to the
@@ -197,6 +198,7 @@ def test_cli_train_two_ranks_on_a_wav_manifest(tmp_path):
     assert ck["global_step"] == 5 and "saved" in r.stdout
 
 
+@pytest.mark.gpu_processes(3)
 def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
     """`python bench.py --gpus 2` with NO launcher around it (no WORLD_SIZE): bench.py starts its own two ranks as fresh child
     processes before any GPU call (launch_ranks) and relays rank 0's line.  The data-parallel code path end to end on the GPU
@@ -221,6 +223,7 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
     assert "launcher: started 2 ranks" in r.stderr
 
 
+@pytest.mark.gpu_processes(5)
 def test_bench_four_ranks_rehearsal_on_one_gpu(tmp_path):
     """`bench.py --gpus 4` under an EXTERNAL launcher (torch.distributed.run: WORLD_SIZE set, bench.py is one rank - the form the
     task statement gives for the driver; the two-rank rehearsal above covers the plain command line), rehearsed with four ranks on cuda:0 over gloo (the GPU box admits six

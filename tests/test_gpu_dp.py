@@ -7,7 +7,7 @@ import sys
 
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.gpu_processes(3)]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
