@@ -121,3 +121,24 @@ def test_device_batch_loader_equals_the_item_path_and_collate(tmp_path, cache):
     got = hb.to_device(dev)
     assert got["chars_idx"].shape == (3, hb.L + 3) and got["mel_spectrogram"].shape == (3, hb.T + 7, 80) and got["gate"].shape == (3, hb.T + 7, 1)
     assert float(got["mel_spectrogram"][:, hb.T:].abs().max()) == 0.0 and int(got["chars_idx"][:, hb.L:].sum()) == 0
+
+
+def test_device_logmel_against_an_fft_based_restatement():
+    """An independent route to the same definition (datasets/prosody_dataset.py:39-50,67 of the reference): torch.stft (an FFT, centred,
+    reflect padding, periodic Hann) -> magnitude -> the slaney filterbank -> log(clamp(1e-5)).  The device path computes the DFT as a
+    GEMM against a window-folded cos/sin basis; oracle/logmel_ref.py uses numpy's FFT on explicitly framed windows.  Three routes, one
+    result (still PARITY-UNPINNED against the reference's own `speech_utils`, which is not available)."""
+    from oracle.logmel_ref import mel_filterbank
+    from tacotron2_amd.datasets.logmel import TacotronMelSpectrogram
+    dev = _dev()
+    fe = TacotronMelSpectrogram(device=dev)
+    x = torch.from_numpy(_signals([50000], seed=21)[0])
+    got = fe(x, id="0").double().cpu()
+    spec = torch.stft(x.double(), 1024, 256, 1024, torch.hann_window(1024, periodic=True, dtype=torch.float64), center=True,
+                      pad_mode="reflect", return_complex=True).abs().T                       # (frames, 513)
+    fb = torch.from_numpy(mel_filterbank(22050, 1024, 80, 0.0, 8000.0))                         # (80, 513)
+    ref = torch.log(torch.clamp(spec @ fb.T, min=1e-5))
+    assert got.shape == ref.shape == (1 + 50000 // 256, 80)
+    assert float((got - ref).abs().max()) < 2e-3 and float((got - ref).abs().mean()) < 1e-4
+    # and the product's own filterbank is the restatement's (built independently in tacotron2_amd/datasets/logmel.py)
+    assert float((fe.fb[:, :513].double().cpu() - fb).abs().max()) < 1e-6
