@@ -210,3 +210,43 @@ def test_dp2_without_a_host_side_group_the_shape_is_agreed_on_the_main_thread_on
         mp.spawn(_no_host_group_worker, args=(world, port, out), nprocs=world, join=True)
         out = dict(out)
     assert out[0] == out[1] == (6, 9, 9)
+
+
+class _FakeWavBatch:
+    """Stands in for datasets.tts_dataset.HostWavBatch: the host half of a training batch, whose padded lengths are host integers."""
+
+    def __init__(self, L, T):
+        self.L, self.T, self.Lg, self.Tg = L, T, L, T
+
+    def set_global_shape(self, Lg, Tg):
+        assert Lg >= self.L and Tg >= self.T
+        self.Lg, self.Tg = Lg, Tg
+
+
+def _wavbatch_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from tacotron2_amd.params import ParamStore
+    from tacotron2_amd.trainer import Trainer
+    tr = Trainer(ParamStore(R.default_dims(**SMALL, dropout=0.0), "cpu"), lr=1e-3, weight_decay=1e-6)
+    shapes = [(17 + 5 * rank, 300 - 40 * rank), (9, 120 + 7 * rank), (30 - rank, 512)]
+    got = []
+    for L, T in shapes:
+        hb = tr.negotiate_collated(_FakeWavBatch(L, T))        # the loader thread's hook, DeviceBatchLoader's batch type
+        got.append((hb.Lg, hb.Tg))
+    out[rank] = got
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp2_device_batch_loader_batches_negotiate_their_shape_from_host_integers():
+    """A batch of the device-resident loader knows its padded (L, T) on the host (frames = 1 + samples // hop) before anything is on
+    the device: Trainer.negotiate_collated agrees the step's global shape over the host-side group and only RECORDS it
+    (set_global_shape); the batched log-mel pass then writes straight into a tensor of that shape."""
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_wavbatch_worker, args=(world, port, out), nprocs=world, join=True)
+        out = dict(out)
+    assert out[0] == out[1] == [(22, 300), (9, 127), (30, 512)]
