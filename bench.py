@@ -340,6 +340,31 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
 
+    # Data-parallel runs also time the OTHER gradient all-reduce mode (one call after the backward <-> two buckets, the larger one started
+    # behind the frame loop) for a few steps, outside the judged region: the default was chosen at world size 1, where the collective
+    # is a device-local pass; a real multi-GPU run is the only place the choice can be measured.  Every rank takes part.
+    other_mode = None
+    if tr.dp and not tr.sync_bn:
+        was = tr.overlap_allreduce
+        tr.overlap_allreduce = not was
+        tr.engine.grad_tail_hook = tr._start_tail_allreduce if tr.overlap_allreduce else None
+        for _ in range(2):
+            tr.train_step(batch, padded=True)
+        sync()
+        to0 = time.perf_counter()
+        n_other = min(args.steps, 8)
+        for _ in range(n_other):
+            tr.train_step(batch, padded=True)
+        sync()
+        dto = torch.tensor([time.perf_counter() - to0], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(dto, op=dist.ReduceOp.MAX)
+        other_mode = dict(allreduce="2 buckets, tail overlapped with the encoder backward" if tr.overlap_allreduce else "1 call after the backward",
+                          ms_per_step=float(dto) / n_other * 1e3, steps=n_other,
+                          note="the non-default all-reduce mode, timed beside the judged line (not the judged value)")
+        tr.overlap_allreduce = was
+        tr.engine.grad_tail_hook = tr._start_tail_allreduce if was else None
+
     # the same step with the GEMMs at the precision the reference's shipped configs ask for (training.float32_matmul_precision =
     # "high", run/train.py:170: three of the six bf16 partial products; mel L1 against the fp32 oracle stays < 1e-4,
     # tests/test_gpu_fullsize.py).  Reported beside the judged fp32-exact line, never as `value`.
@@ -466,7 +491,7 @@ def main():
                                  us_per_decoder_step=dec_fwd_ms * 1e3 / T if T else None),
                    segments_ms={k: round(v, 3) for k, v in seg.items()},
                    per_rank=[{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in per_rank],
-                   decode=decode, decode_b1=decode_b1, matmul_precision_high=high)
+                   other_allreduce_mode=other_mode, decode=decode, decode_b1=decode_b1, matmul_precision_high=high)
         # HBM-side bytes of the same kernels from rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE, profiles/):
         # recorded offline because counters cannot be collected inside this process
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")

@@ -221,6 +221,9 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
     assert [x["rank"] for x in pr] == [0, 1] and all(x["ms_per_step"] > 0 and x["gpu_step_ms"] > 0 and x["allreduce_ms"] >= 0 for x in pr)
     assert d["config"]["queue_check"]["ok"] is True and all(x["queue_check_ok"] for x in pr)
     assert "launcher: started 2 ranks" in r.stderr
+    # the other all-reduce mode is timed beside the judged line, so that a multi-GPU run can settle the default
+    om = d["other_allreduce_mode"]
+    assert om["allreduce"].startswith("2 buckets") and om["ms_per_step"] > 0
 
 
 @pytest.mark.gpu_processes(5)
