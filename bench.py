@@ -340,6 +340,26 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
 
+    # ... and the gradient all-reduce ALONE, behind a barrier (nobody waits for a slower rank's backward): the wire time of the 112.5 MB
+    # buffer, to set against the `allreduce` segment of the step (wire + waiting)
+    allreduce_alone = None
+    if tr.dp:
+        sync()
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist.all_reduce(ps.grad)
+        sync()
+        ea.record()
+        for _ in range(5):
+            dist.all_reduce(ps.grad)
+        eb.record()
+        torch.cuda.synchronize()
+        t_ar = torch.tensor([ea.elapsed_time(eb) / 5], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t_ar, op=dist.ReduceOp.MAX)
+        nbytes = ps.numel * 4
+        allreduce_alone = dict(ms=float(t_ar), bytes=nbytes, algbw_GBs=nbytes / (float(t_ar) * 1e-3) / 1e9,
+                               busbw_GBs=(2 * (world - 1) / world if world > 1 else 0.0) * nbytes / (float(t_ar) * 1e-3) / 1e9)
+
     # Data-parallel runs also time the OTHER gradient all-reduce mode (one call after the backward <-> two buckets, the larger one started
     # behind the frame loop) for a few steps, outside the judged region: the default was chosen at world size 1, where the collective
     # is a device-local pass; a real multi-GPU run is the only place the choice can be measured.  Every rank takes part.
@@ -491,7 +511,7 @@ def main():
                                  us_per_decoder_step=dec_fwd_ms * 1e3 / T if T else None),
                    segments_ms={k: round(v, 3) for k, v in seg.items()},
                    per_rank=[{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in per_rank],
-                   other_allreduce_mode=other_mode, decode=decode, decode_b1=decode_b1, matmul_precision_high=high)
+                   allreduce_alone=allreduce_alone, other_allreduce_mode=other_mode, decode=decode, decode_b1=decode_b1, matmul_precision_high=high)
         # HBM-side bytes of the same kernels from rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE, profiles/):
         # recorded offline because counters cannot be collected inside this process
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")

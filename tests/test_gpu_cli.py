@@ -222,6 +222,7 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
     assert d["config"]["queue_check"]["ok"] is True and all(x["queue_check_ok"] for x in pr)
     assert "launcher: started 2 ranks" in r.stderr
     # the other all-reduce mode is timed beside the judged line, so that a multi-GPU run can settle the default
+    assert d["allreduce_alone"]["bytes"] > 1e6 and d["allreduce_alone"]["ms"] > 0
     om = d["other_allreduce_mode"]
     assert om["allreduce"].startswith("2 buckets") and om["ms_per_step"] > 0
 
